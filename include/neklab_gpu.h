@@ -1,0 +1,225 @@
+/*
+ * neklab_gpu.h -- C ABI of the MI355X-native hot path of nekStab/neklab.
+ *
+ * Drop-in boundary: the reference consumes this path through Fortran 2008 type-bound
+ * procedures of LightKrylov's abstract_vector_rdp / abstract_exptA_linop_rdp.  A Fortran shim
+ * (neklab_amd/fortran/neklab_gpu.f90) extends those abstract types and forwards every binding to one
+ * entry point of this header through ISO_C_BINDING.  Each declaration cites the reference interface
+ * (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, non-zero = error (text in nlg_last_error()).  The reference
+ *     has no status codes on the vector API and aborts through type_error / stop_error
+ *     (src/vectors/real_vectors.f90:202-204, src/neklab_nek_setup.f90:406-417); the shim turns a
+ *     non-zero return into stop_error.
+ *   - handles are opaque; all field data lives in HBM and is owned by the library.
+ *   - host arrays handed in are plain double / int64_t arrays in Nek5000's element-major layout
+ *     ijke = ix + n*(iy + n*(iz + n*e))   (src/vectors/real_vectors.f90:69).
+ *   - single-threaded per rank, every call collective across ranks (SURVEY.md §8b "Threading").
+ *   - there is NO CPU fallback: every entry point fails with an error if no HIP device is usable.
+ */
+#ifndef NEKLAB_GPU_H
+#define NEKLAB_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nlg_ctx nlg_ctx;     /* device + stream + communicator                                   */
+typedef struct nlg_mesh nlg_mesh;   /* SEM discretisation: what Nek5000 keeps in SIZE/TOTAL commons     */
+typedef struct nlg_vec nlg_vec;     /* nek_dvector  (src/vectors/neklab_vectors.f90:26-50)               */
+typedef struct nlg_basis nlg_basis; /* array of nek_dvector as LightKrylov allocates for the Krylov basis */
+typedef struct nlg_linop nlg_linop; /* exptA_linop  (src/linops/neklab_linops.f90:35-44)                 */
+
+/* field selectors for nlg_vec_set_field / nlg_vec_get_field */
+enum { NLG_VX = 0, NLG_VY = 1, NLG_VZ = 2, NLG_PR = 3, NLG_THETA = 4 /* + scalar index */ };
+
+/* ---------------------------------------------------------------------------------------------- */
+/* context                                                                                          */
+/* ---------------------------------------------------------------------------------------------- */
+const char *nlg_last_error(void);
+int nlg_version(void);
+int nlg_ctx_create(int device, nlg_ctx **out);
+int nlg_ctx_destroy(nlg_ctx *ctx);
+int nlg_ctx_sync(nlg_ctx *ctx);
+/* RCCL communicator over xGMI: rank 0 calls nlg_comm_unique_id, the 128 bytes are broadcast by the
+ * host program (MPI_Bcast in a Nek5000 host, torch.distributed in bench.py), every rank then calls
+ * nlg_ctx_comm_init.  Replaces the MPI_Allreduce inside glsc3 (src/vectors/real_vectors.f90:217-224). */
+int nlg_comm_unique_id(void *out128);
+int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id128);
+int nlg_ctx_rank(const nlg_ctx *ctx, int *rank, int *nranks);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* mesh: replaces the Nek5000 commons the reference reads through include "SIZE"/"TOTAL"            */
+/* (src/vectors/neklab_vectors.f90:8-14: lx1, lelv, lv, lp; real_vectors.f90: xm1, ym1, zm1, bm1,   */
+/*  vmult, v1mask..v3mask, lglel; gather-scatter handle behind opdssum/dsavg :100-104)              */
+/* ---------------------------------------------------------------------------------------------- */
+typedef struct nlg_mesh_desc {
+    int dim;                /* ldim: 2 or 3                                           */
+    int n;                  /* lx1 (= ly1 = lz1 in 3-D); pressure mesh is lx2 = n - 2 */
+    int lxd;                /* dealiasing points, 0 => 3*n/2                          */
+    int64_t nelv;           /* local element count                                    */
+    const double *xm1;      /* [nelv * n^dim] GLL coordinates                         */
+    const double *ym1;
+    const double *zm1;      /* NULL in 2-D                                            */
+    const int64_t *glo_num; /* [nelv * n^dim] global (assembled) dof labels           */
+    const int64_t *lglel;   /* [nelv] global element ids (0-based), NULL => 0..nelv-1 */
+    const double *v1mask;   /* [nelv * n^dim] Dirichlet masks, 0/1                    */
+    const double *v2mask;
+    const double *v3mask;   /* NULL in 2-D                                            */
+    const double *tmask;    /* NULL => no scalar mask                                 */
+    int has_outflow;        /* 0 => pressure defined up to a constant (Nek ifvcor)    */
+} nlg_mesh_desc;
+
+int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *desc, nlg_mesh **out);
+int nlg_mesh_destroy(nlg_mesh *mesh);
+int nlg_mesh_sizes(const nlg_mesh *mesh, int64_t *lvn, int64_t *lpn, int *dim, int *n);
+/* read back a derived array by name for verification: "bm1", "binvm1", "vmult", "jac", "bm2",
+ * "g11".."g33" (Nek g1m1..g6m1 ordering by index pair), "rxm1"... (as "rst11".."rst33") */
+int nlg_mesh_get(const nlg_mesh *mesh, const char *name, double *out, int64_t count);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* nek_dvector                                                                                      */
+/* ---------------------------------------------------------------------------------------------- */
+/* type(nek_dvector) storage, src/vectors/neklab_vectors.f90:26-36; nscal = active scalars (ifto /
+ * ifpsco), lorder as in SIZE (restart history holds lorder-1 slots). */
+int nlg_vec_create(nlg_mesh *mesh, int nscal, int lorder, nlg_vec **out);
+int nlg_vec_destroy(nlg_vec *v);
+/* Fortran intrinsic assignment / sourced allocation of a nek_dvector */
+int nlg_vec_clone(const nlg_vec *src, nlg_vec **out);
+int nlg_vec_copy(nlg_vec *dst, const nlg_vec *src);
+/* nek_dzero   src/vectors/real_vectors.f90:37-50   (interface neklab_vectors.f90:65-67) */
+int nlg_vec_zero(nlg_vec *self);
+/* nek_drand   real_vectors.f90:52-123   (interface :69-72); seed replaces the compiler RNG */
+int nlg_vec_rand(nlg_vec *self, int ifnorm, uint64_t seed);
+/* nek_dscal   real_vectors.f90:125-160  (interface :74-77) */
+int nlg_vec_scal(nlg_vec *self, double alpha);
+/* nek_daxpby  real_vectors.f90:162-206  (interface :79-84): self = alpha*vec + beta*self */
+int nlg_vec_axpby(double alpha, const nlg_vec *vec, double beta, nlg_vec *self);
+/* nek_ddot    real_vectors.f90:208-233  (interface :86-89): globally reduced, same on all ranks */
+int nlg_vec_dot(const nlg_vec *self, const nlg_vec *vec, double *out);
+/* %norm() inherited from abstract_vector_rdp, used at real_vectors.f90:117 */
+int nlg_vec_norm(const nlg_vec *self, double *out);
+/* nek_dsize   real_vectors.f90:235-247  (interface :91-93) */
+int nlg_vec_size(const nlg_vec *self, int64_t *out);
+/* dsave_rst / dget_rst / dhas_rst_fields / dclear_rst_fields  real_vectors.f90:249-346 (irst 1-based) */
+int nlg_vec_save_rst(nlg_vec *self, const nlg_vec *vec_rst, int irst);
+int nlg_vec_get_rst(const nlg_vec *self, nlg_vec *vec_rst, int irst);
+int nlg_vec_has_rst_fields(const nlg_vec *self, int *out);
+int nlg_vec_clear_rst_fields(nlg_vec *self);
+int nlg_vec_nrst(const nlg_vec *self, int *out);
+/* nek2vec / vec2nek  src/neklab_utils.f90:84-134 (nopcopy :279-301): move one field between a host
+ * array and the vector.  field = NLG_VX.., irst = 0 main field, 1..lorder-1 history slot. */
+int nlg_vec_set_field(nlg_vec *self, int field, int irst, const double *host, int64_t count);
+int nlg_vec_get_field(const nlg_vec *self, int field, int irst, double *host, int64_t count);
+/* 0: reproduce real_vectors.f90:188-192 (history += alpha * vec's MAIN field) -- default;
+ * 1: mathematically consistent (history += alpha * vec's history). Process-wide switch. */
+int nlg_set_axpby_rst_consistent(int flag);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Krylov basis: what LightKrylov's allocate(X(kdim+1)) + innerprod / linear_combination do with     */
+/* k separate dot/axpby calls (call sites src/neklab_analysis.f90:5-8, :77-81), as block kernels     */
+/* ---------------------------------------------------------------------------------------------- */
+int nlg_basis_create(nlg_mesh *mesh, int nscal, int lorder, int nvec, nlg_basis **out);
+int nlg_basis_destroy(nlg_basis *b);
+int nlg_basis_vec(nlg_basis *b, int i, nlg_vec **out); /* borrowed view of column i (0-based) */
+/* h[0:k] = V(:,0:k)^T B w   (LightKrylov innerprod(X(1:k), w); k allreduces fused into one) */
+int nlg_basis_block_dot(const nlg_basis *b, int k, const nlg_vec *w, double *h);
+/* w -= V(:,0:k) h           (LightKrylov linear_combination + axpby loop) */
+int nlg_basis_block_axpy(const nlg_basis *b, int k, const double *h, nlg_vec *w);
+/* classical Gram-Schmidt with one re-orthogonalisation pass, then norm and scale:
+ * h[0:k] accumulated coefficients, *beta = ||w|| before normalisation */
+int nlg_basis_cgs2(const nlg_basis *b, int k, nlg_vec *w, double *h, double *beta);
+/* out = sum_j c[j] V(:,j)  over ALL fields (eigenvector reconstruction, LightKrylov eigs tail) */
+int nlg_basis_combine(const nlg_basis *b, int k, const double *c, nlg_vec *out);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* exptA_linop                                                                                      */
+/* ---------------------------------------------------------------------------------------------- */
+typedef struct nlg_exptA_config {
+    double tau;        /* abstract_exptA_linop_rdp%tau; exptA_linop(1.0_dp, bf) in 1cyl.usr:20       */
+    double re;         /* 1/viscosity; 1cyl.par: viscosity = -50                                      */
+    double cfl_limit;  /* 0.5 at src/linops/exponential_propagator.f90:12                             */
+    double vtol;       /* Helmholtz residual tolerance (param(22), neklab_nek_setup.f90:228)          */
+    double ptol;       /* pressure residual tolerance  (param(21), neklab_nek_setup.f90:227)          */
+    double dt;         /* > 0: fixed dt, skips the CFL rule (recompute_dt = .false. branch, :218-220) */
+    int torder;        /* |param(27)|: 1cyl.par timeStepper = bdf3                                    */
+    int maxit_v;
+    int maxit_p;
+    int fixed_iters_v; /* > 0: run exactly this many PCG iterations (parity / benchmarking mode)      */
+    int fixed_iters_p;
+    int reserved;
+} nlg_exptA_config;
+
+int nlg_exptA_config_default(nlg_exptA_config *cfg);
+/* exptA_linop(tau, baseflow) constructor (1cyl.usr:20); baseflow is copied (held by value in the
+ * reference, neklab_linops.f90:36) */
+int nlg_linop_create(nlg_mesh *mesh, const nlg_exptA_config *cfg, const nlg_vec *baseflow, nlg_linop **out);
+int nlg_linop_destroy(nlg_linop *op);
+/* init_exptA  src/linops/exponential_propagator.f90:4-13: dt / nsteps from CFL, solver set-up */
+int nlg_linop_init(nlg_linop *op);
+/* exptA_matvec  exponential_propagator.f90:15-60   (interface neklab_linops.f90:52-56) */
+int nlg_linop_matvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
+/* exptA_rmatvec exponential_propagator.f90:62-107  (interface neklab_linops.f90:58-62) */
+int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
+/* %tau read/written by the driver (src/neklab_analysis.f90:84; apply_exptA neklab_linops.f90:252) */
+int nlg_linop_set_tau(nlg_linop *op, double tau);
+int nlg_linop_get_info(const nlg_linop *op, double *tau, double *dt, int *nsteps, double *cfl);
+/* counters since creation: time steps, Helmholtz iterations, pressure iterations, matvecs
+ * (LightKrylov's per-linop matvec counter/timer, src/neklab_analysis.f90:98) */
+int nlg_linop_get_stats(const nlg_linop *op, int64_t *steps, int64_t *v_iters, int64_t *p_iters, int64_t *matvecs);
+
+/* Building blocks of the matvec, exposed for operator-level parity tests and for the
+ * "operator applies per second" unit of SURVEY.md §8(d).  They act on the fields of nlg_vec objects
+ * that live on the same mesh.
+ *   helmholtz : out.v_i = [mask_i * QQ^T] (h1 * A + h2 * B) in.v_i    (assemble=0: element-local only)
+ *               operator pieces spelled out at src/linops/neklab_linops.f90:332-366
+ *   dssum     : v_i <- QQ^T v_i                     (opdssum, real_vectors.f90:100)
+ *   cdabdtp   : out.pr = D (mask B^-1 QQ^T) D^T in.pr
+ *   opdiv     : out.pr = sum_i D_i in.v_i ;  opgradt: out.v_i = D_i^T in.pr (neklab_linops.f90:368-380)
+ *   conv      : out.v_i = weak linearised convective term around `base` (neklab_linops.f90:268-313)
+ */
+int nlg_op_helmholtz(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out, double h1, double h2, int assemble);
+int nlg_op_dssum(nlg_mesh *mesh, nlg_vec *v);
+int nlg_op_cdabdtp(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out);
+int nlg_op_opdiv(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out);
+int nlg_op_opgradt(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out);
+int nlg_op_conv(nlg_mesh *mesh, const nlg_vec *base, const nlg_vec *in, nlg_vec *out, int adjoint);
+int nlg_op_cfl(nlg_mesh *mesh, const nlg_vec *base, double dt, double *cfl);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* eigs: the LightKrylov call at src/neklab_analysis.f90:80-81                                       */
+/* ---------------------------------------------------------------------------------------------- */
+/* one Arnoldi step on device: basis column k -> column k+1, H(0:k+1, k) written to H (column-major,
+ * leading dimension ldh). transpose != 0 uses rmatvec. */
+int nlg_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, double *H, int ldh, int transpose);
+
+typedef struct nlg_eigs_opts {
+    int kdim;               /* kdim=  (1cyl.usr:11: 128)                                          */
+    int transpose;          /* transpose= adjoint_                                                 */
+    int max_restarts;       /* Krylov-Schur restarts                                               */
+    int write_intermediate; /* write_intermediate=.true. -> eigs_output.txt rewritten every step   */
+    double tol;             /* tolerance=, <= 0 => sqrt(1e-15) (LightKrylov rtol_dp)               */
+    const char *logfile;    /* NULL => "eigs_output.txt"                                           */
+    uint64_t seed;          /* start vector seed when x0 == NULL                                   */
+} nlg_eigs_opts;
+
+int nlg_eigs_opts_default(nlg_eigs_opts *o);
+/* eigs(A, X, eigvals, residuals, info, x0, kdim, transpose, write_intermediate):
+ * X[nev] are existing vectors (allocate(eigvecs(nev)); zero_basis, neklab_analysis.f90:77) and are
+ * overwritten; eigvals (re, im) and residuals have nev entries; *info = number of matvecs (>0) or
+ * a negative error.  Eigenvectors follow the real LAPACK convention (pair = Re, Im consecutive). */
+int nlg_eigs(nlg_linop *op, nlg_vec **X, int nev, double *eig_re, double *eig_im, double *residuals,
+             int *info, const nlg_vec *x0, const nlg_eigs_opts *opts);
+
+/* host-side dense helper used by nlg_eigs, exported for unit tests: eigen-decomposition of a real
+ * n x n matrix (column-major, lda); vr column-major complex pairs as LAPACK dgeev. */
+int nlg_dense_eig(int n, const double *A, int lda, double *wr, double *wi, double *vr, int ldvr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEKLAB_GPU_H */

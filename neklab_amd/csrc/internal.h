@@ -1,0 +1,184 @@
+// Internal declarations of libneklab_gpu (gfx950 only). Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "neklab_gpu.h"
+
+namespace nlg {
+
+void set_error(const char *fmt, ...);
+
+#define NLG_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            nlg::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define NLG_NCCL(call)                                                                            \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess) {                                                                  \
+            nlg::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+#define NLG_CHECK(cond, ...)             \
+    do {                                 \
+        if (!(cond)) {                   \
+            nlg::set_error(__VA_ARGS__); \
+            return 1;                    \
+        }                                \
+    } while (0)
+
+#define NLG_TRY(call)           \
+    do {                        \
+        int rc_ = (call);       \
+        if (rc_) return rc_;    \
+    } while (0)
+
+constexpr int kMaxBlocksReduce = 1024;  // fixed first-stage grid => run-to-run deterministic sums
+constexpr int kAlign = 32;              // field starts aligned to 32 doubles (256 B)
+
+inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace nlg
+
+struct nlg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    // reduction workspace
+    double *d_partial = nullptr;   // [kMaxVecReduce * kMaxBlocksReduce]
+    double *d_scalars = nullptr;   // small device scalars (results of reductions)
+    double *h_scalars = nullptr;   // pinned host mirror
+    int n_scalars = 0;
+    int max_red_vec = 0;
+};
+
+// Small dense operators of the discretisation, host copies (device copies live in nlg_mesh::d_ops)
+struct nlg_ops1d {
+    int n = 0, n2 = 0, nd = 0;
+    std::vector<double> z1, w1, z2, w2, zd, wd;
+    std::vector<double> D;     // n  x n   d/dr on GLL
+    std::vector<double> I12;   // n2 x n   GLL -> GL(n2)
+    std::vector<double> D12;   // n2 x n
+    std::vector<double> Jd;    // nd x n   GLL -> GL(nd)
+    std::vector<double> DJd;   // nd x n
+    std::vector<double> rdr;   // n  inverse reference spacing (CFL)
+};
+
+struct nlg_gs {
+    // groups of local dofs that share a global label (only groups of size >= 2 are stored)
+    int64_t ngroups = 0;
+    int64_t nshared = 0;
+    int *d_offsets = nullptr;   // [ngroups + 1]
+    int *d_indices = nullptr;   // [nshared] local dof index
+};
+
+struct nlg_mesh {
+    nlg_ctx *ctx = nullptr;
+    int dim = 3, n = 8, n2 = 6, nd = 12;
+    int64_t E = 0;
+    int np1 = 0, np2 = 0, npd = 0;      // points per element on the three meshes
+    int64_t lvn = 0, lpn = 0, lvs = 0, lps = 0, lfn = 0;  // lvs/lps: padded field strides
+    int has_outflow = 0;
+    nlg_ops1d ops;
+    // device copies of the 1-D operators, row-major; transposes stored too
+    double *d_D = nullptr, *d_Dt = nullptr, *d_I12 = nullptr, *d_I12t = nullptr, *d_D12 = nullptr, *d_D12t = nullptr;
+    double *d_Jd = nullptr, *d_Jdt = nullptr, *d_DJd = nullptr, *d_DJdt = nullptr, *d_rdr = nullptr;
+    double *d_w1 = nullptr, *d_w2 = nullptr, *d_wd = nullptr;
+    // geometry (velocity mesh), each lvn
+    double *d_x[3] = {nullptr, nullptr, nullptr};
+    double *d_rst[9] = {};     // rst[j*dim+i] = J * dr_j/dx_i
+    double *d_jac = nullptr, *d_bm1 = nullptr, *d_binvm1 = nullptr, *d_vmult = nullptr;
+    double *d_G[6] = {};       // 3-D: 11,12,13,22,23,33 ; 2-D: 11,12,22
+    double *d_mask[3] = {nullptr, nullptr, nullptr};
+    double *d_tmask = nullptr;
+    double *d_mbinv[3] = {nullptr, nullptr, nullptr};   // mask_i * binvm1 (fused opbinv weight)
+    // pressure mesh
+    double *d_rst2w[9] = {};   // each lpn
+    double *d_bm2 = nullptr, *d_bm2inv = nullptr;
+    // fine mesh
+    double *d_rstdw[9] = {};   // each lfn
+    int64_t *d_lglel = nullptr;
+    std::vector<int64_t> h_lglel;
+    nlg_gs gs;
+    double volvm1 = 0, volvm2 = 0;
+    int64_t lpn_global = 0;   // global pressure dof count (ortho)
+    // scratch fields
+    std::vector<double *> scratch1, scratchd, scratch2;   // velocity-mesh / fine-mesh / pressure-mesh scratch
+    std::map<std::string, const double *> named;          // for nlg_mesh_get
+    std::map<std::string, int64_t> named_len;
+};
+
+struct nlg_vec {
+    nlg_mesh *mesh = nullptr;
+    int nscal = 0, lorder = 3;
+    int ncomp = 0;             // dim + nscal : fields in the inner product
+    int64_t main_len = 0;      // ncomp*lvs + lps
+    int64_t total_len = 0;     // main_len * lorder
+    double *d = nullptr;
+    bool owns = true;
+    int nrst = 0;
+    // field pointers
+    double *vel(int i, int irst = 0) const { return d + irst * main_len + (int64_t)i * mesh->lvs; }
+    double *theta(int m, int irst = 0) const { return d + irst * main_len + (int64_t)(mesh->dim + m) * mesh->lvs; }
+    double *pr(int irst = 0) const { return d + irst * main_len + (int64_t)ncomp * mesh->lvs; }
+};
+
+struct nlg_basis {
+    nlg_mesh *mesh = nullptr;
+    int nvec = 0, nscal = 0, lorder = 3;
+    int64_t stride = 0;        // doubles between consecutive vectors
+    double *d = nullptr;
+    std::vector<nlg_vec *> views;
+    double *d_h = nullptr;     // [2 * nvec + 8] device coefficients
+};
+
+namespace nlg {
+
+// ---- vec.hip ----
+int reduce_ws_reserve(nlg_ctx *ctx, int nvec);
+// weighted dot over the inner-product part, result left on device at ctx->d_scalars[slot]; allreduced
+int dev_dot(const nlg_vec *a, const nlg_vec *b, int slot);
+int scalars_to_host(nlg_ctx *ctx, int first, int count, double *out);   // syncs the stream
+int allreduce_sum(nlg_ctx *ctx, double *d_buf, int count);
+int allreduce_max(nlg_ctx *ctx, double *d_buf, int count);
+
+int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc);
+int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign);
+int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
+
+// ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
+int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place QQ^T
+int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2);
+int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w);
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale);
+int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out);
+int sem_ediag(nlg_mesh *m, double *out);
+int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, const double *Mx, const double *My,
+               const double *Mz, const double *wt);
+int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU);
+int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint);
+int sem_cfl(nlg_mesh *m, double *const *U, double dt, double *cfl_host);
+int sem_ortho(nlg_mesh *m, double *p);
+double *sem_scratch1(nlg_mesh *m, int i);
+double *sem_scratchd(nlg_mesh *m, int i);
+double *sem_scratch2(nlg_mesh *m, int i);
+
+}  // namespace nlg

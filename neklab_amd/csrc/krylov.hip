@@ -1,0 +1,321 @@
+// Arnoldi / Krylov-Schur eigensolver driving the device kernels: the LightKrylov `eigs` call of
+// /root/reference/src/neklab_analysis.f90:80-81, restated (LightKrylov itself is not in the reference
+// tree) exactly as in oracle/krylov.py:
+//   - Arnoldi with classical Gram-Schmidt + one re-orthogonalisation pass as two block projections
+//     (one fused reduction per pass instead of k dots),
+//   - Ritz pairs of the projected matrix, residual |h_{k+1,:} y|, sorted by decreasing modulus,
+//   - thick restart on the wanted Ritz subspace (Krylov-Schur in its orthonormal-basis form),
+//   - eigs_output.txt rows "i Re Im modulus residual T|F" as parsed by
+//     /root/reference/test/lib/neklabTestCase.py:425-449.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <numeric>
+
+#include "internal.h"
+
+using namespace nlg;
+
+namespace {
+
+typedef std::complex<double> cplx;
+
+struct Ritz {
+    std::vector<cplx> lam;             // sorted by decreasing modulus
+    std::vector<std::vector<cplx>> y;  // y[j] = eigenvector j (length k), unit norm
+    std::vector<double> res;
+};
+
+// H column-major (ldh), leading k x k block + row k
+int ritz_pairs(const std::vector<double> &H, int ldh, int k, Ritz &out) {
+    std::vector<double> A((size_t)k * k), wr(k), wi(k), vr((size_t)k * k);
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i < k; ++i) A[(size_t)j * k + i] = H[(size_t)j * ldh + i];
+    int rc = nlg_dense_eig(k, A.data(), k, wr.data(), wi.data(), vr.data(), k);
+    NLG_CHECK(rc == 0, "eigs: dense eigen-solver failed (rc=%d) on the %d x %d projected matrix", rc, k, k);
+    std::vector<cplx> lam(k);
+    std::vector<std::vector<cplx>> y(k, std::vector<cplx>(k));
+    int j = 0;
+    while (j < k) {
+        if (wi[j] > 0.0 && j + 1 < k) {
+            lam[j] = cplx(wr[j], wi[j]);
+            lam[j + 1] = cplx(wr[j], -wi[j]);
+            for (int i = 0; i < k; ++i) {
+                y[j][i] = cplx(vr[(size_t)j * k + i], vr[(size_t)(j + 1) * k + i]);
+                y[j + 1][i] = std::conj(y[j][i]);
+            }
+            j += 2;
+        } else {
+            lam[j] = cplx(wr[j], 0.0);
+            for (int i = 0; i < k; ++i) y[j][i] = cplx(vr[(size_t)j * k + i], 0.0);
+            j += 1;
+        }
+    }
+    std::vector<double> res(k);
+    for (int c = 0; c < k; ++c) {
+        cplx s = 0.0;
+        for (int i = 0; i < k; ++i) s += H[(size_t)i * ldh + k] * y[c][i];
+        res[c] = std::abs(s);
+    }
+    std::vector<int> order(k);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::abs(lam[a]) > std::abs(lam[b]); });
+    out.lam.resize(k);
+    out.y.resize(k);
+    out.res.resize(k);
+    for (int c = 0; c < k; ++c) {
+        out.lam[c] = lam[order[c]];
+        out.y[c] = y[order[c]];
+        out.res[c] = res[order[c]];
+    }
+    return 0;
+}
+
+int select_wanted(const std::vector<cplx> &lam, int nkeep_min) {
+    const int k = (int)lam.size();
+    std::vector<double> mod(k);
+    for (int i = 0; i < k; ++i) mod[i] = std::abs(lam[i]);
+    std::vector<double> srt(mod);
+    std::sort(srt.begin(), srt.end());
+    const double med = (k % 2) ? srt[k / 2] : 0.5 * (srt[k / 2 - 1] + srt[k / 2]);
+    int p = 0;
+    for (int i = 0; i < k; ++i)
+        if (mod[i] > med) ++p;
+    p = std::max(p, nkeep_min);
+    p = std::min(p, k - 1);
+    if (p >= 1 && p < k && std::fabs(lam[p - 1].imag()) > 0.0) {
+        const cplx d = lam[p - 1] - std::conj(lam[p]);
+        if (std::abs(d) <= 1e-10 * std::abs(lam[p]) + 1e-14) ++p;
+    }
+    return std::min(p, k - 1);
+}
+
+// real orthonormal basis (k x p', column-major) of the span of the first p Ritz vectors
+void real_basis(const Ritz &r, int k, int p, std::vector<double> &Q, int &pout) {
+    std::vector<std::vector<double>> cols;
+    int j = 0;
+    while (j < p) {
+        std::vector<double> re(k), im(k);
+        for (int i = 0; i < k; ++i) {
+            re[i] = r.y[j][i].real();
+            im[i] = r.y[j][i].imag();
+        }
+        if (std::fabs(r.lam[j].imag()) > 0.0 && j + 1 < p) {
+            cols.push_back(re);
+            cols.push_back(im);
+            j += 2;
+        } else {
+            cols.push_back(re);
+            j += 1;
+        }
+    }
+    // modified Gram-Schmidt, twice
+    pout = (int)cols.size();
+    for (int c = 0; c < pout; ++c) {
+        for (int pass = 0; pass < 2; ++pass)
+            for (int b = 0; b < c; ++b) {
+                double s = 0.0;
+                for (int i = 0; i < k; ++i) s += cols[b][i] * cols[c][i];
+                for (int i = 0; i < k; ++i) cols[c][i] -= s * cols[b][i];
+            }
+        double nrm = 0.0;
+        for (int i = 0; i < k; ++i) nrm += cols[c][i] * cols[c][i];
+        nrm = std::sqrt(nrm);
+        for (int i = 0; i < k; ++i) cols[c][i] /= nrm;
+    }
+    Q.assign((size_t)k * pout, 0.0);
+    for (int c = 0; c < pout; ++c)
+        for (int i = 0; i < k; ++i) Q[(size_t)c * k + i] = cols[c][i];
+}
+
+void write_log(const char *path, int nmv, const Ritz &r, double tol) {
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    fprintf(f, "# matvecs = %d   tolerance = %.6e\n", nmv, tol);
+    fprintf(f, "#   i              Re                      Im                  modulus                residual   conv\n");
+    for (size_t i = 0; i < r.lam.size(); ++i)
+        fprintf(f, "%5zu  %22.15e  %22.15e  %22.15e  %14.6e  %s\n", i + 1, r.lam[i].real(), r.lam[i].imag(),
+                std::abs(r.lam[i]), r.res[i], r.res[i] < tol ? "T" : "F");
+    fclose(f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlg_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, double *H, int ldh, int transpose) {
+    NLG_CHECK(op && basis && H, "nlg_arnoldi_step: NULL argument");
+    NLG_CHECK(k >= 0 && k + 1 < basis->nvec, "nlg_arnoldi_step: k=%d needs basis columns %d, %d (nvec=%d)", k, k, k + 1, basis->nvec);
+    NLG_CHECK(ldh >= k + 2, "nlg_arnoldi_step: ldh=%d too small for k=%d", ldh, k);
+    nlg_vec *vk = basis->views[k], *w = basis->views[k + 1];
+    NLG_TRY(transpose ? nlg_linop_rmatvec(op, vk, w) : nlg_linop_matvec(op, vk, w));
+    NLG_TRY(basis_cgs2_dev(basis, k + 1, w));
+    std::vector<double> tmp(k + 2);
+    hipStream_t st = basis->mesh->ctx->stream;
+    NLG_HIP(hipMemcpyAsync(tmp.data(), basis->d_h, sizeof(double) * (k + 2), hipMemcpyDeviceToHost, st));
+    NLG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i <= k; ++i) H[(size_t)k * ldh + i] = tmp[i];
+    H[(size_t)k * ldh + k + 1] = std::sqrt(tmp[k + 1]);
+    return 0;
+}
+
+int nlg_eigs_opts_default(nlg_eigs_opts *o) {
+    NLG_CHECK(o, "nlg_eigs_opts_default: NULL");
+    o->kdim = 0;
+    o->transpose = 0;
+    o->max_restarts = 50;
+    o->write_intermediate = 1;
+    o->tol = 0.0;
+    o->logfile = nullptr;
+    o->seed = 0;
+    return 0;
+}
+
+int nlg_eigs(nlg_linop *op, nlg_vec **X, int nev, double *eig_re, double *eig_im, double *residuals, int *info,
+             const nlg_vec *x0, const nlg_eigs_opts *opts_in) {
+    NLG_CHECK(op && X && eig_re && eig_im && residuals && info, "nlg_eigs: NULL argument");
+    NLG_CHECK(nev >= 1, "nlg_eigs: nev must be >= 1");
+    nlg_eigs_opts o;
+    nlg_eigs_opts_default(&o);
+    if (opts_in) o = *opts_in;
+    const int kdim = o.kdim > 0 ? o.kdim : 4 * nev;   // LightKrylov default kdim = 4*nev
+    NLG_CHECK(kdim > nev, "nlg_eigs: kdim=%d must exceed nev=%d", kdim, nev);
+    const double tol = o.tol > 0.0 ? o.tol : std::sqrt(1e-15);
+    const char *logfile = o.logfile ? o.logfile : "eigs_output.txt";
+    nlg_vec *proto = X[0];
+    NLG_CHECK(proto, "nlg_eigs: X[0] is NULL");
+    nlg_mesh *mesh = proto->mesh;
+    *info = -1;
+
+    nlg_basis *V = nullptr, *T = nullptr;
+    NLG_TRY(nlg_basis_create(mesh, proto->nscal, proto->lorder, kdim + 1, &V));
+    auto cleanup = [&]() {
+        nlg_basis_destroy(V);
+        if (T) nlg_basis_destroy(T);
+    };
+    int rc = 0;
+#define EIGS_TRY(call)  \
+    do {                \
+        rc = (call);    \
+        if (rc) {       \
+            cleanup();  \
+            return rc;  \
+        }               \
+    } while (0)
+
+    // start vector
+    if (x0) {
+        EIGS_TRY(nlg_vec_copy(V->views[0], x0));
+    } else {
+        EIGS_TRY(nlg_vec_zero(V->views[0]));
+        EIGS_TRY(nlg_vec_rand(V->views[0], 0, o.seed));
+    }
+    {
+        double nrm = 0.0;
+        EIGS_TRY(nlg_vec_norm(V->views[0], &nrm));
+        if (!(nrm > 0.0)) {
+            cleanup();
+            set_error("nlg_eigs: start vector has zero norm");
+            return 1;
+        }
+        EIGS_TRY(nlg_vec_scal(V->views[0], 1.0 / nrm));
+    }
+    const int ldh = kdim + 1;
+    std::vector<double> H((size_t)ldh * kdim, 0.0);
+    Ritz r;
+    int kstart = 0, nmv = 0, k = 0;
+    bool done = false;
+    for (int restart = 0; restart <= o.max_restarts; ++restart) {
+        k = kstart;
+        while (k < kdim) {
+            EIGS_TRY(nlg_arnoldi_step(op, V, k, H.data(), ldh, o.transpose));
+            ++nmv;
+            ++k;
+            EIGS_TRY(ritz_pairs(H, ldh, k, r));
+            int conv = 0;
+            for (int i = 0; i < k; ++i)
+                if (r.res[i] < tol) ++conv;
+            if (o.write_intermediate) write_log(logfile, nmv, r, tol);
+            if (conv >= nev) {
+                done = true;
+                break;
+            }
+        }
+        if (done || k < kdim) break;
+        if (restart == o.max_restarts) break;
+        // thick restart
+        int p = select_wanted(r.lam, nev);
+        std::vector<double> Q;
+        int pq = 0;
+        real_basis(r, k, p, Q, pq);
+        p = pq;
+        if (!T) EIGS_TRY(nlg_basis_create(mesh, proto->nscal, proto->lorder, kdim, &T));
+        for (int j = 0; j < p; ++j) EIGS_TRY(nlg_basis_combine(V, k, Q.data() + (size_t)j * k, T->views[j]));
+        // S = Q^T H_k Q ; b = H[k, :k] Q
+        std::vector<double> HQ((size_t)k * p, 0.0), S((size_t)p * p, 0.0), b(p, 0.0);
+        for (int j = 0; j < p; ++j)
+            for (int i = 0; i < k; ++i) {
+                double s = 0.0;
+                for (int l = 0; l < k; ++l) s += H[(size_t)l * ldh + i] * Q[(size_t)j * k + l];
+                HQ[(size_t)j * k + i] = s;
+            }
+        for (int j = 0; j < p; ++j) {
+            for (int i = 0; i < p; ++i) {
+                double s = 0.0;
+                for (int l = 0; l < k; ++l) s += Q[(size_t)i * k + l] * HQ[(size_t)j * k + l];
+                S[(size_t)j * p + i] = s;
+            }
+            double s = 0.0;
+            for (int l = 0; l < k; ++l) s += H[(size_t)l * ldh + k] * Q[(size_t)j * k + l];
+            b[j] = s;
+        }
+        EIGS_TRY(nlg_vec_copy(T->views[p], V->views[k]));
+        std::fill(H.begin(), H.end(), 0.0);
+        for (int j = 0; j < p; ++j) {
+            for (int i = 0; i < p; ++i) H[(size_t)j * ldh + i] = S[(size_t)j * p + i];
+            H[(size_t)j * ldh + p] = b[j];
+        }
+        for (int j = 0; j <= p; ++j) EIGS_TRY(nlg_vec_copy(V->views[j], T->views[j]));
+        kstart = p;
+    }
+    const int kf = k;
+    const int nout = std::min(nev, kf);
+    // eigenvectors (real LAPACK convention)
+    {
+        int j = 0;
+        std::vector<double> c(kf);
+        while (j < nout) {
+            if (std::fabs(r.lam[j].imag()) > 0.0) {
+                const bool pos = r.lam[j].imag() > 0.0;
+                for (int i = 0; i < kf; ++i) c[i] = r.y[j][i].real();
+                EIGS_TRY(nlg_basis_combine(V, kf, c.data(), X[j]));
+                if (j + 1 < nout) {
+                    for (int i = 0; i < kf; ++i) c[i] = pos ? r.y[j][i].imag() : -r.y[j][i].imag();
+                    EIGS_TRY(nlg_basis_combine(V, kf, c.data(), X[j + 1]));
+                }
+                j += 2;
+            } else {
+                for (int i = 0; i < kf; ++i) c[i] = r.y[j][i].real();
+                EIGS_TRY(nlg_basis_combine(V, kf, c.data(), X[j]));
+                j += 1;
+            }
+        }
+    }
+    for (int j = 0; j < nev; ++j) {
+        if (j < nout) {
+            eig_re[j] = r.lam[j].real();
+            eig_im[j] = r.lam[j].imag();
+            residuals[j] = r.res[j];
+        } else {
+            eig_re[j] = eig_im[j] = 0.0;
+            residuals[j] = -1.0;
+        }
+    }
+    *info = nmv;
+    cleanup();
+#undef EIGS_TRY
+    return 0;
+}
+
+}  // extern "C"

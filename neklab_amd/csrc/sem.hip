@@ -1,0 +1,1605 @@
+// Spectral-element discretisation on device: mesh set-up, gather-scatter and the element-local
+// operators of the matvec (gfx950).
+//
+// What the reference pins (file:line under /root/reference):
+//   - Laplacian = grad -> metric -> grad^T with rxm1..tzm1, jacmi   src/linops/neklab_linops.f90:332-366
+//   - pressure gradient / divergence on the lx2 = lx1-2 mesh         src/linops/neklab_linops.f90:368-380
+//   - linearised convective terms, direct + adjoint                  src/linops/neklab_linops.f90:268-313
+//   - dssum / multiplicity / masks                                   src/vectors/real_vectors.f90:100-108
+// The Nek5000 routines behind those calls are restated from the published algorithm.
+//
+// Kernel / roofline summary (fp64, all HBM-bound; algorithmic bytes per element, n = lx1):
+//   k_axhelm3   : (16*NF + 56) n^3 B   (u in, w out, 6 metric factors + mass)          12n^4+20n^3 flop/field
+//   k_gs        : 20 B per shared local dof and field (value in/out + 4-byte index)
+//   k_opgradt3  : 8 n2^3 (1 + 9) + 24 n^3 B ; k_opdiv3 : 24 n^3 + 8 n2^3 (9 + 1) B
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "internal.h"
+
+using namespace nlg;
+
+// =================================================================================================
+// host: 1-D operators (same formulas as oracle/sem.py, barycentric Lagrange form)
+// =================================================================================================
+namespace {
+
+void legendre(int N, double x, double &pN, double &pNm1) {
+    double p0 = 1.0, p1 = x;
+    if (N == 0) {
+        pN = 1.0;
+        pNm1 = 0.0;
+        return;
+    }
+    for (int k = 2; k <= N; ++k) {
+        const double p2 = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+        p0 = p1;
+        p1 = p2;
+    }
+    pN = p1;
+    pNm1 = p0;
+}
+
+void gll_nodes(int n, std::vector<double> &x, std::vector<double> &w) {
+    const int N = n - 1;
+    x.resize(n);
+    w.resize(n);
+    for (int i = 0; i < n; ++i) x[i] = -cos(M_PI * i / N);
+    for (int it = 0; it < 100; ++it) {
+        double mx = 0.0;
+        for (int i = 1; i < n - 1; ++i) {
+            double pN, pNm1;
+            legendre(N, x[i], pN, pNm1);
+            const double f = N * (pNm1 - x[i] * pN);
+            const double df = -(double)N * (N + 1) * pN;
+            const double dx = f / df;
+            x[i] -= dx;
+            mx = std::max(mx, std::fabs(dx));
+        }
+        if (mx < 1e-16) break;
+    }
+    x[0] = -1.0;
+    x[n - 1] = 1.0;
+    std::vector<double> xs(x);
+    for (int i = 0; i < n; ++i) x[i] = 0.5 * (xs[i] - xs[n - 1 - i]);
+    for (int i = 0; i < n; ++i) {
+        double pN, pNm1;
+        legendre(N, x[i], pN, pNm1);
+        w[i] = 2.0 / (N * (N + 1) * pN * pN);
+    }
+}
+
+void gl_nodes(int n, std::vector<double> &x, std::vector<double> &w) {
+    x.resize(n);
+    w.resize(n);
+    for (int k = 1; k <= n; ++k) x[k - 1] = -cos(M_PI * (k - 0.25) / (n + 0.5));
+    for (int it = 0; it < 100; ++it) {
+        double mx = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double pn, pnm1;
+            legendre(n, x[i], pn, pnm1);
+            const double dpn = n * (x[i] * pn - pnm1) / (x[i] * x[i] - 1.0);
+            const double dx = pn / dpn;
+            x[i] -= dx;
+            mx = std::max(mx, std::fabs(dx));
+        }
+        if (mx < 1e-16) break;
+    }
+    std::vector<double> xs(x);
+    for (int i = 0; i < n; ++i) x[i] = 0.5 * (xs[i] - xs[n - 1 - i]);
+    for (int i = 0; i < n; ++i) {
+        double pn, pnm1;
+        legendre(n, x[i], pn, pnm1);
+        const double dpn = n * (x[i] * pn - pnm1) / (x[i] * x[i] - 1.0);
+        w[i] = 2.0 / ((1.0 - x[i] * x[i]) * dpn * dpn);
+    }
+}
+
+std::vector<double> bary(const std::vector<double> &x) {
+    const int n = (int)x.size();
+    std::vector<double> w(n, 1.0);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k)
+            if (k != j) w[j] /= (x[j] - x[k]);
+    return w;
+}
+
+// M[k*nf + j] = l_j(xto_k)
+std::vector<double> interp_mat(const std::vector<double> &xf, const std::vector<double> &xt) {
+    const int nf = (int)xf.size(), nt = (int)xt.size();
+    std::vector<double> bw = bary(xf), M((size_t)nt * nf, 0.0);
+    for (int k = 0; k < nt; ++k) {
+        int hit = -1;
+        for (int j = 0; j < nf; ++j)
+            if (std::fabs(xt[k] - xf[j]) < 1e-15) hit = j;
+        if (hit >= 0) {
+            M[(size_t)k * nf + hit] = 1.0;
+        } else {
+            double s = 0.0;
+            for (int j = 0; j < nf; ++j) {
+                M[(size_t)k * nf + j] = bw[j] / (xt[k] - xf[j]);
+                s += M[(size_t)k * nf + j];
+            }
+            for (int j = 0; j < nf; ++j) M[(size_t)k * nf + j] /= s;
+        }
+    }
+    return M;
+}
+
+std::vector<double> deriv_mat(const std::vector<double> &x) {
+    const int n = (int)x.size();
+    std::vector<double> bw = bary(x), D((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j)
+            if (i != j) {
+                D[(size_t)i * n + j] = (bw[j] / bw[i]) / (x[i] - x[j]);
+                s += D[(size_t)i * n + j];
+            }
+        D[(size_t)i * n + i] = -s;
+    }
+    return D;
+}
+
+std::vector<double> matmul(const std::vector<double> &A, const std::vector<double> &B, int m, int k, int n) {
+    std::vector<double> C((size_t)m * n, 0.0);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int l = 0; l < k; ++l) s += A[(size_t)i * k + l] * B[(size_t)l * n + j];
+            C[(size_t)i * n + j] = s;
+        }
+    return C;
+}
+
+std::vector<double> transpose(const std::vector<double> &A, int m, int n) {
+    std::vector<double> T((size_t)m * n);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) T[(size_t)j * m + i] = A[(size_t)i * n + j];
+    return T;
+}
+
+int upload(const std::vector<double> &h, double **d) {
+    NLG_HIP(hipMalloc(d, sizeof(double) * std::max<size_t>(h.size(), 1)));
+    NLG_HIP(hipMemcpy(*d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dalloc(double **d, int64_t n, hipStream_t s) {
+    NLG_HIP(hipMalloc(d, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+    NLG_HIP(hipMemsetAsync(*d, 0, sizeof(double) * (size_t)std::max<int64_t>(n, 1), s));
+    return 0;
+}
+
+struct F3 {
+    double *p[3];
+};
+struct CF3 {
+    const double *p[3];
+};
+struct CF9 {
+    const double *p[9];
+};
+struct F9 {
+    double *p[9];
+};
+
+constexpr int NT = 256;
+
+// =================================================================================================
+// generic (runtime-size) set-up kernels: speed is irrelevant here
+// =================================================================================================
+
+// out = (Mz x My x Mx) in per element, optional pointwise tensor weight (wt[a]*wt[b]*wt[c]) on the output.
+// M* are nout x nin row-major. One block per element, dynamic LDS: 2 * max(nin,nout)^dim doubles.
+__global__ void k_tensor_generic(const double *in, double *out, int dim, int nin, int nout, const double *Mx,
+                                 const double *My, const double *Mz, const double *wt, int64_t E) {
+    extern __shared__ double sh[];
+    const int64_t e = blockIdx.x;
+    int nmax = nin > nout ? nin : nout;
+    int cap = nmax * nmax * (dim == 3 ? nmax : 1);
+    double *A = sh, *B = sh + cap;
+    int s0 = nin, s1 = nin, s2 = (dim == 3 ? nin : 1);
+    const int npin = s0 * s1 * s2;
+    for (int p = threadIdx.x; p < npin; p += blockDim.x) A[p] = in[e * npin + p];
+    __syncthreads();
+    // x
+    {
+        const int o0 = nout;
+        for (int p = threadIdx.x; p < o0 * s1 * s2; p += blockDim.x) {
+            const int a = p % o0, bc = p / o0;
+            double s = 0.0;
+            for (int l = 0; l < s0; ++l) s += Mx[a * nin + l] * A[l + s0 * bc];
+            B[p] = s;
+        }
+        s0 = o0;
+        __syncthreads();
+    }
+    // y
+    {
+        const int o1 = nout;
+        for (int p = threadIdx.x; p < s0 * o1 * s2; p += blockDim.x) {
+            const int a = p % s0, b = (p / s0) % o1, c = p / (s0 * o1);
+            double s = 0.0;
+            for (int l = 0; l < s1; ++l) s += My[b * nin + l] * B[a + s0 * (l + s1 * c)];
+            A[p] = s;
+        }
+        s1 = o1;
+        __syncthreads();
+    }
+    double *res = A;
+    if (dim == 3) {
+        const int o2 = nout;
+        for (int p = threadIdx.x; p < s0 * s1 * o2; p += blockDim.x) {
+            const int ab = p % (s0 * s1), c = p / (s0 * s1);
+            double s = 0.0;
+            for (int l = 0; l < s2; ++l) s += Mz[c * nin + l] * A[ab + s0 * s1 * l];
+            B[p] = s;
+        }
+        s2 = o2;
+        res = B;
+        __syncthreads();
+    }
+    const int npout = s0 * s1 * s2;
+    for (int p = threadIdx.x; p < npout; p += blockDim.x) {
+        double v = res[p];
+        if (wt) {
+            const int a = p % s0, b = (p / s0) % s1, c = p / (s0 * s1);
+            v *= wt[a] * wt[b] * (dim == 3 ? wt[c] : 1.0);
+        }
+        out[e * npout + p] = v;
+    }
+}
+
+// geometry from coordinates: rst (J-scaled), jac, bm1, G. One block per element.
+__global__ void k_geom(int dim, int n, const double *D, const double *w1, CF3 X, F9 rst, double *jac, double *bm1,
+                       double *G0, double *G1, double *G2, double *G3, double *G4, double *G5, int *bad) {
+    extern __shared__ double sh[];
+    const int np = n * n * (dim == 3 ? n : 1);
+    const int64_t e = blockIdx.x;
+    double *sx = sh, *sy = sh + np, *sz = sh + 2 * np;
+    for (int p = threadIdx.x; p < np; p += blockDim.x) {
+        sx[p] = X.p[0][e * np + p];
+        sy[p] = X.p[1][e * np + p];
+        if (dim == 3) sz[p] = X.p[2][e * np + p];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < np; p += blockDim.x) {
+        const int i = p % n, j = (p / n) % n, k = p / (n * n);
+        double d[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // d[c][a] = d x_c / d r_a
+        const double *sc[3] = {sx, sy, sz};
+        for (int c = 0; c < dim; ++c) {
+            double r = 0, s = 0, t = 0;
+            for (int l = 0; l < n; ++l) {
+                r += D[i * n + l] * sc[c][l + n * (j + n * k)];
+                s += D[j * n + l] * sc[c][i + n * (l + n * k)];
+                if (dim == 3) t += D[k * n + l] * sc[c][i + n * (j + n * l)];
+            }
+            d[c][0] = r;
+            d[c][1] = s;
+            d[c][2] = t;
+        }
+        double a[3][3];   // a[j][i] = J dr_j/dx_i
+        double J;
+        double w = w1[i] * w1[j] * (dim == 3 ? w1[k] : 1.0);
+        if (dim == 2) {
+            const double xr = d[0][0], xs = d[0][1], yr = d[1][0], ys = d[1][1];
+            J = xr * ys - xs * yr;
+            a[0][0] = ys;
+            a[0][1] = -xs;
+            a[1][0] = -yr;
+            a[1][1] = xr;
+        } else {
+            const double xr = d[0][0], xs = d[0][1], xt = d[0][2];
+            const double yr = d[1][0], ys = d[1][1], yt = d[1][2];
+            const double zr = d[2][0], zs = d[2][1], zt = d[2][2];
+            a[0][0] = ys * zt - yt * zs;
+            a[0][1] = xt * zs - xs * zt;
+            a[0][2] = xs * yt - xt * ys;
+            a[1][0] = yt * zr - yr * zt;
+            a[1][1] = xr * zt - xt * zr;
+            a[1][2] = xt * yr - xr * yt;
+            a[2][0] = yr * zs - ys * zr;
+            a[2][1] = xs * zr - xr * zs;
+            a[2][2] = xr * ys - xs * yr;
+            J = xr * a[0][0] + xs * a[1][0] + xt * a[2][0];
+        }
+        if (!(J > 0.0)) atomicExch(bad, 1);
+        const int64_t q = e * np + p;
+        for (int jj = 0; jj < dim; ++jj)
+            for (int ii = 0; ii < dim; ++ii) rst.p[jj * dim + ii][q] = a[jj][ii];
+        jac[q] = J;
+        bm1[q] = w * J;
+        const double s = w / J;
+        auto dotr = [&](int r1, int r2) {
+            double v = 0;
+            for (int m = 0; m < dim; ++m) v += a[r1][m] * a[r2][m];
+            return v * s;
+        };
+        if (dim == 2) {
+            G0[q] = dotr(0, 0);
+            G1[q] = dotr(0, 1);
+            G2[q] = dotr(1, 1);
+        } else {
+            G0[q] = dotr(0, 0);
+            G1[q] = dotr(0, 1);
+            G2[q] = dotr(0, 2);
+            G3[q] = dotr(1, 1);
+            G4[q] = dotr(1, 2);
+            G5[q] = dotr(2, 2);
+        }
+    }
+}
+
+__global__ void k_set(double *x, double v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void k_recip(double *y, const double *x, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = 1.0 / x[i];
+}
+__global__ void k_addto(double *a, const double *b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+__global__ void k_mul(double *y, const double *a, const double *b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a[i] * b[i];
+}
+
+// =================================================================================================
+// gather-scatter: one thread per group of local copies of a shared global dof
+// =================================================================================================
+template <int NF>
+__global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const int *__restrict__ idx, int64_t ngroups,
+                                           F3 f) {
+    const int64_t g = blockIdx.x * (int64_t)NT + threadIdx.x;
+    if (g >= ngroups) return;
+    const int b = off[g], e = off[g + 1];
+    double s[NF];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) s[c] = 0.0;
+    for (int q = b; q < e; ++q) {
+        const int i = idx[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) s[c] += f.p[c][i];
+    }
+    for (int q = b; q < e; ++q) {
+        const int i = idx[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) f.p[c][i] = s[c];
+    }
+}
+
+// w_c <- wt_c * w_c  (opbinv after dssum; also mask application)
+template <int NF>
+__global__ __launch_bounds__(NT) void k_colmul(F3 w, CF3 wt, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+#pragma unroll
+        for (int c = 0; c < NF; ++c) w.p[c][i] *= wt.p[c][i];
+    }
+}
+
+// =================================================================================================
+// Helmholtz operator, element-local:  w = h1 * D^T G D u + h2 * B u
+// 3-D: (N x N) threads per element sweep the k-slabs; u column and w column live in registers,
+// the r/s contractions go through an LDS slab, geometric factors are read once for NF fields.
+// =================================================================================================
+template <int N, int NF>
+__global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) void k_axhelm3(
+    int64_t E, const double *__restrict__ Dg, const double *__restrict__ G0, const double *__restrict__ G1,
+    const double *__restrict__ G2, const double *__restrict__ G3, const double *__restrict__ G4,
+    const double *__restrict__ G5, const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2) {
+    constexpr int EPB = (NT / (N * N)) > 0 ? (NT / (N * N)) : 1;
+    constexpr int NP = N * N * N;
+    __shared__ double sD[N * N];
+    __shared__ double sU[EPB][NF][N * N];
+    __shared__ double sR[EPB][NF][N * N];
+    __shared__ double sS[EPB][NF][N * N];
+    const int tid = threadIdx.x;
+    const int le = tid / (N * N);
+    const int ij = tid % (N * N);
+    const int i = ij % N, j = ij / N;
+    for (int p = tid; p < N * N; p += EPB * N * N) sD[p] = Dg[p];
+    const int64_t e = (int64_t)blockIdx.x * EPB + le;
+    const bool act = e < E;
+    const int64_t base = (act ? e : 0) * NP;
+    double ru[NF][N], rw[NF][N];
+#pragma unroll
+    for (int c = 0; c < NF; ++c)
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            ru[c][k] = act ? u.p[c][base + ij + k * N * N] : 0.0;
+            rw[c][k] = 0.0;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int64_t q = base + ij + k * N * N;
+        const double g0 = G0[q], g1 = G1[q], g2 = G2[q], g3 = G3[q], g4 = G4[q], g5 = G5[q], bm = bm1[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) sU[le][c][ij] = ru[c][k];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                ur += sD[i * N + l] * sU[le][c][l + N * j];
+                us += sD[j * N + l] * sU[le][c][i + N * l];
+                ut += sD[k * N + l] * ru[c][l];
+            }
+            const double gr = h1 * (g0 * ur + g1 * us + g2 * ut);
+            const double gs = h1 * (g1 * ur + g3 * us + g4 * ut);
+            const double gt = h1 * (g2 * ur + g4 * us + g5 * ut);
+            sR[le][c][ij] = gr;
+            sS[le][c][ij] = gs;
+#pragma unroll
+            for (int l = 0; l < N; ++l) rw[c][l] += sD[k * N + l] * gt;   // D^T along t
+            rw[c][k] += h2 * bm * ru[c][k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) a += sD[l * N + i] * sR[le][c][l + N * j] + sD[l * N + j] * sS[le][c][i + N * l];
+            rw[c][k] += a;
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < NF; ++c)
+#pragma unroll
+            for (int k = 0; k < N; ++k) w.p[c][base + ij + k * N * N] = rw[c][k];
+    }
+}
+
+// 2-D: one thread per point.
+template <int N, int NF>
+__global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) void k_axhelm2(
+    int64_t E, const double *__restrict__ Dg, const double *__restrict__ G0, const double *__restrict__ G1,
+    const double *__restrict__ G2, const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2) {
+    constexpr int EPB = (NT / (N * N)) > 0 ? (NT / (N * N)) : 1;
+    constexpr int NP = N * N;
+    __shared__ double sD[N * N];
+    __shared__ double sU[EPB][NF][NP];
+    __shared__ double sR[EPB][NF][NP];
+    __shared__ double sS[EPB][NF][NP];
+    const int tid = threadIdx.x;
+    const int le = tid / NP, ij = tid % NP, i = ij % N, j = ij / N;
+    for (int p = tid; p < N * N; p += EPB * NP) sD[p] = Dg[p];
+    const int64_t e = (int64_t)blockIdx.x * EPB + le;
+    const bool act = e < E;
+    const int64_t q = (act ? e : 0) * NP + ij;
+    double uu[NF];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) {
+        uu[c] = act ? u.p[c][q] : 0.0;
+        sU[le][c][ij] = uu[c];
+    }
+    const double g0 = G0[q], g1 = G1[q], g2 = G2[q], bm = bm1[q];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NF; ++c) {
+        double ur = 0.0, us = 0.0;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            ur += sD[i * N + l] * sU[le][c][l + N * j];
+            us += sD[j * N + l] * sU[le][c][i + N * l];
+        }
+        sR[le][c][ij] = g0 * ur + g1 * us;
+        sS[le][c][ij] = g1 * ur + g2 * us;
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) a += sD[l * N + i] * sR[le][c][l + N * j] + sD[l * N + j] * sS[le][c][i + N * l];
+            w.p[c][q] = h1 * a + h2 * bm * uu[c];
+        }
+    }
+}
+
+// exact diagonal of the local Helmholtz operator (cross metric terms included), generic sizes
+__global__ void k_helm_diag(int dim, int n, int64_t E, const double *D, const double *G0, const double *G1,
+                            const double *G2, const double *G3, const double *G4, const double *G5,
+                            const double *bm1, double *out, double h1, double h2) {
+    const int np = n * n * (dim == 3 ? n : 1);
+    const int64_t tot = E * np;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < tot; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = q / np;
+        const int p = (int)(q % np);
+        const int i = p % n, j = (p / n) % n, k = p / (n * n);
+        const int64_t b = e * np;
+        double s = 0.0;
+        if (dim == 2) {
+            for (int l = 0; l < n; ++l) {
+                s += D[l * n + i] * D[l * n + i] * G0[b + l + n * j];
+                s += D[l * n + j] * D[l * n + j] * G2[b + i + n * l];
+            }
+            s += 2.0 * G1[q] * D[i * n + i] * D[j * n + j];
+        } else {
+            for (int l = 0; l < n; ++l) {
+                s += D[l * n + i] * D[l * n + i] * G0[b + l + n * (j + n * k)];
+                s += D[l * n + j] * D[l * n + j] * G3[b + i + n * (l + n * k)];
+                s += D[l * n + k] * D[l * n + k] * G5[b + i + n * (j + n * l)];
+            }
+            const double di = D[i * n + i], dj = D[j * n + j], dk = D[k * n + k];
+            s += 2.0 * (G1[q] * di * dj + G2[q] * di * dk + G4[q] * dj * dk);
+        }
+        out[q] = h1 * s + h2 * bm1[q];
+    }
+}
+
+// =================================================================================================
+// tensor contraction helper on LDS arrays: contract axis AX of in[S2][S1][S0] with M (NOUT x NIN,
+// row-major) ; out has that axis replaced by NOUT.
+// =================================================================================================
+template <int S0, int S1, int S2, int AX, int NOUT, bool ACC>
+__device__ __forceinline__ void contract(const double *__restrict__ in, double *__restrict__ out,
+                                         const double *__restrict__ M, int tid, int nth) {
+    constexpr int NIN = AX == 0 ? S0 : (AX == 1 ? S1 : S2);
+    constexpr int O0 = AX == 0 ? NOUT : S0, O1 = AX == 1 ? NOUT : S1, O2 = AX == 2 ? NOUT : S2;
+    for (int p = tid; p < O0 * O1 * O2; p += nth) {
+        const int a = p % O0, b = (p / O0) % O1, c = p / (O0 * O1);
+        const int o = AX == 0 ? a : (AX == 1 ? b : c);
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < NIN; ++l) {
+            const int q = AX == 0 ? (l + S0 * (b + S1 * c)) : (AX == 1 ? (a + S0 * (l + S1 * c)) : (a + S0 * (b + S1 * l)));
+            s += M[o * NIN + l] * in[q];
+        }
+        if (ACC)
+            out[p] += s;
+        else
+            out[p] = s;
+    }
+}
+
+// ---- opgradt 3-D: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise) -------------
+// It / Dt are the transposes (N x N2 row-major) of I12 / D12.
+template <int N>
+__global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, const double *__restrict__ Itg,
+                                                 const double *__restrict__ Dtg, CF9 g, const double *__restrict__ p,
+                                                 F3 w) {
+    constexpr int N2 = N - 2;
+    constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
+    constexpr int SA = N2 * N2 * N, SB = N2 * N * N;
+    __shared__ double sI[N * N2], sDt[N * N2];
+    __shared__ double sP[NP2];
+    __shared__ double sQ[3][NP2];
+    __shared__ double sA[3][SA];
+    __shared__ double sB[2][SB];
+    const int tid = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    for (int q = tid; q < N * N2; q += NT) {
+        sI[q] = Itg[q];
+        sDt[q] = Dtg[q];
+    }
+    for (int q = tid; q < NP2; q += NT) sP[q] = p[e * NP2 + q];
+    __syncthreads();
+    for (int i = 0; i < 3; ++i) {
+        // q_j = g_ji * p  (j = 0,1,2)
+        for (int q = tid; q < NP2; q += NT) {
+            const double pv = sP[q];
+            sQ[0][q] = g.p[0 * 3 + i][e * NP2 + q] * pv;
+            sQ[1][q] = g.p[1 * 3 + i][e * NP2 + q] * pv;
+            sQ[2][q] = g.p[2 * 3 + i][e * NP2 + q] * pv;
+        }
+        __syncthreads();
+        // z stage
+        contract<N2, N2, N2, 2, N, false>(sQ[0], sA[0], sI, tid, NT);
+        contract<N2, N2, N2, 2, N, false>(sQ[1], sA[1], sI, tid, NT);
+        contract<N2, N2, N2, 2, N, false>(sQ[2], sA[2], sDt, tid, NT);
+        __syncthreads();
+        // y stage: B0 = I^T_y A0 ; B1 = D^T_y A1 + I^T_y A2
+        contract<N2, N2, N, 1, N, false>(sA[0], sB[0], sI, tid, NT);
+        contract<N2, N2, N, 1, N, false>(sA[1], sB[1], sDt, tid, NT);
+        contract<N2, N2, N, 1, N, true>(sA[2], sB[1], sI, tid, NT);
+        __syncthreads();
+        // x stage: w = D^T_x B0 + I^T_x B1
+        for (int q = tid; q < NP1; q += NT) {
+            const int a = q % N, bc = q / N;
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < N2; ++l) s += sDt[a * N2 + l] * sB[0][l + N2 * bc] + sI[a * N2 + l] * sB[1][l + N2 * bc];
+            w.p[i][e * NP1 + q] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- opdiv 3-D: out = scale * sum_i sum_j g_ji o (T_j u_i) ------------------------------------------
+// Im / Dm are I12 / D12 (N2 x N row-major).
+template <int N>
+__global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, const double *__restrict__ Img,
+                                               const double *__restrict__ Dmg, CF9 g, CF3 u,
+                                               double *__restrict__ out, double scale) {
+    constexpr int N2 = N - 2;
+    constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
+    constexpr int SB = N2 * N * N, SC = N2 * N2 * N;
+    __shared__ double sI[N2 * N], sD[N2 * N];
+    __shared__ double sU[NP1];
+    __shared__ double sB[2][SB];
+    __shared__ double sC[3][SC];
+    const int tid = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    for (int q = tid; q < N * N2; q += NT) {
+        sI[q] = Img[q];
+        sD[q] = Dmg[q];
+    }
+    constexpr int NACC = (NP2 + NT - 1) / NT;
+    double acc[NACC];
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[r] = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        __syncthreads();
+        for (int q = tid; q < NP1; q += NT) sU[q] = u.p[i][e * NP1 + q];
+        __syncthreads();
+        // x stage: B0 = D_x u, B1 = I_x u
+        contract<N, N, N, 0, N2, false>(sU, sB[0], sD, tid, NT);
+        contract<N, N, N, 0, N2, false>(sU, sB[1], sI, tid, NT);
+        __syncthreads();
+        // y stage: C0 = I_y B0 ; C1 = D_y B1 ; C2 = I_y B1
+        contract<N2, N, N, 1, N2, false>(sB[0], sC[0], sI, tid, NT);
+        contract<N2, N, N, 1, N2, false>(sB[1], sC[1], sD, tid, NT);
+        contract<N2, N, N, 1, N2, false>(sB[1], sC[2], sI, tid, NT);
+        __syncthreads();
+        // z stage fused with metric contraction
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const int q = tid + r * NT;
+            if (q < NP2) {
+                const int ab = q % (N2 * N2), c = q / (N2 * N2);
+                double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) {
+                    t0 += sI[c * N + l] * sC[0][ab + N2 * N2 * l];
+                    t1 += sI[c * N + l] * sC[1][ab + N2 * N2 * l];
+                    t2 += sD[c * N + l] * sC[2][ab + N2 * N2 * l];
+                }
+                const int64_t gq = e * NP2 + q;
+                acc[r] += g.p[0 * 3 + i][gq] * t0 + g.p[1 * 3 + i][gq] * t1 + g.p[2 * 3 + i][gq] * t2;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+        const int q = tid + r * NT;
+        if (q < NP2) out[e * NP2 + q] = scale * acc[r];
+    }
+}
+
+// ---- 2-D versions (several elements per block would be faster; correctness first) -------------------
+template <int N>
+__global__ __launch_bounds__(NT) void k_opgradt2(int64_t E, const double *__restrict__ Itg,
+                                                 const double *__restrict__ Dtg, CF9 g, const double *__restrict__ p,
+                                                 F3 w) {
+    constexpr int N2 = N - 2;
+    constexpr int NP2 = N2 * N2, NP1 = N * N, SA = N2 * N;
+    constexpr int EPB = NT / NP1 > 0 ? NT / NP1 : 1;
+    __shared__ double sI[N * N2], sDt[N * N2];
+    __shared__ double sQ[EPB][2][NP2];
+    __shared__ double sA[EPB][2][SA];
+    const int tid = threadIdx.x;
+    const int le = tid / NP1, lt = tid % NP1;
+    const int64_t e = (int64_t)blockIdx.x * EPB + le;
+    const bool act = (le < EPB) && (e < E);
+    for (int q = tid; q < N * N2; q += NT) {
+        sI[q] = Itg[q];
+        sDt[q] = Dtg[q];
+    }
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
+        if (act && lt < NP2) {
+            const double pv = p[e * NP2 + lt];
+            sQ[le][0][lt] = g.p[0 * 2 + i][e * NP2 + lt] * pv;
+            sQ[le][1][lt] = g.p[1 * 2 + i][e * NP2 + lt] * pv;
+        }
+        __syncthreads();
+        // y stage: A0 = I^T_y q0 ; A1 = D^T_y q1   -> (a2, b)
+        if (act && lt < SA) {
+            const int a = lt % N2, b = lt / N2;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int l = 0; l < N2; ++l) {
+                s0 += sI[b * N2 + l] * sQ[le][0][a + N2 * l];
+                s1 += sDt[b * N2 + l] * sQ[le][1][a + N2 * l];
+            }
+            sA[le][0][lt] = s0;
+            sA[le][1][lt] = s1;
+        }
+        __syncthreads();
+        if (act) {
+            const int a = lt % N, b = lt / N;
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < N2; ++l) s += sDt[a * N2 + l] * sA[le][0][l + N2 * b] + sI[a * N2 + l] * sA[le][1][l + N2 * b];
+            w.p[i][e * NP1 + lt] = s;
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(NT) void k_opdiv2(int64_t E, const double *__restrict__ Img,
+                                               const double *__restrict__ Dmg, CF9 g, CF3 u,
+                                               double *__restrict__ out, double scale) {
+    constexpr int N2 = N - 2;
+    constexpr int NP2 = N2 * N2, NP1 = N * N, SB = N2 * N;
+    constexpr int EPB = NT / NP1 > 0 ? NT / NP1 : 1;
+    __shared__ double sI[N2 * N], sD[N2 * N];
+    __shared__ double sU[EPB][NP1];
+    __shared__ double sB[EPB][2][SB];
+    const int tid = threadIdx.x;
+    const int le = tid / NP1, lt = tid % NP1;
+    const int64_t e = (int64_t)blockIdx.x * EPB + le;
+    const bool act = (le < EPB) && (e < E);
+    for (int q = tid; q < N * N2; q += NT) {
+        sI[q] = Img[q];
+        sD[q] = Dmg[q];
+    }
+    double acc = 0.0;
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
+        if (act) sU[le][lt] = u.p[i][e * NP1 + lt];
+        __syncthreads();
+        if (act && lt < SB) {
+            const int a = lt % N2, b = lt / N2;   // (a2, b)
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                s0 += sD[a * N + l] * sU[le][l + N * b];
+                s1 += sI[a * N + l] * sU[le][l + N * b];
+            }
+            sB[le][0][lt] = s0;
+            sB[le][1][lt] = s1;
+        }
+        __syncthreads();
+        if (act && lt < NP2) {
+            const int a = lt % N2, b = lt / N2;
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                t0 += sI[b * N + l] * sB[le][0][a + N2 * l];
+                t1 += sD[b * N + l] * sB[le][1][a + N2 * l];
+            }
+            const int64_t gq = e * NP2 + lt;
+            acc += g.p[0 * 2 + i][gq] * t0 + g.p[1 * 2 + i][gq] * t1;
+        }
+    }
+    if (act && lt < NP2) out[e * NP2 + lt] = scale * acc;
+}
+
+// ---- pointwise kernels of the convective term on the fine mesh ------------------------------------
+// Ur_j = sum_m rstdw[j][m] Uf_m
+__global__ void k_conv_ur(int dim, int64_t n, CF9 rd, CF3 Uf, F3 Ur) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        for (int j = 0; j < dim; ++j) {
+            double s = 0.0;
+            for (int m = 0; m < dim; ++m) s += rd.p[j * dim + m][q] * Uf.p[m][q];
+            Ur.p[j][q] = s;
+        }
+    }
+}
+// GU[i][m] = sum_j rstdw[j][m] dU_i/dr_j   (dU holds d/dr_j of one component i: 3 fields)
+__global__ void k_conv_gu(int dim, int64_t n, CF9 rd, CF3 dUi, F3 GUi) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        for (int m = 0; m < dim; ++m) {
+            double s = 0.0;
+            for (int j = 0; j < dim; ++j) s += rd.p[j * dim + m][q] * dUi.p[j][q];
+            GUi.p[m][q] = s;
+        }
+    }
+}
+// acc = sgn * sum_j Ur_j du_j + sum_m uf_m GUsel_m
+__global__ void k_conv_combine(int dim, int64_t n, CF3 Ur, CF3 du, CF3 uf, CF3 GUsel, double sgn, double *acc) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0, t = 0.0;
+        for (int j = 0; j < dim; ++j) {
+            s += Ur.p[j][q] * du.p[j][q];
+            t += uf.p[j][q] * GUsel.p[j][q];
+        }
+        acc[q] = sgn * s + t;
+    }
+}
+
+// CFL (Nek compute_cfl): max over points of dt * sum_j |u_rj| * rdr
+__global__ __launch_bounds__(NT) void k_cfl(int dim, int n, int64_t E, CF9 rst, const double *jac, const double *rdr,
+                                            CF3 U, double dt, double *partial) {
+    __shared__ double sm[NT];
+    const int np = n * n * (dim == 3 ? n : 1);
+    const int64_t tot = E * np;
+    double mx = 0.0;
+    for (int64_t q = blockIdx.x * (int64_t)NT + threadIdx.x; q < tot; q += (int64_t)gridDim.x * NT) {
+        const int p = (int)(q % np);
+        const int ijk[3] = {p % n, (p / n) % n, p / (n * n)};
+        double s = 0.0;
+        for (int j = 0; j < dim; ++j) {
+            double ur = 0.0;
+            for (int m = 0; m < dim; ++m) ur += rst.p[j * dim + m][q] * U.p[m][q];
+            s += fabs(ur / jac[q] * rdr[ijk[j]]);
+        }
+        mx = fmax(mx, s * dt);
+    }
+    sm[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+__global__ void k_max_final(const double *partial, int n, double *out) {
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) m = fmax(m, partial[i]);
+    out[0] = m;
+}
+
+// sum of a pressure-mesh vector (ortho)
+__global__ __launch_bounds__(NT) void k_sum_partial(const double *x, int64_t n, double *partial) {
+    __shared__ double sm[NT];
+    double a = 0.0;
+    for (int64_t q = blockIdx.x * (int64_t)NT + threadIdx.x; q < n; q += (int64_t)gridDim.x * NT) a += x[q];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+__global__ void k_sum_final(const double *partial, int n, double *out) {
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) m += partial[i];
+    out[0] = m;
+}
+__global__ void k_sub_mean(double *x, int64_t n, const double *sum, double inv_count) {
+    const double mean = sum[0] * inv_count;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) x[q] -= mean;
+}
+
+// nek_drand noise (reference: real_vectors.f90:52-98 + neklab_vectors.f90:305-314), counter-based RNG
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void k_rand_add(int dim, int n, int64_t E, const int64_t *lglel, CF3 X, double *field, int field_id,
+                           uint64_t seed) {
+    const int np = n * n * (dim == 3 ? n : 1);
+    const int64_t tot = E * np;
+    const uint64_t sk = splitmix64(seed);
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < tot; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = q / np;
+        const int p = (int)(q % np);
+        const int ix = p % n + 1, iy = (p / n) % n + 1, iz = (dim == 3) ? p / (n * n) + 1 : 1;
+        const int64_t ieg = lglel[e] + 1;
+        const uint64_t base = (((uint64_t)((ieg - 1) * np + p)) * 8ull + (uint64_t)field_id) * 4ull;
+        double fc[3];
+        for (int c = 0; c < 3; ++c)
+            fc[c] = (double)(splitmix64((base + (uint64_t)c) ^ sk) >> 11) * (1.0 / 9007199254740992.0) * 1.0e4;
+        const double x = X.p[0][q], y = X.p[1][q];
+        double r = fc[0] * ((double)ieg + x * sin(y)) + fc[1] * ix * iy + fc[2] * ix;
+        if (dim == 3) r = fc[0] * ((double)ieg + X.p[2][q] * sin(r)) + fc[1] * iz * ix + fc[2] * iz;
+        r = 1.0e3 * sin(r);
+        r = 1.0e3 * sin(r);
+        field[q] += cos(r);
+    }
+}
+
+inline int grid_for(int64_t n) {
+    int64_t g = (n + NT - 1) / NT;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+// =================================================================================================
+// dispatch on N
+// =================================================================================================
+#define NLG_FOR_N(MACRO) \
+    switch (m->n) {      \
+        case 4: MACRO(4); break;   \
+        case 5: MACRO(5); break;   \
+        case 6: MACRO(6); break;   \
+        case 7: MACRO(7); break;   \
+        case 8: MACRO(8); break;   \
+        case 9: MACRO(9); break;   \
+        case 10: MACRO(10); break; \
+        case 12: MACRO(12); break; \
+        default: set_error("unsupported lx1 = %d (built for 4..10, 12)", m->n); return 1; \
+    }
+
+namespace nlg {
+
+double *sem_scratch1(nlg_mesh *m, int i) {
+    while ((int)m->scratch1.size() <= i) {
+        double *p = nullptr;
+        if (hipMalloc(&p, sizeof(double) * (size_t)m->lvs) != hipSuccess) return nullptr;
+        hipMemsetAsync(p, 0, sizeof(double) * (size_t)m->lvs, m->ctx->stream);
+        m->scratch1.push_back(p);
+    }
+    return m->scratch1[i];
+}
+double *sem_scratchd(nlg_mesh *m, int i) {
+    while ((int)m->scratchd.size() <= i) {
+        double *p = nullptr;
+        if (hipMalloc(&p, sizeof(double) * (size_t)m->lfn) != hipSuccess) return nullptr;
+        m->scratchd.push_back(p);
+    }
+    return m->scratchd[i];
+}
+double *sem_scratch2(nlg_mesh *m, int i) {
+    while ((int)m->scratch2.size() <= i) {
+        double *p = nullptr;
+        if (hipMalloc(&p, sizeof(double) * (size_t)m->lps) != hipSuccess) return nullptr;
+        hipMemsetAsync(p, 0, sizeof(double) * (size_t)m->lps, m->ctx->stream);
+        m->scratch2.push_back(p);
+    }
+    return m->scratch2[i];
+}
+
+int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
+    if (m->gs.ngroups == 0) return 0;
+    F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
+    const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
+    if (nf == 1)
+        hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+    else if (nf == 2)
+        hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+    else if (nf == 3)
+        hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+    else {
+        set_error("sem_gs: nf=%d unsupported", nf);
+        return 1;
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2) {
+    NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
+    CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
+    F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
+    hipStream_t s = m->ctx->stream;
+    if (m->dim == 3) {
+#define AX3(N_)                                                                                                       \
+    {                                                                                                                 \
+        constexpr int EPB = (NT / (N_ * N_)) > 0 ? (NT / (N_ * N_)) : 1;                                              \
+        const int grid = (int)((m->E + EPB - 1) / EPB);                                                               \
+        if (nf == 1)                                                                                                  \
+            hipLaunchKernelGGL((k_axhelm3<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+                               m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2);      \
+        else if (nf == 2)                                                                                             \
+            hipLaunchKernelGGL((k_axhelm3<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+                               m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2);      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_axhelm3<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+                               m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2);      \
+    }
+        NLG_FOR_N(AX3)
+#undef AX3
+    } else {
+#define AX2(N_)                                                                                                       \
+    {                                                                                                                 \
+        constexpr int EPB = (NT / (N_ * N_)) > 0 ? (NT / (N_ * N_)) : 1;                                              \
+        const int grid = (int)((m->E + EPB - 1) / EPB);                                                               \
+        if (nf == 1)                                                                                                  \
+            hipLaunchKernelGGL((k_axhelm2<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2);                                       \
+        else if (nf == 2)                                                                                             \
+            hipLaunchKernelGGL((k_axhelm2<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2);                                       \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_axhelm2<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2);                                       \
+    }
+        NLG_FOR_N(AX2)
+#undef AX2
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2) {
+    hipLaunchKernelGGL(k_helm_diag, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, m->dim, m->n, m->E, m->d_D,
+                       m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, out, h1, h2);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+static CF9 rst2w_ptrs(const nlg_mesh *m) {
+    CF9 g;
+    for (int q = 0; q < 9; ++q) g.p[q] = m->d_rst2w[q];
+    return g;
+}
+
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
+    F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
+    CF9 g = rst2w_ptrs(m);
+    hipStream_t s = m->ctx->stream;
+    if (m->dim == 3) {
+#define GT3(N_) hipLaunchKernelGGL((k_opgradt3<N_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, m->d_I12t, m->d_D12t, g, p, cw)
+        NLG_FOR_N(GT3)
+#undef GT3
+    } else {
+#define GT2(N_)                                                                                              \
+    {                                                                                                        \
+        constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                         \
+        hipLaunchKernelGGL((k_opgradt2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
+                           m->d_I12t, m->d_D12t, g, p, cw);                                                  \
+    }
+        NLG_FOR_N(GT2)
+#undef GT2
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale) {
+    CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
+    CF9 g = rst2w_ptrs(m);
+    hipStream_t s = m->ctx->stream;
+    if (m->dim == 3) {
+#define DV3(N_) hipLaunchKernelGGL((k_opdiv3<N_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, m->d_I12, m->d_D12, g, cu, out, scale)
+        NLG_FOR_N(DV3)
+#undef DV3
+    } else {
+#define DV2(N_)                                                                                            \
+    {                                                                                                      \
+        constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                       \
+        hipLaunchKernelGGL((k_opdiv2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
+                           m->d_I12, m->d_D12, g, cu, out, scale);                                         \
+    }
+        NLG_FOR_N(DV2)
+#undef DV2
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_opbinv(nlg_mesh *m, double *const *w) {
+    NLG_TRY(sem_gs(m, w, m->dim));
+    F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
+    CF3 wt = {{m->d_mbinv[0], m->d_mbinv[1], m->d_mbinv[2]}};
+    if (m->dim == 3)
+        hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn);
+    else
+        hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out) {
+    double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
+    NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
+    NLG_TRY(sem_opgradt(m, p, w));
+    NLG_TRY(sem_opbinv(m, w));
+    NLG_TRY(sem_opdiv(m, w, out, 1.0));
+    return 0;
+}
+
+int sem_ortho(nlg_mesh *m, double *p) {
+    if (m->has_outflow) return 0;
+    nlg_ctx *ctx = m->ctx;
+    const int nb = 256;
+    hipLaunchKernelGGL(k_sum_partial, dim3(nb), dim3(NT), 0, ctx->stream, p, m->lpn, ctx->d_partial);
+    double *d_sum = ctx->d_scalars + 4000;
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(1), 0, ctx->stream, ctx->d_partial, nb, d_sum);
+    NLG_TRY(allreduce_sum(ctx, d_sum, 1));
+    hipLaunchKernelGGL(k_sub_mean, dim3(grid_for(m->lpn)), dim3(NT), 0, ctx->stream, p, m->lpn, d_sum,
+                       1.0 / (double)m->lpn_global);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_cfl(nlg_mesh *m, double *const *U, double dt, double *cfl_host) {
+    nlg_ctx *ctx = m->ctx;
+    CF9 r;
+    for (int q = 0; q < 9; ++q) r.p[q] = m->d_rst[q];
+    CF3 cu = {{U[0], U[1], m->dim == 3 ? U[2] : nullptr}};
+    const int nb = 256;
+    hipLaunchKernelGGL(k_cfl, dim3(nb), dim3(NT), 0, ctx->stream, m->dim, m->n, m->E, r, m->d_jac, m->d_rdr, cu, dt,
+                       ctx->d_partial);
+    double *d_out = ctx->d_scalars + 4001;
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(1), 0, ctx->stream, ctx->d_partial, nb, d_out);
+    NLG_HIP(hipGetLastError());
+    NLG_TRY(allreduce_max(ctx, d_out, 1));
+    return scalars_to_host(ctx, 4001, 1, cfl_host);
+}
+
+// generic tensor apply launcher (set-up and convection paths)
+int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, const double *Mx, const double *My,
+               const double *Mz, const double *wt) {
+    const int nmax = std::max(nin, nout);
+    const size_t cap = (size_t)nmax * nmax * (m->dim == 3 ? nmax : 1);
+    hipLaunchKernelGGL(k_tensor_generic, dim3((unsigned)m->E), dim3(NT), 2 * cap * sizeof(double), m->ctx->stream, in, out,
+                       m->dim, nin, nout, Mx, My, Mz, wt, m->E);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+// Pre-computation of the base-flow part of the convective term on the fine mesh:
+//   Ur[j]      = sum_m rstdw[j][m] Uf_m                     (dim fields)
+//   GU[i*dim+m] = sum_j rstdw[j][m] dU_i/dr_j               (dim^2 fields)
+int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
+    const int dim = m->dim;
+    CF9 rd;
+    for (int q = 0; q < 9; ++q) rd.p[q] = m->d_rstdw[q];
+    double *t[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
+    NLG_CHECK(t[0] && t[1], "sem_conv_setup: scratch allocation failed");
+    for (int i = 0; i < dim; ++i) NLG_TRY(sem_tensor(m, U[i], t[i], m->n, m->nd, m->d_Jd, m->d_Jd, m->d_Jd, nullptr));
+    {
+        CF3 uf = {{t[0], t[1], t[2]}};
+        F3 ur = {{Ur[0], Ur[1], dim == 3 ? Ur[2] : nullptr}};
+        hipLaunchKernelGGL(k_conv_ur, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, uf, ur);
+    }
+    for (int i = 0; i < dim; ++i) {
+        for (int j = 0; j < dim; ++j)
+            NLG_TRY(sem_tensor(m, U[i], t[j], m->n, m->nd, j == 0 ? m->d_DJd : m->d_Jd, j == 1 ? m->d_DJd : m->d_Jd,
+                               j == 2 ? m->d_DJd : m->d_Jd, nullptr));
+        CF3 du = {{t[0], t[1], t[2]}};
+        F3 gu = {{GU[i * dim + 0], GU[i * dim + 1], dim == 3 ? GU[i * dim + 2] : nullptr}};
+        hipLaunchKernelGGL(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, du, gu);
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+// out_i = weak linearised convective term (B-weighted, element-local), see oracle/sem.py lns_conv_weak
+int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
+    const int dim = m->dim;
+    double *uf[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
+    double *du[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), dim == 3 ? sem_scratchd(m, 5) : nullptr};
+    double *acc = sem_scratchd(m, 6);
+    NLG_CHECK(uf[0] && du[0] && acc, "sem_conv_apply: scratch allocation failed");
+    for (int i = 0; i < dim; ++i) NLG_TRY(sem_tensor(m, u[i], uf[i], m->n, m->nd, m->d_Jd, m->d_Jd, m->d_Jd, nullptr));
+    CF3 cur = {{Ur[0], Ur[1], dim == 3 ? Ur[2] : nullptr}};
+    CF3 cuf = {{uf[0], uf[1], uf[2]}};
+    for (int i = 0; i < dim; ++i) {
+        for (int j = 0; j < dim; ++j)
+            NLG_TRY(sem_tensor(m, u[i], du[j], m->n, m->nd, j == 0 ? m->d_DJd : m->d_Jd, j == 1 ? m->d_DJd : m->d_Jd,
+                               j == 2 ? m->d_DJd : m->d_Jd, nullptr));
+        CF3 cdu = {{du[0], du[1], du[2]}};
+        CF3 gsel;
+        for (int mm = 0; mm < 3; ++mm) gsel.p[mm] = nullptr;
+        // direct: GU[i][m] ; adjoint: GU[m][i]
+        for (int mm = 0; mm < dim; ++mm) gsel.p[mm] = adjoint ? GU[mm * dim + i] : GU[i * dim + mm];
+        hipLaunchKernelGGL(k_conv_combine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdu, cuf,
+                           gsel, adjoint ? -1.0 : 1.0, acc);
+        NLG_TRY(sem_tensor(m, acc, out[i], m->nd, m->n, m->d_Jdt, m->d_Jdt, m->d_Jdt, nullptr));
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int sem_ediag(nlg_mesh *m, double *out) {
+    // diag_k = sum_i sum_{j,jj} g_ji,k g_jji,k [ (M_j o M_jj) applied to c_i ]_k , c_i = mask_i binvm1
+    const int dim = m->dim, n = m->n, n2 = m->n2;
+    const nlg_ops1d &o = m->ops;
+    // elementwise-product matrices II, ID, DD (n2 x n)
+    std::vector<double> II((size_t)n2 * n), ID((size_t)n2 * n), DD((size_t)n2 * n);
+    for (int q = 0; q < n2 * n; ++q) {
+        II[q] = o.I12[q] * o.I12[q];
+        ID[q] = o.I12[q] * o.D12[q];
+        DD[q] = o.D12[q] * o.D12[q];
+    }
+    double *dII, *dID, *dDD;
+    NLG_TRY(upload(II, &dII));
+    NLG_TRY(upload(ID, &dID));
+    NLG_TRY(upload(DD, &dDD));
+    double *tmp = sem_scratch2(m, 6), *acc = out;
+    NLG_CHECK(tmp, "sem_ediag: scratch allocation failed");
+    NLG_HIP(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)m->lps, m->ctx->stream));
+    double *prod = sem_scratch2(m, 7);
+    for (int i = 0; i < dim; ++i)
+        for (int j = 0; j < dim; ++j)
+            for (int jj = 0; jj < dim; ++jj) {
+                const double *M[3];
+                for (int ax = 0; ax < 3; ++ax) {
+                    const bool a = (ax == j), b = (ax == jj);
+                    M[ax] = (a && b) ? dDD : ((a || b) ? dID : dII);
+                }
+                NLG_TRY(sem_tensor(m, m->d_mbinv[i], tmp, n, n2, M[0], M[1], M[2], nullptr));
+                hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, prod, m->d_rst2w[j * dim + i],
+                                   m->d_rst2w[jj * dim + i], m->lpn);
+                // acc += prod * tmp  (reuse k_mul then add via colmul-less path)
+                hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, tmp, prod, tmp, m->lpn);
+                hipLaunchKernelGGL(k_addto, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, acc, tmp, m->lpn);
+            }
+    NLG_HIP(hipStreamSynchronize(m->ctx->stream));
+    hipFree(dII);
+    hipFree(dID);
+    hipFree(dDD);
+    return 0;
+}
+
+}  // namespace nlg
+
+// =================================================================================================
+// C ABI: mesh
+// =================================================================================================
+extern "C" {
+
+int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
+    NLG_CHECK(ctx && d && out, "nlg_mesh_create: NULL argument");
+    NLG_CHECK(d->dim == 2 || d->dim == 3, "nlg_mesh_create: dim must be 2 or 3 (got %d)", d->dim);
+    NLG_CHECK(d->n >= 4 && d->n <= 12 && d->n != 11, "nlg_mesh_create: lx1 = %d unsupported (4..10, 12)", d->n);
+    NLG_CHECK(d->nelv >= 1, "nlg_mesh_create: nelv must be >= 1 (got %lld)", (long long)d->nelv);
+    NLG_CHECK(d->xm1 && d->ym1 && (d->dim == 2 || d->zm1), "nlg_mesh_create: coordinate arrays missing");
+    NLG_CHECK(d->glo_num, "nlg_mesh_create: glo_num missing");
+    NLG_CHECK(d->v1mask && d->v2mask && (d->dim == 2 || d->v3mask), "nlg_mesh_create: velocity masks missing");
+    NLG_HIP(hipSetDevice(ctx->device));
+    nlg_mesh *m = new nlg_mesh();
+    m->ctx = ctx;
+    m->dim = d->dim;
+    m->n = d->n;
+    m->n2 = d->n - 2;
+    m->nd = d->lxd > 0 ? d->lxd : (3 * d->n) / 2;
+    NLG_CHECK(m->nd >= m->n && m->nd <= 18, "nlg_mesh_create: lxd = %d out of range", m->nd);
+    m->E = d->nelv;
+    const int dim = m->dim, n = m->n, n2 = m->n2, nd = m->nd;
+    m->np1 = n * n * (dim == 3 ? n : 1);
+    m->np2 = n2 * n2 * (dim == 3 ? n2 : 1);
+    m->npd = nd * nd * (dim == 3 ? nd : 1);
+    m->lvn = m->E * m->np1;
+    m->lpn = m->E * m->np2;
+    m->lfn = m->E * m->npd;
+    NLG_CHECK(m->lvn < (int64_t)2000000000, "nlg_mesh_create: local dof count %lld exceeds 32-bit gather-scatter indices",
+              (long long)m->lvn);
+    m->lvs = round_up(m->lvn, kAlign);
+    m->lps = round_up(m->lpn, kAlign);
+    m->has_outflow = d->has_outflow;
+    hipStream_t s = ctx->stream;
+
+    // ---- 1-D operators
+    nlg_ops1d &o = m->ops;
+    o.n = n;
+    o.n2 = n2;
+    o.nd = nd;
+    gll_nodes(n, o.z1, o.w1);
+    gl_nodes(n2, o.z2, o.w2);
+    gl_nodes(nd, o.zd, o.wd);
+    o.D = deriv_mat(o.z1);
+    o.I12 = interp_mat(o.z1, o.z2);
+    o.D12 = matmul(o.I12, o.D, n2, n, n);
+    o.Jd = interp_mat(o.z1, o.zd);
+    o.DJd = matmul(o.Jd, o.D, nd, n, n);
+    o.rdr.resize(n);
+    for (int i = 0; i < n; ++i) {
+        double dr;
+        if (i == 0)
+            dr = o.z1[1] - o.z1[0];
+        else if (i == n - 1)
+            dr = o.z1[n - 1] - o.z1[n - 2];
+        else
+            dr = 0.5 * (o.z1[i + 1] - o.z1[i - 1]);
+        o.rdr[i] = 1.0 / dr;
+    }
+    NLG_TRY(upload(o.D, &m->d_D));
+    NLG_TRY(upload(transpose(o.D, n, n), &m->d_Dt));
+    NLG_TRY(upload(o.I12, &m->d_I12));
+    NLG_TRY(upload(transpose(o.I12, n2, n), &m->d_I12t));
+    NLG_TRY(upload(o.D12, &m->d_D12));
+    NLG_TRY(upload(transpose(o.D12, n2, n), &m->d_D12t));
+    NLG_TRY(upload(o.Jd, &m->d_Jd));
+    NLG_TRY(upload(transpose(o.Jd, nd, n), &m->d_Jdt));
+    NLG_TRY(upload(o.DJd, &m->d_DJd));
+    NLG_TRY(upload(transpose(o.DJd, nd, n), &m->d_DJdt));
+    NLG_TRY(upload(o.rdr, &m->d_rdr));
+    NLG_TRY(upload(o.w1, &m->d_w1));
+    NLG_TRY(upload(o.w2, &m->d_w2));
+    NLG_TRY(upload(o.wd, &m->d_wd));
+
+    // ---- coordinates, masks
+    const double *hx[3] = {d->xm1, d->ym1, d->zm1};
+    const double *hm[3] = {d->v1mask, d->v2mask, d->v3mask};
+    for (int c = 0; c < dim; ++c) {
+        NLG_TRY(dalloc(&m->d_x[c], m->lvs, s));
+        NLG_HIP(hipMemcpyAsync(m->d_x[c], hx[c], sizeof(double) * (size_t)m->lvn, hipMemcpyHostToDevice, s));
+        NLG_TRY(dalloc(&m->d_mask[c], m->lvs, s));
+        NLG_HIP(hipMemcpyAsync(m->d_mask[c], hm[c], sizeof(double) * (size_t)m->lvn, hipMemcpyHostToDevice, s));
+        NLG_TRY(dalloc(&m->d_mbinv[c], m->lvs, s));
+    }
+    NLG_TRY(dalloc(&m->d_tmask, m->lvs, s));
+    if (d->tmask)
+        NLG_HIP(hipMemcpyAsync(m->d_tmask, d->tmask, sizeof(double) * (size_t)m->lvn, hipMemcpyHostToDevice, s));
+    else
+        hipLaunchKernelGGL(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_tmask, 1.0, m->lvn);
+    m->h_lglel.resize(m->E);
+    for (int64_t e = 0; e < m->E; ++e) m->h_lglel[e] = d->lglel ? d->lglel[e] : e;
+    NLG_HIP(hipMalloc(&m->d_lglel, sizeof(int64_t) * (size_t)m->E));
+    NLG_HIP(hipMemcpyAsync(m->d_lglel, m->h_lglel.data(), sizeof(int64_t) * (size_t)m->E, hipMemcpyHostToDevice, s));
+
+    // ---- geometry
+    for (int q = 0; q < dim * dim; ++q) NLG_TRY(dalloc(&m->d_rst[q], m->lvs, s));
+    NLG_TRY(dalloc(&m->d_jac, m->lvs, s));
+    NLG_TRY(dalloc(&m->d_bm1, m->lvs, s));
+    NLG_TRY(dalloc(&m->d_binvm1, m->lvs, s));
+    NLG_TRY(dalloc(&m->d_vmult, m->lvs, s));
+    const int ng = dim == 3 ? 6 : 3;
+    for (int q = 0; q < ng; ++q) NLG_TRY(dalloc(&m->d_G[q], m->lvs, s));
+    int *d_bad;
+    NLG_HIP(hipMalloc(&d_bad, sizeof(int)));
+    NLG_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    {
+        CF3 X = {{m->d_x[0], m->d_x[1], m->d_x[2]}};
+        F9 r;
+        for (int q = 0; q < 9; ++q) r.p[q] = m->d_rst[q];
+        hipLaunchKernelGGL(k_geom, dim3((unsigned)m->E), dim3(NT), sizeof(double) * 3 * m->np1, s, dim, n, m->d_D, m->d_w1, X, r,
+                           m->d_jac, m->d_bm1, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], d_bad);
+        NLG_HIP(hipGetLastError());
+    }
+    int bad = 0;
+    NLG_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    NLG_HIP(hipStreamSynchronize(s));
+    hipFree(d_bad);
+    if (bad) {
+        set_error("nlg_mesh_create: non-positive Jacobian in the mesh");
+        return 1;
+    }
+
+    // ---- gather-scatter set-up (host): groups of local dofs sharing a label
+    {
+        std::vector<int> order((size_t)m->lvn);
+        std::iota(order.begin(), order.end(), 0);
+        const int64_t *glo = d->glo_num;
+        std::sort(order.begin(), order.end(), [glo](int a, int b) { return glo[a] < glo[b] || (glo[a] == glo[b] && a < b); });
+        std::vector<int> off, idx;
+        off.push_back(0);
+        // collect groups, then order groups by their first (smallest) local index for locality
+        std::vector<std::pair<int, std::pair<int, int>>> groups;   // (first index, (begin, end) in `order`)
+        int64_t b = 0;
+        while (b < m->lvn) {
+            int64_t e = b + 1;
+            while (e < m->lvn && glo[order[e]] == glo[order[b]]) ++e;
+            if (e - b >= 2) groups.push_back({order[b], {(int)b, (int)e}});
+            b = e;
+        }
+        std::sort(groups.begin(), groups.end());
+        for (auto &g : groups) {
+            for (int q = g.second.first; q < g.second.second; ++q) idx.push_back(order[q]);
+            off.push_back((int)idx.size());
+        }
+        m->gs.ngroups = (int64_t)groups.size();
+        m->gs.nshared = (int64_t)idx.size();
+        NLG_HIP(hipMalloc(&m->gs.d_offsets, sizeof(int) * off.size()));
+        NLG_HIP(hipMalloc(&m->gs.d_indices, sizeof(int) * std::max<size_t>(idx.size(), 1)));
+        NLG_HIP(hipMemcpy(m->gs.d_offsets, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
+        if (!idx.empty()) NLG_HIP(hipMemcpy(m->gs.d_indices, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    }
+    // ---- multiplicity, assembled inverse mass, fused opbinv weights
+    {
+        hipLaunchKernelGGL(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, 1.0, m->lvn);
+        double *f[1] = {m->d_vmult};
+        NLG_TRY(sem_gs(m, f, 1));
+        hipLaunchKernelGGL(k_recip, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, m->d_vmult, m->lvn);
+        NLG_HIP(hipMemcpyAsync(m->d_binvm1, m->d_bm1, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToDevice, s));
+        double *f2[1] = {m->d_binvm1};
+        NLG_TRY(sem_gs(m, f2, 1));
+        hipLaunchKernelGGL(k_recip, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_binvm1, m->d_binvm1, m->lvn);
+        for (int c = 0; c < dim; ++c)
+            hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_mbinv[c], m->d_mask[c], m->d_binvm1, m->lvn);
+        NLG_HIP(hipGetLastError());
+    }
+
+    // ---- pressure-mesh and fine-mesh metrics
+    for (int q = 0; q < dim * dim; ++q) {
+        NLG_TRY(dalloc(&m->d_rst2w[q], m->lps, s));
+        NLG_TRY(sem_tensor(m, m->d_rst[q], m->d_rst2w[q], n, n2, m->d_I12, m->d_I12, m->d_I12, m->d_w2));
+        NLG_HIP(hipMalloc(&m->d_rstdw[q], sizeof(double) * (size_t)m->lfn));
+        NLG_TRY(sem_tensor(m, m->d_rst[q], m->d_rstdw[q], n, nd, m->d_Jd, m->d_Jd, m->d_Jd, m->d_wd));
+    }
+    NLG_TRY(dalloc(&m->d_bm2, m->lps, s));
+    NLG_TRY(dalloc(&m->d_bm2inv, m->lps, s));
+    NLG_TRY(sem_tensor(m, m->d_jac, m->d_bm2, n, n2, m->d_I12, m->d_I12, m->d_I12, m->d_w2));
+    hipLaunchKernelGGL(k_recip, dim3(grid_for(m->lpn)), dim3(NT), 0, s, m->d_bm2inv, m->d_bm2, m->lpn);
+
+    // ---- volumes (host sums; set-up only)
+    {
+        std::vector<double> h((size_t)std::max(m->lvn, m->lpn));
+        NLG_HIP(hipMemcpyAsync(h.data(), m->d_bm1, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, s));
+        NLG_HIP(hipStreamSynchronize(s));
+        double v = 0.0;
+        for (int64_t q = 0; q < m->lvn; ++q) v += h[q];
+        m->volvm1 = v;
+        NLG_HIP(hipMemcpyAsync(h.data(), m->d_bm2, sizeof(double) * (size_t)m->lpn, hipMemcpyDeviceToHost, s));
+        NLG_HIP(hipStreamSynchronize(s));
+        v = 0.0;
+        for (int64_t q = 0; q < m->lpn; ++q) v += h[q];
+        m->volvm2 = v;
+        m->lpn_global = m->lpn;
+    }
+
+    // ---- names for read-back
+    auto reg = [&](const char *nm, const double *p, int64_t len) {
+        m->named[nm] = p;
+        m->named_len[nm] = len;
+    };
+    reg("bm1", m->d_bm1, m->lvn);
+    reg("binvm1", m->d_binvm1, m->lvn);
+    reg("vmult", m->d_vmult, m->lvn);
+    reg("jac", m->d_jac, m->lvn);
+    reg("bm2", m->d_bm2, m->lpn);
+    {
+        const char *gn3[6] = {"g11", "g12", "g13", "g22", "g23", "g33"};
+        const char *gn2[3] = {"g11", "g12", "g22"};
+        for (int q = 0; q < ng; ++q) reg(dim == 3 ? gn3[q] : gn2[q], m->d_G[q], m->lvn);
+        char nm[16];
+        for (int j = 0; j < dim; ++j)
+            for (int i = 0; i < dim; ++i) {
+                snprintf(nm, sizeof(nm), "rst%d%d", j + 1, i + 1);
+                reg(nm, m->d_rst[j * dim + i], m->lvn);
+                snprintf(nm, sizeof(nm), "rst2w%d%d", j + 1, i + 1);
+                reg(nm, m->d_rst2w[j * dim + i], m->lpn);
+                snprintf(nm, sizeof(nm), "rstdw%d%d", j + 1, i + 1);
+                reg(nm, m->d_rstdw[j * dim + i], m->lfn);
+            }
+    }
+    NLG_HIP(hipStreamSynchronize(s));
+    *out = m;
+    return 0;
+}
+
+int nlg_mesh_destroy(nlg_mesh *m) {
+    if (!m) return 0;
+    hipDeviceSynchronize();
+    double *ptrs[] = {m->d_D, m->d_Dt, m->d_I12, m->d_I12t, m->d_D12, m->d_D12t, m->d_Jd, m->d_Jdt, m->d_DJd, m->d_DJdt,
+                      m->d_rdr, m->d_w1, m->d_w2, m->d_wd, m->d_jac, m->d_bm1, m->d_binvm1, m->d_vmult, m->d_tmask,
+                      m->d_bm2, m->d_bm2inv};
+    for (double *p : ptrs)
+        if (p) hipFree(p);
+    for (int c = 0; c < 3; ++c) {
+        if (m->d_x[c]) hipFree(m->d_x[c]);
+        if (m->d_mask[c]) hipFree(m->d_mask[c]);
+        if (m->d_mbinv[c]) hipFree(m->d_mbinv[c]);
+    }
+    for (int q = 0; q < 9; ++q) {
+        if (m->d_rst[q]) hipFree(m->d_rst[q]);
+        if (m->d_rst2w[q]) hipFree(m->d_rst2w[q]);
+        if (m->d_rstdw[q]) hipFree(m->d_rstdw[q]);
+    }
+    for (int q = 0; q < 6; ++q)
+        if (m->d_G[q]) hipFree(m->d_G[q]);
+    if (m->d_lglel) hipFree(m->d_lglel);
+    if (m->gs.d_offsets) hipFree(m->gs.d_offsets);
+    if (m->gs.d_indices) hipFree(m->gs.d_indices);
+    for (double *p : m->scratch1) hipFree(p);
+    for (double *p : m->scratch2) hipFree(p);
+    for (double *p : m->scratchd) hipFree(p);
+    delete m;
+    return 0;
+}
+
+int nlg_mesh_sizes(const nlg_mesh *m, int64_t *lvn, int64_t *lpn, int *dim, int *n) {
+    NLG_CHECK(m, "nlg_mesh_sizes: NULL mesh");
+    if (lvn) *lvn = m->lvn;
+    if (lpn) *lpn = m->lpn;
+    if (dim) *dim = m->dim;
+    if (n) *n = m->n;
+    return 0;
+}
+
+int nlg_mesh_get(const nlg_mesh *m, const char *name, double *out, int64_t count) {
+    NLG_CHECK(m && name && out, "nlg_mesh_get: NULL argument");
+    auto it = m->named.find(name);
+    NLG_CHECK(it != m->named.end(), "nlg_mesh_get: unknown array '%s'", name);
+    const int64_t len = m->named_len.at(name);
+    NLG_CHECK(count == len, "nlg_mesh_get: count %lld != length %lld of '%s'", (long long)count, (long long)len, name);
+    NLG_HIP(hipMemcpyAsync(out, it->second, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, m->ctx->stream));
+    NLG_HIP(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+// ---- rand (needs the gather-scatter, hence lives here) ---------------------------------------------
+int nlg_vec_rand(nlg_vec *self, int ifnorm, uint64_t seed) {
+    NLG_CHECK(self, "nlg_vec_rand: NULL vector");
+    nlg_mesh *m = self->mesh;
+    hipStream_t s = m->ctx->stream;
+    CF3 X = {{m->d_x[0], m->d_x[1], m->d_x[2]}};
+    for (int f = 0; f < self->ncomp; ++f) {
+        double *fld = f < m->dim ? self->vel(f) : self->theta(f - m->dim);
+        hipLaunchKernelGGL(k_rand_add, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->dim, m->n, m->E, m->d_lglel, X, fld, f, seed);
+    }
+    // opdssum, opcolv(vmult), dsavg, bcdirvc   (real_vectors.f90:100-105)
+    double *v[3] = {self->vel(0), self->vel(1), m->dim == 3 ? self->vel(2) : nullptr};
+    F3 fv = {{v[0], v[1], v[2]}};
+    CF3 vm = {{m->d_vmult, m->d_vmult, m->d_vmult}};
+    CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
+    for (int pass = 0; pass < 2; ++pass) {
+        NLG_TRY(sem_gs(m, v, m->dim));
+        if (m->dim == 3)
+            hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, vm, m->lvn);
+        else
+            hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, vm, m->lvn);
+    }
+    if (m->dim == 3)
+        hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, mk, m->lvn);
+    else
+        hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, mk, m->lvn);
+    for (int sc = 0; sc < self->nscal; ++sc) {
+        double *t[1] = {self->theta(sc)};
+        F3 ft = {{t[0], nullptr, nullptr}};
+        CF3 vm1 = {{m->d_vmult, nullptr, nullptr}};
+        CF3 tm = {{m->d_tmask, nullptr, nullptr}};
+        NLG_TRY(sem_gs(m, t, 1));
+        hipLaunchKernelGGL(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, ft, vm1, m->lvn);
+        hipLaunchKernelGGL(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, ft, tm, m->lvn);
+    }
+    NLG_HIP(hipGetLastError());
+    if (ifnorm) {
+        double nrm = 0.0;
+        NLG_TRY(nlg_vec_norm(self, &nrm));
+        NLG_CHECK(nrm > 0.0, "nlg_vec_rand: zero norm");
+        NLG_TRY(nlg_vec_scal(self, 1.0 / nrm));
+    }
+    self->nrst = 0;
+    return 0;
+}
+
+// ---- operator-level entry points ------------------------------------------------------------------
+static int vel_ptrs(const nlg_vec *v, double **p) {
+    for (int i = 0; i < 3; ++i) p[i] = i < v->mesh->dim ? v->vel(i) : nullptr;
+    return 0;
+}
+
+int nlg_op_helmholtz(nlg_mesh *m, const nlg_vec *in, nlg_vec *out, double h1, double h2, int assemble) {
+    NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m, "nlg_op_helmholtz: bad arguments");
+    NLG_CHECK(in != out, "nlg_op_helmholtz: in-place application is not supported");
+    double *u[3], *w[3];
+    vel_ptrs(in, u);
+    vel_ptrs(out, w);
+    NLG_TRY(sem_axhelm(m, u, w, m->dim, h1, h2));
+    if (assemble) {
+        NLG_TRY(sem_gs(m, w, m->dim));
+        F3 fw = {{w[0], w[1], w[2]}};
+        CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
+        if (m->dim == 3)
+            hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, fw, mk, m->lvn);
+        else
+            hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, fw, mk, m->lvn);
+        NLG_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int nlg_op_dssum(nlg_mesh *m, nlg_vec *v) {
+    NLG_CHECK(m && v && v->mesh == m, "nlg_op_dssum: bad arguments");
+    double *w[3];
+    vel_ptrs(v, w);
+    return sem_gs(m, w, m->dim);
+}
+
+int nlg_op_cdabdtp(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {
+    NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m, "nlg_op_cdabdtp: bad arguments");
+    return sem_cdabdtp(m, in->pr(), out->pr());
+}
+
+int nlg_op_opdiv(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {
+    NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m, "nlg_op_opdiv: bad arguments");
+    double *u[3];
+    vel_ptrs(in, u);
+    return sem_opdiv(m, u, out->pr(), 1.0);
+}
+
+int nlg_op_opgradt(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {
+    NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m, "nlg_op_opgradt: bad arguments");
+    double *w[3];
+    vel_ptrs(out, w);
+    return sem_opgradt(m, in->pr(), w);
+}
+
+int nlg_op_cfl(nlg_mesh *m, const nlg_vec *base, double dt, double *cfl) {
+    NLG_CHECK(m && base && cfl && base->mesh == m, "nlg_op_cfl: bad arguments");
+    double *u[3];
+    vel_ptrs(base, u);
+    return sem_cfl(m, u, dt, cfl);
+}
+
+}  // extern "C"

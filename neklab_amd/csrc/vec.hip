@@ -1,0 +1,621 @@
+// nek_dvector vector space and Krylov-basis block kernels (gfx950).
+//
+// Layout of one vector in HBM (doubles):
+//   [ v_0 | v_1 | (v_2) | theta_0.. | pr ]  main block, `main_len = ncomp*lvs + lps`
+//   followed by lorder-1 history blocks of the same shape (reference: neklab_vectors.f90:30-35).
+// `lvs`/`lps` are the field lengths rounded up to 32 doubles; the padding is zero in every vector and
+// in the weight `bm1`, so every kernel can sweep whole padded ranges with 16-byte accesses.
+//
+// Roofline: every kernel here is HBM-bound (<= 0.25 flop/B).  Algorithmic bytes per call:
+//   scal 16 B/dof, axpby 24 B/dof, dot 24 B/dof (a, b, bm1), block_dot 8*(k+2) B per inner-product
+//   dof, block_axpy 8*(k+2) B per dof.
+#include "internal.h"
+
+using namespace nlg;
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over the 256 threads of a block; valid in thread 0. `sm` needs 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += sm[i];
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(NT) void k_fill(double2 *x, double v, int64_t n2) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) x[i] = make_double2(v, v);
+}
+
+__global__ __launch_bounds__(NT) void k_copy(double2 *y, const double2 *x, int64_t n2) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) y[i] = x[i];
+}
+
+// reference cmult: x(i) = x(i)*alpha  (real_vectors.f90:131)
+__global__ __launch_bounds__(NT) void k_scal(double2 *x, double a, int64_t n2) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        double2 v = x[i];
+        v.x = __dmul_rn(v.x, a);
+        v.y = __dmul_rn(v.y, a);
+        x[i] = v;
+    }
+}
+
+// x *= f(s[0]) with the scalar on device: mode 0: 1/sqrt(s), mode 1: 1/s
+__global__ __launch_bounds__(NT) void k_scal_dev(double2 *x, const double *s, int mode, int64_t n2) {
+    const double sv = s[0];
+    const double a = (mode == 0) ? (sv > 0.0 ? 1.0 / sqrt(sv) : 0.0) : 1.0 / sv;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        double2 v = x[i];
+        v.x = __dmul_rn(v.x, a);
+        v.y = __dmul_rn(v.y, a);
+        x[i] = v;
+    }
+}
+
+// reference nek_daxpby (real_vectors.f90:162-206): scal(beta) then add2s2(self, vec, alpha) on the main
+// block, and for each valid history slot of self: slot += alpha * (vec main | vec slot).
+// Rounding mirrors the two sweeps: fl(fl(beta*y) + fl(alpha*x)).
+__global__ __launch_bounds__(NT) void k_axpby(double2 *y, const double2 *x, double a, double b, int64_t n2,
+                                              int nrst, int64_t blk2, int consistent) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        const double2 xv = x[i];
+        const double ax0 = __dmul_rn(a, xv.x), ax1 = __dmul_rn(a, xv.y);
+        double2 yv = y[i];
+        yv.x = __dadd_rn(__dmul_rn(yv.x, b), ax0);
+        yv.y = __dadd_rn(__dmul_rn(yv.y, b), ax1);
+        y[i] = yv;
+        for (int r = 1; r <= nrst; ++r) {
+            double2 rv = y[i + r * blk2];
+            double s0 = ax0, s1 = ax1;
+            if (consistent) {
+                const double2 xr = x[i + r * blk2];
+                s0 = __dmul_rn(a, xr.x);
+                s1 = __dmul_rn(a, xr.y);
+            }
+            rv.x = __dadd_rn(__dmul_rn(rv.x, b), s0);
+            rv.y = __dadd_rn(__dmul_rn(rv.y, b), s1);
+            y[i + r * blk2] = rv;
+        }
+    }
+}
+
+// first stage of glsc3-type sums over the ncomp inner-product fields:
+// partial[c*nblk + blk] = sum_{i in chunk} a_c[i] b_c[i] bm1[i]
+__global__ __launch_bounds__(NT) void k_dot_partial(const double *a, const double *b, const double *bm1, int64_t lvs,
+                                                    int nblk, double *partial) {
+    __shared__ double sm[4];
+    const int c = blockIdx.y;
+    const int64_t n2 = lvs >> 1;
+    const int64_t per = (n2 + nblk - 1) / nblk;
+    const int64_t beg = blockIdx.x * per, end = (beg + per < n2) ? beg + per : n2;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a + c * lvs);
+    const double2 *b2 = reinterpret_cast<const double2 *>(b + c * lvs);
+    const double2 *m2 = reinterpret_cast<const double2 *>(bm1);
+    double acc = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += NT) {
+        const double2 av = a2[i], bv = b2[i], mv = m2[i];
+        acc += av.x * bv.x * mv.x + av.y * bv.y * mv.y;
+    }
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[c * nblk + blockIdx.x] = s;
+}
+
+// second stage, fixed order => deterministic: out[row] (+)= sum_b partial[row*nper + b]
+__global__ __launch_bounds__(NT) void k_reduce_rows(const double *partial, int nper, double *out, int accumulate,
+                                                    double *out2) {
+    __shared__ double sm[4];
+    const double *p = partial + (int64_t)blockIdx.x * nper;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nper; i += NT) acc += p[i];
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = s;
+        if (accumulate) out2[blockIdx.x] += s;
+    }
+}
+
+// h_j = V_j^T (bm1 o w) for a tile of KB basis vectors; V is read exactly once.
+template <int KB>
+__global__ __launch_bounds__(NT) void k_block_dot(const double *V, int64_t vstride, int k, const double *w,
+                                                  const double *bm1, int64_t lvs, int nblk, int nper,
+                                                  double *partial) {
+    __shared__ double sm[4 * KB];
+    const int c = blockIdx.y;
+    const int j0 = blockIdx.z * KB;
+    const int kc = (k - j0 < KB) ? (k - j0) : KB;
+    const int64_t n2 = lvs >> 1;
+    const int64_t per = (n2 + nblk - 1) / nblk;
+    const int64_t beg = blockIdx.x * per, end = (beg + per < n2) ? beg + per : n2;
+    const double2 *w2 = reinterpret_cast<const double2 *>(w + c * lvs);
+    const double2 *m2 = reinterpret_cast<const double2 *>(bm1);
+    const double2 *v2[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        const int jj = (j < kc) ? j : 0;
+        v2[j] = reinterpret_cast<const double2 *>(V + (int64_t)(j0 + jj) * vstride + c * lvs);
+    }
+    double acc[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += NT) {
+        const double2 wv = w2[i], mv = m2[i];
+        const double x0 = wv.x * mv.x, x1 = wv.y * mv.y;
+        double2 vv[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) vv[j] = v2[j][i];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) acc[j] += vv[j].x * x0 + vv[j].y * x1;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        const double s = wave_sum(acc[j]);
+        if (lane == 0) sm[wid * KB + j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kc) {
+        const int j = threadIdx.x;
+        const double s = sm[j] + sm[KB + j] + sm[2 * KB + j] + sm[3 * KB + j];
+        partial[(int64_t)(j0 + j) * nper + c * nblk + blockIdx.x] = s;
+    }
+}
+
+// w -= sum_j h_j V_j on the main block; history slots of w receive the same correction
+// (reference axpby quirk) or the combination of the basis history (consistent mode).
+__global__ __launch_bounds__(NT) void k_block_axpy(const double *V, int64_t vstride, int k, const double *h, double *w,
+                                                   int64_t n2, int nrst, int64_t blk2, int consistent, double sign) {
+    extern __shared__ double sh[];
+    for (int j = threadIdx.x; j < k; j += NT) sh[j] = h[j];
+    __syncthreads();
+    double2 *w2 = reinterpret_cast<double2 *>(w);
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        double s0 = 0.0, s1 = 0.0;
+        const double2 *v = reinterpret_cast<const double2 *>(V) + i;
+        const int64_t vs2 = vstride >> 1;
+        int j = 0;
+        for (; j + 8 <= k; j += 8) {
+            double2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = v[(int64_t)(j + u) * vs2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += sh[j + u] * t[u].x;
+                s1 += sh[j + u] * t[u].y;
+            }
+        }
+        for (; j < k; ++j) {
+            const double2 t = v[(int64_t)j * vs2];
+            s0 += sh[j] * t.x;
+            s1 += sh[j] * t.y;
+        }
+        double2 wv = w2[i];
+        wv.x += sign * s0;
+        wv.y += sign * s1;
+        w2[i] = wv;
+        for (int r = 1; r <= nrst; ++r) {
+            double c0 = s0, c1 = s1;
+            if (consistent) {
+                c0 = c1 = 0.0;
+                for (int jj = 0; jj < k; ++jj) {
+                    const double2 t = v[(int64_t)jj * vs2 + r * blk2];
+                    c0 += sh[jj] * t.x;
+                    c1 += sh[jj] * t.y;
+                }
+            }
+            double2 rv = w2[i + r * blk2];
+            rv.x += sign * c0;
+            rv.y += sign * c1;
+            w2[i + r * blk2] = rv;
+        }
+    }
+}
+
+__global__ void k_vadd(double *a, const double *b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
+inline int grid_for(int64_t n2) {
+    int64_t g = (n2 + NT - 1) / NT;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline int dot_nblk(const nlg_vec *v) {
+    int64_t nb = v->mesh->lvs / 4096;
+    int cap = kMaxBlocksReduce / v->ncomp;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+int check_same(const nlg_vec *a, const nlg_vec *b, const char *who) {
+    NLG_CHECK(a && b, "%s: NULL vector", who);
+    NLG_CHECK(a->mesh == b->mesh && a->nscal == b->nscal && a->lorder == b->lorder,
+              "%s: vectors live on different meshes / layouts (reference: type_error, real_vectors.f90:202-204)", who);
+    return 0;
+}
+
+}  // namespace
+
+namespace nlg {
+
+int dev_dot(const nlg_vec *a, const nlg_vec *b, int slot) {
+    nlg_ctx *ctx = a->mesh->ctx;
+    const int nblk = dot_nblk(a);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nblk, a->ncomp), dim3(NT), 0, ctx->stream, a->d, b->d, a->mesh->d_bm1,
+                       a->mesh->lvs, nblk, ctx->d_partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(NT), 0, ctx->stream, ctx->d_partial, nblk * a->ncomp,
+                       ctx->d_scalars + slot, 0, (double *)nullptr);
+    NLG_HIP(hipGetLastError());
+    NLG_TRY(allreduce_sum(ctx, ctx->d_scalars + slot, 1));
+    return 0;
+}
+
+}  // namespace nlg
+
+static int g_axpby_consistent = 0;
+
+extern "C" {
+
+int nlg_set_axpby_rst_consistent(int flag) {
+    g_axpby_consistent = flag ? 1 : 0;
+    return 0;
+}
+
+int nlg_vec_create(nlg_mesh *mesh, int nscal, int lorder, nlg_vec **out) {
+    NLG_CHECK(mesh && out, "nlg_vec_create: NULL argument");
+    NLG_CHECK(nscal >= 0 && nscal <= 8, "nlg_vec_create: nscal %d out of range", nscal);
+    NLG_CHECK(lorder >= 1 && lorder <= 4, "nlg_vec_create: lorder %d out of range", lorder);
+    nlg_vec *v = new nlg_vec();
+    v->mesh = mesh;
+    v->nscal = nscal;
+    v->lorder = lorder;
+    v->ncomp = mesh->dim + nscal;
+    v->main_len = (int64_t)v->ncomp * mesh->lvs + mesh->lps;
+    v->total_len = v->main_len * lorder;
+    NLG_HIP(hipSetDevice(mesh->ctx->device));
+    hipError_t e = hipMalloc(&v->d, sizeof(double) * (size_t)v->total_len);
+    if (e != hipSuccess) {
+        delete v;
+        set_error("nlg_vec_create: hipMalloc(%zu bytes) failed: %s", sizeof(double) * (size_t)v->total_len,
+                  hipGetErrorString(e));
+        return 1;
+    }
+    NLG_HIP(hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)v->total_len, mesh->ctx->stream));
+    *out = v;
+    return 0;
+}
+
+int nlg_vec_destroy(nlg_vec *v) {
+    if (!v) return 0;
+    if (v->owns && v->d) hipFree(v->d);   // hipFree synchronises; never touch the parent mesh here
+    delete v;
+    return 0;
+}
+
+int nlg_vec_copy(nlg_vec *dst, const nlg_vec *src) {
+    NLG_TRY(check_same(dst, src, "nlg_vec_copy"));
+    if (dst->d != src->d)
+        NLG_HIP(hipMemcpyAsync(dst->d, src->d, sizeof(double) * (size_t)src->total_len, hipMemcpyDeviceToDevice,
+                               src->mesh->ctx->stream));
+    dst->nrst = src->nrst;
+    return 0;
+}
+
+int nlg_vec_clone(const nlg_vec *src, nlg_vec **out) {
+    NLG_CHECK(src && out, "nlg_vec_clone: NULL argument");
+    NLG_TRY(nlg_vec_create(src->mesh, src->nscal, src->lorder, out));
+    return nlg_vec_copy(*out, src);
+}
+
+int nlg_vec_zero(nlg_vec *self) {
+    NLG_CHECK(self, "nlg_vec_zero: NULL vector");
+    NLG_HIP(hipMemsetAsync(self->d, 0, sizeof(double) * (size_t)self->total_len, self->mesh->ctx->stream));
+    self->nrst = 0;
+    return 0;
+}
+
+int nlg_vec_scal(nlg_vec *self, double alpha) {
+    NLG_CHECK(self, "nlg_vec_scal: NULL vector");
+    const int64_t n2 = self->main_len * (1 + self->nrst) / 2;
+    hipLaunchKernelGGL(k_scal, dim3(grid_for(n2)), dim3(NT), 0, self->mesh->ctx->stream,
+                       reinterpret_cast<double2 *>(self->d), alpha, n2);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int nlg_vec_axpby(double alpha, const nlg_vec *vec, double beta, nlg_vec *self) {
+    NLG_TRY(check_same(self, vec, "nlg_vec_axpby"));
+    const int64_t n2 = self->main_len / 2;
+    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n2)), dim3(NT), 0, self->mesh->ctx->stream,
+                       reinterpret_cast<double2 *>(self->d), reinterpret_cast<const double2 *>(vec->d), alpha, beta, n2,
+                       self->nrst, n2, g_axpby_consistent);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int nlg_vec_dot(const nlg_vec *self, const nlg_vec *vec, double *out) {
+    NLG_TRY(check_same(self, vec, "nlg_vec_dot"));
+    NLG_CHECK(out, "nlg_vec_dot: out is NULL");
+    NLG_TRY(dev_dot(self, vec, 0));
+    return scalars_to_host(self->mesh->ctx, 0, 1, out);
+}
+
+int nlg_vec_norm(const nlg_vec *self, double *out) {
+    double d = 0.0;
+    NLG_TRY(nlg_vec_dot(self, self, &d));
+    *out = sqrt(d);
+    return 0;
+}
+
+int nlg_vec_size(const nlg_vec *self, int64_t *out) {
+    NLG_CHECK(self && out, "nlg_vec_size: NULL argument");
+    *out = (int64_t)self->ncomp * self->mesh->lvn + self->mesh->lpn;
+    return 0;
+}
+
+int nlg_vec_save_rst(nlg_vec *self, const nlg_vec *vec_rst, int irst) {
+    NLG_TRY(check_same(self, vec_rst, "nlg_vec_save_rst"));
+    // reference: "Cannot save rst fields <torder> for a simulation of temporal order <torder>"
+    NLG_CHECK(irst >= 1 && irst < self->lorder, "nlg_vec_save_rst: cannot save rst fields %d for temporal order %d", irst,
+              self->lorder);
+    NLG_HIP(hipMemcpyAsync(self->d + (int64_t)irst * self->main_len, vec_rst->d, sizeof(double) * (size_t)self->main_len,
+                           hipMemcpyDeviceToDevice, self->mesh->ctx->stream));
+    if (irst > self->nrst) self->nrst = irst;
+    return 0;
+}
+
+int nlg_vec_get_rst(const nlg_vec *self, nlg_vec *vec_rst, int irst) {
+    NLG_TRY(check_same(self, vec_rst, "nlg_vec_get_rst"));
+    NLG_CHECK(irst >= 1 && irst < self->lorder, "nlg_vec_get_rst: invalid input for irst: %d", irst);
+    NLG_HIP(hipMemcpyAsync(vec_rst->d, self->d + (int64_t)irst * self->main_len, sizeof(double) * (size_t)self->main_len,
+                           hipMemcpyDeviceToDevice, self->mesh->ctx->stream));
+    return 0;
+}
+
+int nlg_vec_has_rst_fields(const nlg_vec *self, int *out) {
+    NLG_CHECK(self && out, "nlg_vec_has_rst_fields: NULL argument");
+    *out = self->nrst > 0;
+    return 0;
+}
+
+int nlg_vec_clear_rst_fields(nlg_vec *self) {
+    NLG_CHECK(self, "nlg_vec_clear_rst_fields: NULL vector");
+    self->nrst = 0;
+    return 0;
+}
+
+int nlg_vec_nrst(const nlg_vec *self, int *out) {
+    NLG_CHECK(self && out, "nlg_vec_nrst: NULL argument");
+    *out = self->nrst;
+    return 0;
+}
+
+static int field_ptr(const nlg_vec *v, int field, int irst, double **p, int64_t *len) {
+    NLG_CHECK(v, "field access: NULL vector");
+    NLG_CHECK(irst >= 0 && irst < v->lorder, "field access: irst %d out of range", irst);
+    const nlg_mesh *m = v->mesh;
+    if (field >= NLG_VX && field <= NLG_VZ) {
+        NLG_CHECK(field < m->dim, "field access: component %d on a %d-D mesh", field, m->dim);
+        *p = v->vel(field, irst);
+        *len = m->lvn;
+    } else if (field == NLG_PR) {
+        *p = v->pr(irst);
+        *len = m->lpn;
+    } else {
+        const int s = field - NLG_THETA;
+        NLG_CHECK(s >= 0 && s < v->nscal, "field access: scalar %d not active (nscal=%d)", s, v->nscal);
+        *p = v->theta(s, irst);
+        *len = m->lvn;
+    }
+    return 0;
+}
+
+int nlg_vec_set_field(nlg_vec *self, int field, int irst, const double *host, int64_t count) {
+    double *p;
+    int64_t len;
+    NLG_TRY(field_ptr(self, field, irst, &p, &len));
+    NLG_CHECK(host && count == len, "nlg_vec_set_field: count %lld != field length %lld", (long long)count, (long long)len);
+    NLG_HIP(hipMemcpyAsync(p, host, sizeof(double) * (size_t)len, hipMemcpyHostToDevice, self->mesh->ctx->stream));
+    NLG_HIP(hipStreamSynchronize(self->mesh->ctx->stream));
+    return 0;
+}
+
+int nlg_vec_get_field(const nlg_vec *self, int field, int irst, double *host, int64_t count) {
+    double *p;
+    int64_t len;
+    NLG_TRY(field_ptr(self, field, irst, &p, &len));
+    NLG_CHECK(host && count == len, "nlg_vec_get_field: count %lld != field length %lld", (long long)count, (long long)len);
+    NLG_HIP(hipMemcpyAsync(host, p, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, self->mesh->ctx->stream));
+    NLG_HIP(hipStreamSynchronize(self->mesh->ctx->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Krylov basis
+// ------------------------------------------------------------------------------------------------
+int nlg_basis_create(nlg_mesh *mesh, int nscal, int lorder, int nvec, nlg_basis **out) {
+    NLG_CHECK(mesh && out, "nlg_basis_create: NULL argument");
+    NLG_CHECK(nvec >= 1 && nvec <= 4096, "nlg_basis_create: nvec %d out of range", nvec);
+    nlg_basis *b = new nlg_basis();
+    b->mesh = mesh;
+    b->nvec = nvec;
+    b->nscal = nscal;
+    b->lorder = lorder;
+    const int ncomp = mesh->dim + nscal;
+    const int64_t main_len = (int64_t)ncomp * mesh->lvs + mesh->lps;
+    b->stride = main_len * lorder;
+    NLG_HIP(hipSetDevice(mesh->ctx->device));
+    const size_t bytes = sizeof(double) * (size_t)b->stride * nvec;
+    hipError_t e = hipMalloc(&b->d, bytes);
+    if (e != hipSuccess) {
+        delete b;
+        set_error("nlg_basis_create: hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return 1;
+    }
+    NLG_HIP(hipMemsetAsync(b->d, 0, bytes, mesh->ctx->stream));
+    NLG_HIP(hipMalloc(&b->d_h, sizeof(double) * (size_t)(3 * nvec + 16)));
+    NLG_HIP(hipMemsetAsync(b->d_h, 0, sizeof(double) * (size_t)(3 * nvec + 16), mesh->ctx->stream));
+    NLG_TRY(reduce_ws_reserve(mesh->ctx, nvec + 8));
+    b->views.resize(nvec);
+    for (int i = 0; i < nvec; ++i) {
+        nlg_vec *v = new nlg_vec();
+        v->mesh = mesh;
+        v->nscal = nscal;
+        v->lorder = lorder;
+        v->ncomp = ncomp;
+        v->main_len = main_len;
+        v->total_len = b->stride;
+        v->d = b->d + (int64_t)i * b->stride;
+        v->owns = false;
+        b->views[i] = v;
+    }
+    *out = b;
+    return 0;
+}
+
+int nlg_basis_destroy(nlg_basis *b) {
+    if (!b) return 0;
+    for (auto *v : b->views) delete v;
+    if (b->d) hipFree(b->d);
+    if (b->d_h) hipFree(b->d_h);
+    delete b;
+    return 0;
+}
+
+int nlg_basis_vec(nlg_basis *b, int i, nlg_vec **out) {
+    NLG_CHECK(b && out, "nlg_basis_vec: NULL argument");
+    NLG_CHECK(i >= 0 && i < b->nvec, "nlg_basis_vec: index %d out of range [0,%d)", i, b->nvec);
+    *out = b->views[i];
+    return 0;
+}
+
+}  // extern "C"
+
+namespace nlg {
+
+// device-resident block projection: d_out[0:k] = V^T B w (allreduced); optionally d_acc += d_out
+int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc) {
+    nlg_ctx *ctx = b->mesh->ctx;
+    const nlg_vec *v0 = b->views[0];
+    constexpr int KB = 8;
+    const int nblk = dot_nblk(v0);
+    const int nper = nblk * v0->ncomp;
+    NLG_TRY(reduce_ws_reserve(ctx, k));
+    hipLaunchKernelGGL(k_block_dot<KB>, dim3(nblk, v0->ncomp, (k + KB - 1) / KB), dim3(NT), 0, ctx->stream, b->d,
+                       b->stride, k, w->d, b->mesh->d_bm1, b->mesh->lvs, nblk, nper, ctx->d_partial);
+    if (ctx->nranks > 1) {
+        hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out, 0,
+                           (double *)nullptr);
+        NLG_TRY(allreduce_sum(ctx, d_out, k));
+        if (d_acc) hipLaunchKernelGGL(k_vadd, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, d_acc, d_out, k);
+    } else {
+        hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out,
+                           d_acc ? 1 : 0, d_acc);
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign) {
+    nlg_ctx *ctx = b->mesh->ctx;
+    const int64_t n2 = w->main_len / 2;
+    hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride, k,
+                       d_h, w->d, n2, w->nrst, n2, g_axpby_consistent, sign);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+// CGS2 + norm + scale, everything stream-ordered on device. Results: d_h[0:k] coefficients,
+// d_h[k] = ||w||^2 before normalisation.
+int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
+    nlg_ctx *ctx = b->mesh->ctx;
+    double *h = b->d_h, *h2 = b->d_h + b->nvec + 8;
+    if (k > 0) {
+        NLG_TRY(basis_block_dot_dev(b, k, w, h, nullptr));
+        NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0));
+        NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));
+        NLG_TRY(basis_block_axpy_dev(b, k, h2, w, -1.0));
+    }
+    // norm
+    const int nblk = dot_nblk(w);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nblk, w->ncomp), dim3(NT), 0, ctx->stream, w->d, w->d, b->mesh->d_bm1,
+                       b->mesh->lvs, nblk, ctx->d_partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(NT), 0, ctx->stream, ctx->d_partial, nblk * w->ncomp, h + k, 0,
+                       (double *)nullptr);
+    NLG_TRY(allreduce_sum(ctx, h + k, 1));
+    const int64_t n2 = w->main_len * (1 + w->nrst) / 2;
+    hipLaunchKernelGGL(k_scal_dev, dim3(grid_for(n2)), dim3(NT), 0, ctx->stream, reinterpret_cast<double2 *>(w->d),
+                       h + k, 0, n2);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace nlg
+
+extern "C" {
+
+int nlg_basis_block_dot(const nlg_basis *b, int k, const nlg_vec *w, double *h) {
+    NLG_CHECK(b && w && h, "nlg_basis_block_dot: NULL argument");
+    NLG_CHECK(k >= 1 && k <= b->nvec, "nlg_basis_block_dot: k=%d out of range [1,%d]", k, b->nvec);
+    NLG_TRY(check_same(b->views[0], w, "nlg_basis_block_dot"));
+    NLG_TRY(nlg::basis_block_dot_dev(b, k, w, b->d_h, nullptr));
+    NLG_HIP(hipMemcpyAsync(h, b->d_h, sizeof(double) * k, hipMemcpyDeviceToHost, b->mesh->ctx->stream));
+    NLG_HIP(hipStreamSynchronize(b->mesh->ctx->stream));
+    return 0;
+}
+
+int nlg_basis_block_axpy(const nlg_basis *b, int k, const double *h, nlg_vec *w) {
+    NLG_CHECK(b && w && h, "nlg_basis_block_axpy: NULL argument");
+    NLG_CHECK(k >= 1 && k <= b->nvec, "nlg_basis_block_axpy: k=%d out of range [1,%d]", k, b->nvec);
+    NLG_TRY(check_same(b->views[0], w, "nlg_basis_block_axpy"));
+    NLG_HIP(hipMemcpyAsync(b->d_h, h, sizeof(double) * k, hipMemcpyHostToDevice, b->mesh->ctx->stream));
+    NLG_TRY(nlg::basis_block_axpy_dev(b, k, b->d_h, w, -1.0));
+    NLG_HIP(hipStreamSynchronize(b->mesh->ctx->stream));
+    return 0;
+}
+
+int nlg_basis_cgs2(const nlg_basis *bc, int k, nlg_vec *w, double *h, double *beta) {
+    nlg_basis *b = const_cast<nlg_basis *>(bc);
+    NLG_CHECK(b && w && h && beta, "nlg_basis_cgs2: NULL argument");
+    NLG_CHECK(k >= 0 && k <= b->nvec, "nlg_basis_cgs2: k=%d out of range [0,%d]", k, b->nvec);
+    NLG_TRY(check_same(b->views[0], w, "nlg_basis_cgs2"));
+    NLG_TRY(nlg::basis_cgs2_dev(b, k, w));
+    std::vector<double> tmp(k + 1);
+    NLG_HIP(hipMemcpyAsync(tmp.data(), b->d_h, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, b->mesh->ctx->stream));
+    NLG_HIP(hipStreamSynchronize(b->mesh->ctx->stream));
+    for (int j = 0; j < k; ++j) h[j] = tmp[j];
+    *beta = sqrt(tmp[k]);
+    return 0;
+}
+
+int nlg_basis_combine(const nlg_basis *b, int k, const double *c, nlg_vec *out) {
+    NLG_CHECK(b && c && out, "nlg_basis_combine: NULL argument");
+    NLG_CHECK(k >= 1 && k <= b->nvec, "nlg_basis_combine: k=%d out of range [1,%d]", k, b->nvec);
+    NLG_TRY(check_same(b->views[0], out, "nlg_basis_combine"));
+    NLG_TRY(nlg_vec_zero(out));
+    NLG_HIP(hipMemcpyAsync(b->d_h, c, sizeof(double) * k, hipMemcpyHostToDevice, b->mesh->ctx->stream));
+    NLG_TRY(nlg::basis_block_axpy_dev(b, k, b->d_h, out, +1.0));
+    NLG_HIP(hipStreamSynchronize(b->mesh->ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,382 @@
+"""Host-side mirror of the reference's operator / plugin interface for the hot path, on top of the
+C ABI (include/neklab_gpu.h).  Names, argument meaning and error behaviour follow the reference:
+
+* `nek_dvector`   <- type nek_dvector           /root/reference/src/vectors/neklab_vectors.f90:26-50
+* `exptA_linop`   <- type exptA_linop           /root/reference/src/linops/neklab_linops.f90:35-44
+* `linear_stability_analysis_fixed_point` <-    /root/reference/src/neklab_analysis.f90:38-105
+* `nek2vec` / `vec2nek` field movers       <-    /root/reference/src/neklab_utils.f90:84-134
+
+In the reference these are Fortran 2008 types driven by LightKrylov; the Fortran shim with the same
+bindings is neklab_amd/fortran/neklab_gpu.f90.  This Python mirror exists so that parity tests can be
+written the way the reference's own driver reads.  All arithmetic happens in HIP kernels; nothing here
+computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import NlgError, check, dptr, vp
+
+VX, VY, VZ, PR, THETA = 0, 1, 2, 3, 4
+
+
+class Context:
+    """Device + stream (+ RCCL communicator).  One per process / GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = vp()
+        check(self.lib.nlg_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.rank, self.nranks = 0, 1
+
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        check(self.lib.nlg_ctx_comm_init(self.h, rank, nranks, C.cast(buf, vp)))
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        check(lib.nlg_comm_unique_id(C.cast(buf, vp)))
+        return buf.raw
+
+    def sync(self):
+        check(self.lib.nlg_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.nlg_ctx_destroy(self.h)
+            self.h = None
+
+
+class Mesh:
+    """The Nek5000 state the reference reads from SIZE/TOTAL commons, uploaded once."""
+
+    def __init__(self, ctx: Context, mesh, lxd: int = 0):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.host = mesh
+        d = _lib.MeshDesc()
+        d.dim, d.n, d.lxd, d.nelv = mesh.dim, mesh.n, int(lxd), mesh.E
+        keep = []
+
+        def f64(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return dptr(a)
+
+        d.xm1, d.ym1 = f64(mesh.x), f64(mesh.y)
+        d.zm1 = f64(mesh.z) if mesh.dim == 3 else None
+        g = np.ascontiguousarray(mesh.glo_num, dtype=np.int64)
+        keep.append(g)
+        d.glo_num = g.ctypes.data_as(_lib.c_int64_p)
+        if mesh.elem_gid is not None:
+            eg = np.ascontiguousarray(mesh.elem_gid, dtype=np.int64)
+            keep.append(eg)
+            d.lglel = eg.ctypes.data_as(_lib.c_int64_p)
+        d.v1mask, d.v2mask = f64(mesh.mask[0]), f64(mesh.mask[1])
+        d.v3mask = f64(mesh.mask[2]) if mesh.dim == 3 else None
+        d.tmask = f64(mesh.tmask)
+        d.has_outflow = int(mesh.has_outflow)
+        h = vp()
+        check(self.lib.nlg_mesh_create(ctx.h, C.byref(d), C.byref(h)))
+        self.h = h
+        lvn, lpn = C.c_int64(), C.c_int64()
+        check(self.lib.nlg_mesh_sizes(h, C.byref(lvn), C.byref(lpn), None, None))
+        self.lvn, self.lpn = lvn.value, lpn.value
+        self.dim, self.n = mesh.dim, mesh.n
+        self.E = mesh.E
+
+    def get(self, name: str, on_mesh: int = 1) -> np.ndarray:
+        npts = {1: self.lvn, 2: self.lpn}.get(on_mesh, on_mesh)
+        out = np.empty(npts)
+        check(self.lib.nlg_mesh_get(self.h, name.encode(), dptr(out), npts))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.nlg_mesh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class nek_dvector:
+    """reference: type nek_dvector (neklab_vectors.f90:26-50).  Fields live in HBM."""
+
+    def __init__(self, mesh: Mesh, nscal: int = 0, lorder: int = 3, _handle=None, _owns=True):
+        self.mesh, self.lib = mesh, mesh.lib
+        self.nscal, self.lorder = nscal, lorder
+        self._owns = _owns
+        if _handle is None:
+            h = vp()
+            check(self.lib.nlg_vec_create(mesh.h, nscal, lorder, C.byref(h)))
+            self.h = h
+        else:
+            self.h = _handle
+
+    # ---- the six deferred procedures of abstract_vector_rdp (neklab_vectors.f90:39-44)
+    def zero(self):
+        check(self.lib.nlg_vec_zero(self.h))
+
+    def rand(self, ifnorm: bool = False, seed: int = 0):
+        check(self.lib.nlg_vec_rand(self.h, int(bool(ifnorm)), int(seed)))
+
+    def scal(self, alpha: float):
+        check(self.lib.nlg_vec_scal(self.h, float(alpha)))
+
+    def axpby(self, alpha: float, vec: "nek_dvector", beta: float):
+        """self = alpha*vec + beta*self  (argument order of nek_daxpby with pass(self))."""
+        if not isinstance(vec, nek_dvector):
+            raise TypeError("type_error: vec must be nek_dvector (reference: real_vectors.f90:202-204)")
+        check(self.lib.nlg_vec_axpby(float(alpha), vec.h, float(beta), self.h))
+
+    def dot(self, vec: "nek_dvector") -> float:
+        if not isinstance(vec, nek_dvector):
+            raise TypeError("type_error: vec must be nek_dvector (reference: real_vectors.f90:229-231)")
+        out = C.c_double()
+        check(self.lib.nlg_vec_dot(self.h, vec.h, C.byref(out)))
+        return out.value
+
+    def get_size(self) -> int:
+        out = C.c_int64()
+        check(self.lib.nlg_vec_size(self.h, C.byref(out)))
+        return out.value
+
+    # ---- inherited helpers LightKrylov provides on top of the deferred set
+    def norm(self) -> float:
+        out = C.c_double()
+        check(self.lib.nlg_vec_norm(self.h, C.byref(out)))
+        return out.value
+
+    def sub(self, vec):
+        self.axpby(-1.0, vec, 1.0)
+
+    def add(self, vec):
+        self.axpby(1.0, vec, 1.0)
+
+    # ---- neklab-specific restart history (neklab_vectors.f90:46-49)
+    def save_rst(self, vec_rst: "nek_dvector", irst: int):
+        check(self.lib.nlg_vec_save_rst(self.h, vec_rst.h, int(irst)))
+
+    def get_rst(self, vec_rst: "nek_dvector", irst: int):
+        check(self.lib.nlg_vec_get_rst(self.h, vec_rst.h, int(irst)))
+
+    def has_rst_fields(self) -> bool:
+        out = C.c_int()
+        check(self.lib.nlg_vec_has_rst_fields(self.h, C.byref(out)))
+        return bool(out.value)
+
+    def clear_rst_fields(self):
+        check(self.lib.nlg_vec_clear_rst_fields(self.h))
+
+    @property
+    def nrst(self) -> int:
+        out = C.c_int()
+        check(self.lib.nlg_vec_nrst(self.h, C.byref(out)))
+        return out.value
+
+    # ---- Fortran assignment semantics / host transfer
+    def copy(self) -> "nek_dvector":
+        h = vp()
+        check(self.lib.nlg_vec_clone(self.h, C.byref(h)))
+        return nek_dvector(self.mesh, self.nscal, self.lorder, _handle=h)
+
+    def assign(self, other: "nek_dvector"):
+        check(self.lib.nlg_vec_copy(self.h, other.h))
+
+    def set_field(self, field: int, data, irst: int = 0):
+        a = np.ascontiguousarray(data, dtype=np.float64).reshape(-1)
+        check(self.lib.nlg_vec_set_field(self.h, int(field), int(irst), dptr(a), a.size))
+
+    def get_field(self, field: int, irst: int = 0) -> np.ndarray:
+        n = self.mesh.lpn if field == PR else self.mesh.lvn
+        out = np.empty(n)
+        check(self.lib.nlg_vec_get_field(self.h, int(field), int(irst), dptr(out), n))
+        return out
+
+    def close(self):
+        if self.h and self._owns:
+            self.lib.nlg_vec_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nek2vec(vec: nek_dvector, vx, vy, vz=None, pr=None, t=None):
+    """reference: neklab_utils.f90:84-108 (nopcopy :279-301): host fields -> vector."""
+    vec.set_field(VX, vx)
+    vec.set_field(VY, vy)
+    if vec.mesh.dim == 3 and vz is not None:
+        vec.set_field(VZ, vz)
+    if pr is not None:
+        vec.set_field(PR, pr)
+    if t is not None:
+        for m, tm in enumerate(t[: vec.nscal]):
+            vec.set_field(THETA + m, tm)
+
+
+def vec2nek(vec: nek_dvector):
+    """reference: neklab_utils.f90:110-134: vector -> host fields (vx, vy, vz|None, pr, [theta])."""
+    vz = vec.get_field(VZ) if vec.mesh.dim == 3 else None
+    return (vec.get_field(VX), vec.get_field(VY), vz, vec.get_field(PR),
+            [vec.get_field(THETA + m) for m in range(vec.nscal)])
+
+
+class KrylovBasis:
+    """Contiguous array of nek_dvector (what LightKrylov allocates as X(kdim+1)) with block kernels."""
+
+    def __init__(self, mesh: Mesh, nvec: int, nscal: int = 0, lorder: int = 3):
+        self.mesh, self.lib, self.nvec = mesh, mesh.lib, nvec
+        h = vp()
+        check(self.lib.nlg_basis_create(mesh.h, nscal, lorder, nvec, C.byref(h)))
+        self.h = h
+        self.nscal, self.lorder = nscal, lorder
+
+    def __getitem__(self, i: int) -> nek_dvector:
+        h = vp()
+        check(self.lib.nlg_basis_vec(self.h, int(i), C.byref(h)))
+        return nek_dvector(self.mesh, self.nscal, self.lorder, _handle=h, _owns=False)
+
+    def block_dot(self, k: int, w: nek_dvector) -> np.ndarray:
+        out = np.empty(k)
+        check(self.lib.nlg_basis_block_dot(self.h, k, w.h, dptr(out)))
+        return out
+
+    def block_axpy(self, k: int, h, w: nek_dvector):
+        a = np.ascontiguousarray(h, dtype=np.float64)
+        check(self.lib.nlg_basis_block_axpy(self.h, k, dptr(a), w.h))
+
+    def cgs2(self, k: int, w: nek_dvector):
+        h = np.empty(max(k, 1))
+        beta = C.c_double()
+        check(self.lib.nlg_basis_cgs2(self.h, k, w.h, dptr(h), C.byref(beta)))
+        return h[:k], beta.value
+
+    def combine(self, k: int, c, out: nek_dvector):
+        a = np.ascontiguousarray(c, dtype=np.float64)
+        check(self.lib.nlg_basis_combine(self.h, k, dptr(a), out.h))
+
+    def close(self):
+        if self.h:
+            self.lib.nlg_basis_destroy(self.h)
+            self.h = None
+
+
+class exptA_linop:
+    """reference: type exptA_linop (neklab_linops.f90:35-44); constructor idiom `exptA_linop(tau, bf)`
+    (examples/cylinder/stability/direct/1cyl.usr:20)."""
+
+    def __init__(self, tau: float, baseflow: nek_dvector, **cfg):
+        self.mesh, self.lib = baseflow.mesh, baseflow.lib
+        c = _lib.ExptAConfig()
+        check(self.lib.nlg_exptA_config_default(C.byref(c)))
+        c.tau = float(tau)
+        for k, v in cfg.items():
+            if not hasattr(c, k):
+                raise TypeError("unknown exptA option %r" % k)
+            setattr(c, k, v)
+        self.cfg = c
+        self.baseflow = baseflow
+        h = vp()
+        check(self.lib.nlg_linop_create(self.mesh.h, C.byref(c), baseflow.h, C.byref(h)))
+        self.h = h
+
+    @property
+    def tau(self) -> float:
+        return self.info()["tau"]
+
+    @tau.setter
+    def tau(self, v: float):
+        check(self.lib.nlg_linop_set_tau(self.h, float(v)))
+
+    def init(self):
+        check(self.lib.nlg_linop_init(self.h))
+
+    def matvec(self, vec_in: nek_dvector, vec_out: nek_dvector):
+        if not isinstance(vec_in, nek_dvector) or not isinstance(vec_out, nek_dvector):
+            raise TypeError("type_error: nek_dvector expected (reference: exponential_propagator.f90:53-58)")
+        check(self.lib.nlg_linop_matvec(self.h, vec_in.h, vec_out.h))
+
+    def rmatvec(self, vec_in: nek_dvector, vec_out: nek_dvector):
+        if not isinstance(vec_in, nek_dvector) or not isinstance(vec_out, nek_dvector):
+            raise TypeError("type_error: nek_dvector expected (reference: exponential_propagator.f90:100-105)")
+        check(self.lib.nlg_linop_rmatvec(self.h, vec_in.h, vec_out.h))
+
+    def info(self) -> dict:
+        tau, dt, cfl, ns = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        check(self.lib.nlg_linop_get_info(self.h, C.byref(tau), C.byref(dt), C.byref(ns), C.byref(cfl)))
+        return {"tau": tau.value, "dt": dt.value, "nsteps": ns.value, "cfl": cfl.value}
+
+    def stats(self) -> dict:
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.nlg_linop_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"steps": a.value, "v_iters": b.value, "p_iters": c.value, "matvecs": d.value}
+
+    def close(self):
+        if self.h:
+            self.lib.nlg_linop_destroy(self.h)
+            self.h = None
+
+
+def arnoldi_step(exptA: exptA_linop, basis: KrylovBasis, k: int, H: np.ndarray, transpose: bool = False):
+    """H is Fortran-ordered (kdim+1, kdim)."""
+    assert H.flags.f_contiguous
+    check(exptA.lib.nlg_arnoldi_step(exptA.h, basis.h, int(k), dptr(H), H.shape[0], int(bool(transpose))))
+
+
+def eigs(exptA: exptA_linop, X: list, kdim: int = 0, tol: float = 0.0, x0: nek_dvector | None = None,
+         transpose: bool = False, write_intermediate: bool = True, logfile: str | None = None, seed: int = 0,
+         max_restarts: int = 50):
+    """reference call: eigs(exptA, eigvecs, eigvals, residuals, info, x0=, kdim=, transpose=,
+    write_intermediate=) at neklab_analysis.f90:80-81.  Returns (eigvals complex[nev], residuals, info)."""
+    lib = exptA.lib
+    nev = len(X)
+    o = _lib.EigsOpts()
+    check(lib.nlg_eigs_opts_default(C.byref(o)))
+    o.kdim, o.transpose, o.write_intermediate, o.tol, o.seed = int(kdim), int(bool(transpose)), int(bool(write_intermediate)), float(tol), int(seed)
+    o.max_restarts = int(max_restarts)
+    if logfile is not None:
+        o.logfile = logfile.encode()
+    re, im, res = np.zeros(nev), np.zeros(nev), np.zeros(nev)
+    info = C.c_int()
+    arr = (vp * nev)(*[x.h for x in X])
+    check(lib.nlg_eigs(exptA.h, arr, nev, dptr(re), dptr(im), dptr(res), C.byref(info), x0.h if x0 is not None else None,
+                       C.byref(o)))
+    return re + 1j * im, res, info.value
+
+
+def save_eigenspectrum(eigvals, residuals, filename: str):
+    """reference call site: neklab_analysis.f90:90 (LightKrylov save_eigenspectrum): (n,3) array
+    [Re, Im, residual] in .npy format, the layout examples/*/plot_eigenvalues.py reads."""
+    data = np.column_stack([np.real(eigvals), np.imag(eigvals), residuals])
+    np.save(filename, data)
+
+
+def linear_stability_analysis_fixed_point(exptA: exptA_linop, kdim: int, nev: int, adjoint: bool = False,
+                                          X0: nek_dvector | None = None, tol: float = 0.0, outdir: str = ".",
+                                          seed: int = 0):
+    """reference: neklab_analysis.f90:38-105.  Returns (eigvals continuous-time, residuals, eigvecs)."""
+    mesh = exptA.mesh
+    eigvecs = [nek_dvector(mesh, 0, 3) for _ in range(nev)]   # lorder = 3 as in every reference SIZE file
+    for v in eigvecs:
+        v.zero()                                                     # zero_basis, :77
+    prefix = "adj" if adjoint else "dir"
+    mu, residuals, info = eigs(exptA, eigvecs, kdim=kdim, x0=X0, transpose=adjoint, write_intermediate=True,
+                               logfile=os.path.join(outdir, "eigs_output.txt"), tol=tol, seed=seed)
+    eigvals = np.log(mu.astype(complex)) / exptA.info()["tau"]       # :84
+    save_eigenspectrum(eigvals, residuals, os.path.join(outdir, prefix + "_eigenspectrum.npy"))   # :90
+    return eigvals, residuals, eigvecs, mu, info

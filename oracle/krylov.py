@@ -1,0 +1,161 @@
+"""ORACLE (test infrastructure only) -- Arnoldi / Krylov-Schur eigensolver over the abstract
+vector API, restated in numpy.  Never imported by the product.
+
+PARITY UNPINNED: the algorithm is LightKrylov's `eigs` (nekStab/LightKrylov @ main, un-pinned,
+/root/reference/LightKrylov_setup.sh:55-57), absent from `/root/reference`.  Its call site and the
+post-processing ARE in the tree and are followed here:
+/root/reference/src/neklab_analysis.f90:77-93 (`zero_basis`, `eigs(exptA, eigvecs, eigvals, residuals,
+info, x0=, kdim=, transpose=, write_intermediate=)`, `eigvals = log(eigvals)/tau`).
+The algorithm is restated from the published methods: Arnoldi with classical Gram-Schmidt plus one
+re-orthogonalisation pass (CGS2, Giraud et al. 2005), Ritz residual estimate
+`|h_{k+1,k}| |e_k^T y|` (Saad 2011), thick restart on the wanted Ritz subspace (Krylov-Schur,
+Stewart 2001, in its orthonormal-basis-of-the-invariant-subspace form).
+
+The structure deliberately mirrors how neklab + LightKrylov drive the vectors: one `dot` per basis
+vector, one `axpby` per basis vector.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def innerprod(X, w):
+    return np.array([x.dot(w) for x in X])
+
+
+def cgs2_step(X, w):
+    """w <- (I - X X^T B)^2 w ; returns accumulated coefficients."""
+    h = innerprod(X, w)
+    for hj, x in zip(h, X):
+        w.axpby(-hj, x, 1.0)
+    h2 = innerprod(X, w)
+    for hj, x in zip(h2, X):
+        w.axpby(-hj, x, 1.0)
+    return h + h2
+
+
+def arnoldi_step(matvec, V, H, k):
+    """Extend A V_k = V_{k+1} H by one column (k is 0-based: uses V[k], creates V[k+1])."""
+    w = matvec(V[k])
+    h = cgs2_step(V[: k + 1], w)
+    beta = w.norm()
+    H[: k + 1, k] = h
+    H[k + 1, k] = beta
+    if beta > 0:
+        w.scal(1.0 / beta)
+    V[k + 1] = w
+    return beta
+
+
+def ritz(H, k):
+    """Eigen-decomposition of the leading k x k block; residuals from row k (0-based)."""
+    lam, Y = np.linalg.eig(H[:k, :k])
+    res = np.abs(H[k, :k] @ Y)
+    order = np.argsort(-np.abs(lam), kind="stable")
+    return lam[order], Y[:, order], res[order]
+
+
+def select_wanted(lam, nkeep_min):
+    """Keep Ritz values with modulus above the median, at least nkeep_min, conjugate pairs together.
+    `lam` sorted by decreasing modulus."""
+    k = len(lam)
+    med = np.median(np.abs(lam))
+    p = max(int(np.sum(np.abs(lam) > med)), nkeep_min)
+    p = min(p, k - 1)
+    # do not split a conjugate pair
+    if p < k and abs(lam[p - 1].imag) > 0 and p >= 1:
+        if np.isclose(lam[p - 1], np.conj(lam[p]), rtol=1e-10, atol=1e-14):
+            p += 1
+    return min(p, k - 1)
+
+
+def real_basis(Y, lam, p):
+    """Real orthonormal basis Q (k x p) of span of the first p Ritz vectors."""
+    cols = []
+    j = 0
+    while j < p:
+        if abs(lam[j].imag) > 0 and j + 1 < p:
+            cols.append(Y[:, j].real)
+            cols.append(Y[:, j].imag)
+            j += 2
+        else:
+            cols.append(Y[:, j].real)
+            j += 1
+    M = np.stack(cols, axis=1)
+    Q, _ = np.linalg.qr(M)
+    return Q
+
+
+def eigs(matvec, x0, nev, kdim, tol=None, max_restarts=50, new_vector=None, log=None):
+    """Leading-modulus eigenpairs of the operator behind `matvec`.
+
+    Returns (eigvals[nev], eigvecs list (LAPACK real convention: a conjugate pair occupies two
+    consecutive vectors Re, Im), residuals[nev], info) with info = number of matvecs.
+    """
+    if tol is None:
+        tol = np.sqrt(10.0 ** -15)
+    V = [None] * (kdim + 1)
+    H = np.zeros((kdim + 1, kdim))
+    v0 = x0.copy()
+    v0.scal(1.0 / v0.norm())
+    V[0] = v0
+    kstart, nmv = 0, 0
+    lam = Y = res = None
+    for _ in range(max_restarts + 1):
+        k = kstart
+        done = False
+        while k < kdim:
+            arnoldi_step(matvec, V, H, k)
+            nmv += 1
+            k += 1
+            lam, Y, res = ritz(H, k)
+            conv = int(np.sum(res < tol))
+            if log is not None:
+                log(nmv, lam, res, tol)
+            if conv >= nev:
+                done = True
+                break
+        if done or k < kdim:
+            break
+        # thick restart (Krylov-Schur): compress onto the wanted Ritz subspace
+        p = select_wanted(lam, nev)
+        Q = real_basis(Y, lam, p)
+        p = Q.shape[1]
+        Vnew = []
+        for j in range(p):
+            w = V[0].copy()
+            w.zero()
+            for i in range(k):
+                w.axpby(Q[i, j], V[i], 1.0)
+            Vnew.append(w)
+        S = Q.T @ H[:k, :k] @ Q
+        b = H[k, :k] @ Q
+        vk = V[k]
+        H[:, :] = 0.0
+        H[:p, :p] = S
+        H[p, :p] = b
+        for j in range(p):
+            V[j] = Vnew[j]
+        V[p] = vk
+        kstart = p
+    kf = k
+    nev_out = min(nev, kf)
+    vecs = []
+    j = 0
+    while j < nev_out:
+        def comb(c):
+            w = V[0].copy()
+            w.zero()
+            for i in range(kf):
+                w.axpby(c[i], V[i], 1.0)
+            return w
+        if abs(lam[j].imag) > 0:
+            y = Y[:, j] if lam[j].imag > 0 else np.conj(Y[:, j])
+            vecs.append(comb(y.real))
+            if j + 1 < nev_out:
+                vecs.append(comb(y.imag))
+            j += 2
+        else:
+            vecs.append(comb(Y[:, j].real))
+            j += 1
+    return lam[:nev_out], vecs[:nev_out], res[:nev_out], nmv

@@ -1,0 +1,219 @@
+"""ORACLE (test infrastructure only) -- exponential propagator exp(tau L) of the linearised
+Navier-Stokes operator, restated in numpy.  Never imported by the product.
+
+In-tree protocol followed (what the reference DOES pin):
+* matvec protocol: base flow in, solver set-up, IC in, `nsteps` x advance with restart-history replay
+  for `istep <= nrst`, result out, `nrst` extra steps to refill the history
+  (/root/reference/src/linops/exponential_propagator.f90:15-60, :109-142),
+* `dt`/`nsteps` rule from tau and CFL (/root/reference/src/neklab_nek_setup.f90:195-200, cfl_limit 0.5
+  at exponential_propagator.f90:9-12),
+* operator terms of L (/root/reference/src/linops/neklab_linops.f90:268-426).
+
+PARITY UNPINNED for the time integrator itself: `nek_advance` is Nek5000 code (absent, un-pinned).  It
+is restated from the published Pn-Pn-2 BDFk/EXTk splitting (Fischer 1997; Deville-Fischer-Mund ch. 6):
+tentative Helmholtz solve in residual form with the lagged pressure, consistent-Poisson pressure
+correction, velocity update.  Solver details that Nek5000 hides (one joint Jacobi-PCG over the
+velocity components, Jacobi-PCG on E) are this project's own and are documented in DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from .vectors import NekDVector
+
+BDF = {1: (1.0, (1.0,)), 2: (1.5, (2.0, -0.5)), 3: (11.0 / 6.0, (3.0, -1.5, 1.0 / 3.0))}
+EXT = {1: (1.0,), 2: (2.0, -1.0), 3: (3.0, -3.0, 1.0)}
+
+
+@dataclass
+class LNSConfig:
+    re: float = 100.0           # viscosity = 1/re  (1cyl.par: viscosity = -50 => Re = 50)
+    torder: int = 3             # |param(27)|, 1cyl.par: timeStepper = bdf3
+    tau: float = 1.0
+    cfl_limit: float = 0.5      # exponential_propagator.f90:12
+    vtol: float = 1e-9          # 1cyl.par [VELOCITY] residualTol
+    ptol: float = 1e-7          # 1cyl.par [PRESSURE] residualTol
+    maxit_v: int = 200
+    maxit_p: int = 2000
+    fixed_iters_v: int = 0      # >0: run exactly this many PCG iterations (parity mode)
+    fixed_iters_p: int = 0
+    dt: float = 0.0             # >0: skip the CFL rule and use nsteps = ceil(tau/dt)
+
+
+def dt_rule(tau, cfl_at_unit_dt, cfl_limit):
+    """reference: neklab_nek_setup.f90:195-198."""
+    dt = cfl_limit / cfl_at_unit_dt
+    nsteps = int(math.ceil(tau / dt))
+    return tau / nsteps, nsteps
+
+
+class ExptA:
+    def __init__(self, sem, baseflow, cfg: LNSConfig):
+        self.sem = sem
+        self.cfg = cfg
+        self.U = [sem.f1(a).copy() for a in baseflow]
+        if cfg.dt > 0:
+            self.nsteps = int(math.ceil(cfg.tau / cfg.dt - 1e-12))
+            self.dt = cfg.tau / self.nsteps
+        else:
+            c1 = sem.compute_cfl(self.U, 1.0)
+            self.dt, self.nsteps = dt_rule(cfg.tau, c1, cfg.cfl_limit)
+        self.nu = 1.0 / cfg.re
+        self.ediag_inv = 1.0 / sem.e_diag()
+        self._hdiag = {}
+        self.stats = {"v_iters": 0, "p_iters": 0, "steps": 0}
+
+    # ---------------- solvers ----------------
+    def hdiag_inv(self, h2):
+        key = float(h2)
+        if key not in self._hdiag:
+            d = self.sem.gs(self.sem.helm_diag_local(self.nu, h2))
+            self._hdiag[key] = 1.0 / d
+        return self._hdiag[key]
+
+    def helm_apply(self, p, h2):
+        s = self.sem
+        return [s.mask[i] * s.gs(s.axhelm_local(p[i], self.nu, h2)) for i in range(s.dim)]
+
+    def pcg_helm(self, b, h2):
+        s, cfg = self.sem, self.cfg
+        dim = s.dim
+        minv = self.hdiag_inv(h2)
+        wnorm = s.binvm1 * s.vmult / s.volvm1
+        x = [np.zeros(s.shape1) for _ in range(dim)]
+        r = [bi.copy() for bi in b]
+        z = [s.mask[i] * minv * r[i] for i in range(dim)]
+        p = [zi.copy() for zi in z]
+        rz = sum(np.sum(r[i] * z[i] * s.vmult) for i in range(dim))
+        it = 0
+        maxit = cfg.fixed_iters_v if cfg.fixed_iters_v > 0 else cfg.maxit_v
+        while it < maxit:
+            if cfg.fixed_iters_v <= 0:
+                rn = math.sqrt(sum(np.sum(r[i] * r[i] * wnorm) for i in range(dim)))
+                if rn < cfg.vtol:
+                    break
+            w = self.helm_apply(p, h2)
+            pw = sum(np.sum(p[i] * w[i] * s.vmult) for i in range(dim))
+            alpha = rz / pw
+            for i in range(dim):
+                x[i] += alpha * p[i]
+                r[i] -= alpha * w[i]
+                z[i] = s.mask[i] * minv * r[i]
+            rz_new = sum(np.sum(r[i] * z[i] * s.vmult) for i in range(dim))
+            beta = rz_new / rz
+            rz = rz_new
+            for i in range(dim):
+                p[i] = z[i] + beta * p[i]
+            it += 1
+        self.stats["v_iters"] += it
+        return x
+
+    def pcg_E(self, b, scale):
+        """Solve E x = b; converged when scale*||r||_p < ptol (remaining divergence)."""
+        s, cfg = self.sem, self.cfg
+        minv = self.ediag_inv
+        x = np.zeros(s.shape2)
+        r = b.copy()
+        z = minv * r
+        p = z.copy()
+        rz = float(np.sum(r * z))
+        it = 0
+        maxit = cfg.fixed_iters_p if cfg.fixed_iters_p > 0 else cfg.maxit_p
+        while it < maxit:
+            if cfg.fixed_iters_p <= 0:
+                rn = scale * math.sqrt(float(np.sum(r * r / s.bm2)) / s.volvm2)
+                if rn < cfg.ptol:
+                    break
+            w = s.cdabdtp(p)
+            pw = float(np.sum(p * w))
+            alpha = rz / pw
+            x += alpha * p
+            r -= alpha * w
+            z = minv * r
+            rz_new = float(np.sum(r * z))
+            beta = rz_new / rz
+            rz = rz_new
+            p = z + beta * p
+            it += 1
+        self.stats["p_iters"] += it
+        return x
+
+    # ---------------- one time step (restated nek_advance, perturbation mode) ----------------
+    def _reset_state(self, vec: NekDVector, adjoint):
+        s = self.sem
+        self.u = [a.copy() for a in vec.v]
+        self.p = vec.pr.copy()
+        self.ulag = [[np.zeros(s.shape1) for _ in range(s.dim)] for _ in range(2)]
+        self.flag = [[np.zeros(s.shape1) for _ in range(s.dim)] for _ in range(2)]
+        self.istep = 0
+        self.adjoint = adjoint
+
+    def advance(self):
+        s, cfg = self.sem, self.cfg
+        dim, dt = s.dim, self.dt
+        self.istep += 1
+        k = min(self.istep, cfg.torder)
+        b0, bd = BDF[k]
+        ab = EXT[k]
+        N = s.lns_conv_weak(self.U, self.u, adjoint=self.adjoint)
+        F = [-a for a in N]
+        hist_f = [F] + self.flag
+        hist_u = [self.u] + self.ulag
+        rhs = []
+        for i in range(dim):
+            acc = sum(ab[j] * hist_f[j][i] for j in range(k))
+            acc = acc + (s.bm1 / dt) * sum(bd[j] * hist_u[j][i] for j in range(k))
+            rhs.append(acc)
+        # shift histories
+        self.flag = [F, self.flag[0]]
+        self.ulag = [[a.copy() for a in self.u], self.ulag[0]]
+        # tentative velocity, residual form with lagged pressure
+        h2 = b0 / dt
+        gp = s.opgradt(self.p)
+        res = [s.mask[i] * s.gs(rhs[i] + gp[i] - s.axhelm_local(self.u[i], self.nu, h2)) for i in range(dim)]
+        du = self.pcg_helm(res, h2)
+        uh = [self.u[i] + du[i] for i in range(dim)]
+        # pressure correction
+        rp = -(b0 / dt) * s.opdiv(uh)
+        rp = s.ortho(rp)
+        dp = self.pcg_E(rp, dt / b0)
+        dp = s.ortho(dp)
+        self.p = self.p + dp
+        w = s.opbinv(s.opgradt(dp))
+        self.u = [uh[i] + (dt / b0) * w[i] for i in range(dim)]
+        self.stats["steps"] += 1
+
+    def _load(self, vec):
+        self.u = [a.copy() for a in vec.v]
+        self.p = vec.pr.copy()
+
+    def _store(self, vec):
+        for a, b in zip(vec.v, self.u):
+            a[...] = b
+        vec.pr[...] = self.p
+
+    # ---------------- reference: exponential_propagator.f90:15-60 / :62-107 ----------------
+    def matvec(self, vec_in: NekDVector, adjoint=False) -> NekDVector:
+        nrst = self.cfg.torder - 1
+        vec_out = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)   # intent(out): default-initialised
+        self._reset_state(vec_in, adjoint)
+        for istep in range(1, self.nsteps + 1):
+            self.advance()
+            if istep <= nrst and vec_in.has_rst_fields():          # get_rst, :129-142
+                tmp = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)
+                vec_in.get_rst(tmp, istep)
+                self._load(tmp)
+        self._store(vec_out)
+        # compute_rst, :109-127
+        for irst in range(1, nrst + 1):
+            self.advance()
+            tmp = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)
+            self._store(tmp)
+            vec_out.save_rst(tmp, irst)
+        return vec_out
+
+    def rmatvec(self, vec_in):
+        return self.matvec(vec_in, adjoint=True)
