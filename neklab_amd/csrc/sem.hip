@@ -1488,6 +1488,29 @@ int nlg_mesh_sizes(const nlg_mesh *m, int64_t *lvn, int64_t *lpn, int *dim, int 
 
 int nlg_mesh_get(const nlg_mesh *m, const char *name, double *out, int64_t count) {
     NLG_CHECK(m && name && out, "nlg_mesh_get: NULL argument");
+    // derived-on-demand arrays (verification only): "ediag" = diag(E), "hdiag:<h1>:<h2>" = assembled diag(H)
+    if (strcmp(name, "ediag") == 0) {
+        NLG_CHECK(count == m->lpn, "nlg_mesh_get: count mismatch for ediag");
+        nlg_mesh *mm = const_cast<nlg_mesh *>(m);
+        double *ed = sem_scratch2(mm, 5);
+        NLG_TRY(sem_ediag(mm, ed));
+        NLG_HIP(hipMemcpyAsync(out, ed, sizeof(double) * (size_t)m->lpn, hipMemcpyDeviceToHost, m->ctx->stream));
+        NLG_HIP(hipStreamSynchronize(m->ctx->stream));
+        return 0;
+    }
+    if (strncmp(name, "hdiag:", 6) == 0) {
+        double h1 = 0, h2 = 0;
+        NLG_CHECK(sscanf(name + 6, "%lf:%lf", &h1, &h2) == 2, "nlg_mesh_get: bad hdiag spec '%s'", name);
+        NLG_CHECK(count == m->lvn, "nlg_mesh_get: count mismatch for hdiag");
+        nlg_mesh *mm = const_cast<nlg_mesh *>(m);
+        double *dg = sem_scratch1(mm, 3);
+        NLG_TRY(sem_helm_diag(mm, dg, h1, h2));
+        double *f[1] = {dg};
+        NLG_TRY(sem_gs(mm, f, 1));
+        NLG_HIP(hipMemcpyAsync(out, dg, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, m->ctx->stream));
+        NLG_HIP(hipStreamSynchronize(m->ctx->stream));
+        return 0;
+    }
     auto it = m->named.find(name);
     NLG_CHECK(it != m->named.end(), "nlg_mesh_get: unknown array '%s'", name);
     const int64_t len = m->named_len.at(name);

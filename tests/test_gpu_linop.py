@@ -1,0 +1,163 @@
+"""GPU parity of the exponential propagator, the Arnoldi step and eigs against the CPU oracle."""
+import numpy as np
+import pytest
+
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+from oracle.krylov import arnoldi_step as o_arnoldi_step
+from oracle.krylov import eigs as o_eigs
+from oracle.lns import ExptA, LNSConfig
+from oracle.sem import SEM
+from oracle.vectors import NekDVector
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.04):
+    if dim == 2:
+        hm = box_mesh((4, 3), n, lengths=(4.0, 2.0), periodic=(True, False), deform=deform)
+    else:
+        hm = box_mesh((3, 2, 2), n, lengths=(3.0, 2.0, 2.0), periodic=(True, False, False), deform=deform)
+    sem = SEM(hm)
+    gm = host.Mesh(ctx, hm)
+    rng = np.random.default_rng(5)
+    # smooth-ish divergence-free-agnostic base flow: C0, masked
+    ob = NekDVector(sem)
+    for i in range(dim):
+        ob.v[i][...] = sem.mask[i] * sem.dsavg(np.sin(sem.X[0] * (i + 1)) * np.cos(sem.X[1]) + 0.3 * rng.standard_normal(sem.shape1) * 0)
+    ob.v[0][...] += sem.mask[0] * 1.0
+    gb = host.nek_dvector(gm)
+    for i in range(dim):
+        gb.set_field(i, ob.v[i])
+    kw = dict(re=re, torder=torder, tau=tau, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    if fixed:
+        kw.update(fixed_iters_v=30, fixed_iters_p=600)   # converged: unconverged CG amplifies rounding differences
+    ocfg = LNSConfig(**kw)
+    oA = ExptA(sem, ob.v, ocfg)
+    gA = host.exptA_linop(tau, gb, **{k: v for k, v in kw.items() if k != "tau"})
+    gA.init()
+    return hm, sem, gm, oA, gA, rng
+
+
+def load_pair(sem, gm, rng):
+    ov = NekDVector(sem)
+    ov.rand(ifnorm=True, seed=3)
+    ov.pr[...] = 0.01 * rng.standard_normal(sem.shape2)
+    gv = host.nek_dvector(gm)
+    for i in range(sem.dim):
+        gv.set_field(i, ov.v[i])
+    gv.set_field(host.PR, ov.pr)
+    return ov, gv
+
+
+def cmp_vec(gv, ov, tol, what=""):
+    sc = max(np.abs(a).max() for a in ov.v)
+    for i in range(len(ov.v)):
+        err = np.max(np.abs(gv.get_field(i) - ov.v[i].ravel()))
+        assert err < tol * sc, "%s v%d err %.3e (scale %.3e)" % (what, i, err, sc)
+    scp = max(np.abs(ov.pr).max(), 1e-300)
+    errp = np.max(np.abs(gv.get_field(host.PR) - ov.pr.ravel()))
+    assert errp < 10 * tol * max(scp, sc), "%s pr err %.3e (scale %.3e)" % (what, errp, scp)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_matvec_fixed_iterations(gpu_ctx, dim, adjoint):
+    """Identical discrete operator, identical iteration counts -> agreement to rounding."""
+    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, dim)
+    info = gA.info()
+    assert info["nsteps"] == oA.nsteps and abs(info["dt"] - oA.dt) < 1e-15
+    ov, gv = load_pair(sem, gm, rng)
+    gout = host.nek_dvector(gm)
+    (gA.rmatvec if adjoint else gA.matvec)(gv, gout)
+    oout = oA.matvec(ov, adjoint=adjoint)
+    cmp_vec(gout, oout, 1e-11, "matvec")
+    assert gout.nrst == oout.nrst == 2
+    for r in (1, 2):
+        for i in range(dim):
+            assert np.max(np.abs(gout.get_field(i, r) - oout.v_rst[r - 1][i].ravel())) < 1e-11 * np.abs(oout.v[i]).max()
+    # second matvec replays the restart history (exponential_propagator.f90:44)
+    gout2 = host.nek_dvector(gm)
+    (gA.rmatvec if adjoint else gA.matvec)(gout, gout2)
+    oout2 = oA.matvec(oout, adjoint=adjoint)
+    cmp_vec(gout2, oout2, 1e-10, "matvec2")
+    st = gA.stats()
+    assert st["steps"] == oA.stats["steps"] and st["p_iters"] == oA.stats["p_iters"] and st["v_iters"] == oA.stats["v_iters"]
+
+
+def test_matvec_tolerance_mode(gpu_ctx):
+    """Tolerance-terminated solves: agreement at the level of the tolerances."""
+    # undeformed mesh: the GL(lx2) quadrature of the divergence is then exact, the constant is exactly in
+    # the null space of E and `ortho` is consistent, so the result must be discretely solenoidal
+    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, 2, fixed=False, deform=0.0)
+    ov, gv = load_pair(sem, gm, rng)
+    gout = host.nek_dvector(gm)
+    gA.matvec(gv, gout)
+    oout = oA.matvec(ov)
+    cmp_vec(gout, oout, 1e-9, "matvec-tol")
+    # incompressibility of the result
+    div = sem.opdiv([gout.get_field(i).reshape(sem.shape1) for i in range(2)]) / sem.bm2
+    assert np.sqrt(np.sum(div ** 2 * sem.bm2) / sem.volvm2) < 1e-10
+
+
+def test_matvec_errors(gpu_ctx):
+    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, 2)
+    ov, gv = load_pair(sem, gm, rng)
+    with pytest.raises(host.NlgError):
+        gA.matvec(gv, gv)                      # intent(in)/intent(out) aliasing
+    with pytest.raises(TypeError):
+        gA.matvec(gv, object())                # type_error
+    other = host.Mesh(gpu_ctx, box_mesh((2, 2), 6))
+    with pytest.raises(host.NlgError):
+        gA.matvec(gv, host.nek_dvector(other))
+    hb = host.nek_dvector(gm)
+    with pytest.raises(host.NlgError):
+        host.exptA_linop(1.0, hb, fixed_iters_v=1).matvec(gv, host.nek_dvector(gm))   # init() not called
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_arnoldi_steps(gpu_ctx, dim):
+    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, dim, tau=0.03)
+    m = 5
+    ov, gv = load_pair(sem, gm, rng)
+    B = host.KrylovBasis(gm, m + 1)
+    B[0].assign(gv)
+    H = np.zeros((m + 1, m), order="F")
+    oV = [None] * (m + 1)
+    oV[0] = ov
+    oH = np.zeros((m + 1, m))
+    for k in range(m):
+        host.arnoldi_step(gA, B, k, H)
+        o_arnoldi_step(oA.matvec, oV, oH, k)
+    assert np.max(np.abs(H - oH)) < 1e-10 * np.max(np.abs(oH))
+    for k in range(m + 1):
+        cmp_vec(B[k], oV[k], 1e-9, "basis %d" % k)
+    # orthonormality in the mass inner product
+    G = np.array([[B[i].dot(B[j]) for j in range(m + 1)] for i in range(m + 1)])
+    assert np.max(np.abs(G - np.eye(m + 1))) < 1e-13
+
+
+def test_eigs_against_oracle(gpu_ctx):
+    """Ritz values within 1e-10 relative, Ritz vectors within 1e-6 (BASELINE.json north_star)."""
+    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, 2, tau=0.2, re=20.0)
+    ov, gv = load_pair(sem, gm, rng)
+    nev, kdim = 2, 12
+    X = [host.nek_dvector(gm) for _ in range(nev)]
+    import os
+    import tempfile
+    log = os.path.join(tempfile.mkdtemp(), "eigs_output.txt")
+    mu, res, info = host.eigs(gA, X, kdim=kdim, tol=1e-6, x0=gv, logfile=log, max_restarts=4)
+    olam, ovecs, ores, onmv = o_eigs(oA.matvec, ov, nev, kdim, tol=1e-6, max_restarts=4)
+    assert info == onmv
+    assert np.max(np.abs(mu - olam) / np.abs(olam)) < 1e-10
+    assert np.max(np.abs(res - ores)) < 1e-8
+    for j in range(nev):
+        # eigenvectors are defined up to a sign / complex phase; compare through the projector
+        a = np.concatenate([X[j].get_field(i) for i in range(2)])
+        b = np.concatenate([ovecs[j].v[i].ravel() for i in range(2)])
+        s = np.sign(np.dot(a, b))
+        assert np.max(np.abs(a - s * b)) < 1e-6 * np.max(np.abs(b))
+    # eigs_output.txt in the format test/lib/neklabTestCase.py:425-449 parses
+    rows = [ln.split() for ln in open(log) if not ln.startswith("#")]
+    assert len(rows) >= nev and all(len(r) == 6 and r[5] in ("T", "F") for r in rows)
+    assert abs(float(rows[0][3]) - abs(mu[0])) < 1e-12
