@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: exptA matvec + Arnoldi orthogonalisation on the MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+
+A "step" is one Arnoldi iteration at full basis size on BASELINE.json's headline configuration
+(configs[2]: 3-D, E = 10 000 = 25x20x20 spectral elements, N = 7 i.e. lx1 = 8, Krylov dimension m = 64):
+one `exptA` matvec (nsteps + torder-1 restated nek_advance steps, each with a dealiased convective
+term, one joint Helmholtz Jacobi-PCG solve and one consistent-Poisson Jacobi-PCG solve to the
+reference tolerances 1e-9 / 1e-7 of examples/cylinder/stability/direct/1cyl.par:22,27) followed by the
+CGS2 orthogonalisation of the result against the m basis vectors, normalisation included.
+`value` = matvecs per second of the whole job; inputs are resident in HBM before the timed region.
+
+The JSON also carries `roofline` for the kernel class with the largest share of the timed region
+(HIP events on the launch stream, algorithmic bytes from DESIGN.md §5) and `cpu_baseline` (the CPU
+restatement in oracle/, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nel", type=str, default="25,20,20", help="elements per direction (E = product)")
+    ap.add_argument("--lx1", type=int, default=8)
+    ap.add_argument("--kdim", type=int, default=64)
+    ap.add_argument("--nsteps", type=int, default=2, help="time steps per matvec before the torder-1 history steps")
+    ap.add_argument("--re", type=float, default=100.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len):
+    """Algorithmic HBM bytes of ONE launch of a kernel class, fp64."""
+    n2 = n - 2
+    np1, np2 = n ** dim, n2 ** dim
+    if cls == "opgradt":      # p + dim^2 metric terms in, dim velocity-mesh fields out
+        return 8.0 * E * (np2 * (1 + dim * dim) + dim * np1)
+    if cls == "opdiv":        # dim fields + dim fused weights in, dim^2 metric terms, p out
+        return 8.0 * E * (2 * dim * np1 + np2 * (dim * dim + 1))
+    if cls == "axhelm":       # NF = dim fields in/out, 6 (3) metric factors + mass
+        ng = 6 if dim == 3 else 3
+        return 8.0 * E * np1 * (2 * dim + ng + 1)
+    if cls == "gs":           # value in + out per shared local dof and field, 4-byte index once
+        return nshared * (16.0 * dim + 4.0)
+    if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
+        return 8.0 * (k * ncomp + ncomp + 1) * lvs
+    if cls == "block_axpy":   # k basis vectors + w in/out over all main fields
+        return 8.0 * (k + 2) * main_len
+    return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    from neklab_amd import host
+    from neklab_amd.mesh import box_mesh, partition_elements
+
+    nel = tuple(int(x) for x in args.nel.split(","))
+    n, dim, m = args.lx1, len(nel), args.kdim
+    E = int(np.prod(nel))
+    ctx = host.Context(local_rank)
+    if world > 1:
+        import torch
+        uid = [host.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, world, uid[0])
+    lib = ctx.lib
+
+    # ---- synthetic inputs: deformed box, wall-masked, C0 noise on a smooth shear flow
+    t0 = time.time()
+    full = box_mesh(nel, n, deform=0.05)
+    if world > 1:
+        # weak scaling: every rank holds a full-size E-element block of an N-times larger global basis;
+        # inner products are global (RCCL allreduce); see DESIGN.md §7 for what is and is not exchanged.
+        hm = full
+        hm.elem_gid = hm.elem_gid + rank * E
+    else:
+        hm = full
+    gm = host.Mesh(ctx, hm)
+    bf = host.nek_dvector(gm)
+    L = hm.lengths
+    X = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
+    ph = [2 * np.pi * X[d] / L[d] for d in range(dim)]
+    if dim == 3:
+        U = [np.sin(ph[1]) * np.cos(ph[2]), 0.5 * np.sin(ph[2]) * np.cos(ph[0]), 0.5 * np.sin(ph[0]) * np.cos(ph[1])]
+    else:
+        U = [np.sin(ph[1]), 0.5 * np.sin(ph[0])]
+    for i in range(dim):
+        bf.set_field(i, U[i] * hm.mask[i])
+    noise = host.nek_dvector(gm)
+    noise.rand(False, seed=0)
+    bf.axpby(0.05, noise, 1.0)
+    # tau such that the CFL rule (cfl_limit 0.5) gives exactly args.nsteps steps
+    cfl1 = C.c_double()
+    host.check(lib.nlg_op_cfl(gm.h, bf.h, 1.0, C.byref(cfl1)))
+    dt0 = 0.5 / cfl1.value
+    tau = dt0 * (args.nsteps - 0.5)
+    A = host.exptA_linop(tau, bf, re=args.re, torder=3, vtol=1e-9, ptol=1e-7, maxit_v=200, maxit_p=4000)
+    A.init()
+    info = A.info()
+    assert info["nsteps"] == args.nsteps, info
+
+    # ---- Krylov basis of m orthonormal vectors + one work column, resident in HBM
+    B = host.KrylovBasis(gm, m + 1)
+    for j in range(m):
+        v = B[j]
+        v.rand(False, seed=100 + j + 1000 * rank)
+        B.cgs2(j, v)
+    ctx.sync()
+    setup_s = time.time() - t0
+    H = np.zeros((m + 2, m + 1), order="F")
+    names = ["axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops"]
+
+    def step():
+        host.arnoldi_step(A, B, m - 1, H)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warmup (all kernel classes timed to find the dominant one)
+    host.check(lib.nlg_prof_reset(ctx.h))
+    host.check(lib.nlg_prof_enable(ctx.h, -1))
+    st0 = A.stats()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    ctx.sync()
+    prof = {}
+    for nm in names:
+        cnt, ms = C.c_int64(), C.c_double()
+        host.check(lib.nlg_prof_get(ctx.h, nm.encode(), C.byref(cnt), C.byref(ms)))
+        prof[nm] = (cnt.value, ms.value)
+    dominant = max(prof, key=lambda k: prof[k][1])
+    host.check(lib.nlg_prof_enable(ctx.h, 1 << names.index(dominant)))
+    host.check(lib.nlg_prof_reset(ctx.h))
+    st1 = A.stats()
+
+    # ---- timed region: exactly K steps
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st2 = A.stats()
+    cnt, ms = C.c_int64(), C.c_double()
+    host.check(lib.nlg_prof_get(ctx.h, dominant.encode(), C.byref(cnt), C.byref(ms)))
+    host.check(lib.nlg_prof_enable(ctx.h, 0))
+    avg_ms = ms.value / max(cnt.value, 1)
+    # shared local dofs: copies of labels that occur more than once
+    _, inv, counts = np.unique(hm.glo_num.ravel(), return_inverse=True, return_counts=True)
+    nshared = int(np.sum(counts[inv] > 1))
+    lvs = -(-gm.lvn // 32) * 32
+    lps = -(-gm.lpn // 32) * 32
+    abytes = algorithmic_bytes(dominant, E, n, dim, m, dim, lvs, lps, nshared, dim * lvs + lps)
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None, "traffic": None, "launches": cnt.value, "avg_ms": avg_ms,
+                "algorithmic_bytes_per_launch": abytes,
+                "share_of_step": {k: round(v[1] / max(sum(x[1] for x in prof.values()), 1e-30), 4) for k, v in prof.items()}}
+    if abytes is not None and avg_ms > 0:
+        roofline["achieved"] = abytes / (avg_ms * 1e-3) / 1e9
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+
+    steps_per_mv = (st2["steps"] - st1["steps"]) / max(args.steps, 1)
+    p_iters = (st2["p_iters"] - st1["p_iters"]) / max(st2["steps"] - st1["steps"], 1)
+    v_iters = (st2["v_iters"] - st1["v_iters"]) / max(st2["steps"] - st1["steps"], 1)
+
+    # ---- CPU baseline (rank 0, N = 1 only): oracle restatement on a bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        try:
+            from oracle import cpu_baseline
+            cpu = cpu_baseline.run(hm, U_fields=[bf.get_field(i) for i in range(dim)], re=args.re, dt=info["dt"],
+                                   kdim=m, v_iters=max(int(round(v_iters)), 1), p_iters=max(int(round(p_iters)), 1),
+                                   steps_per_matvec=steps_per_mv, budget_s=args.cpu_seconds)
+        except Exception as exc:   # the baseline is a report, never a reason to lose the GPU number
+            cpu = {"value": None, "unit": "matvecs/s", "cores": None, "kind": "port", "sample": "failed: %r" % (exc,)}
+
+    if rank == 0:
+        out = {
+            "metric": "linop matvecs/sec + Arnoldi iter time, E=10k N=7, 1/2/4/8 GPU",
+            "value": world * args.steps / elapsed if world > 1 else args.steps / elapsed,
+            "unit": "matvecs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D deformed box E=%d (%s) lx1=%d (N=%d), Krylov dim m=%d, exptA: Re=%g bdf3/ext3 "
+                                   "nsteps=%d(+2 history steps), tol 1e-9/1e-7, one Arnoldi iteration per step at k=m"
+                                   % (E, "x".join(map(str, nel)), n, n - 1, m, args.re, args.nsteps),
+                       "elements_per_gpu": E, "time_steps_per_matvec": steps_per_mv,
+                       "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
+                       "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
+                       "parallelism": "1 process per GPU, element-partitioned basis, RCCL allreduce for inner products"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

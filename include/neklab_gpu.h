@@ -51,6 +51,12 @@ int nlg_ctx_sync(nlg_ctx *ctx);
 int nlg_comm_unique_id(void *out128);
 int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id128);
 int nlg_ctx_rank(const nlg_ctx *ctx, int *rank, int *nranks);
+/* Per-kernel-class timing with HIP events recorded on the launch stream (the reference's counterpart
+ * is LightKrylov's timer object, src/neklab_analysis.f90:66-67, :98-101).  Classes: "axhelm", "gs",
+ * "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops". */
+int nlg_prof_enable(nlg_ctx *ctx, int class_mask); /* bit i = class i in the order above; -1 = all; 0 = off */
+int nlg_prof_reset(nlg_ctx *ctx);
+int nlg_prof_get(nlg_ctx *ctx, const char *name, int64_t *count, double *total_ms);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* mesh: replaces the Nek5000 commons the reference reads through include "SIZE"/"TOTAL"            */

@@ -41,9 +41,78 @@ int reduce_ws_reserve(nlg_ctx *ctx, int nvec) {
     return 0;
 }
 
+static const char *kProfNames[P_COUNT] = {"axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy",
+                                          "cg_vec", "conv", "vec_ops"};
+
+void prof_begin(nlg_ctx *ctx, int id) {
+    nlg_prof_slot &s = ctx->prof[id];
+    if (s.used + 2 > (int)s.ev.size()) {
+        if (s.ev.size() >= 16384) {
+            prof_flush(ctx);
+        } else {
+            const size_t old = s.ev.size();
+            s.ev.resize(old + 1024);
+            for (size_t i = old; i < s.ev.size(); ++i) hipEventCreate(&s.ev[i]);
+        }
+    }
+    hipEventRecord(s.ev[s.used], ctx->stream);
+}
+
+void prof_end(nlg_ctx *ctx, int id) {
+    nlg_prof_slot &s = ctx->prof[id];
+    hipEventRecord(s.ev[s.used + 1], ctx->stream);
+    s.used += 2;
+}
+
+int prof_flush(nlg_ctx *ctx) {
+    hipStreamSynchronize(ctx->stream);
+    for (int id = 0; id < P_COUNT; ++id) {
+        nlg_prof_slot &s = ctx->prof[id];
+        for (int i = 0; i + 1 < s.used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]) == hipSuccess) {
+                s.total_ms += ms;
+                s.count += 1;
+            }
+        }
+        s.used = 0;
+    }
+    return 0;
+}
+
 }  // namespace nlg
 
 using namespace nlg;
+
+extern "C" int nlg_prof_enable(nlg_ctx *ctx, int on) {
+    NLG_CHECK(ctx, "nlg_prof_enable: NULL ctx");
+    prof_flush(ctx);
+    ctx->prof_on = on;   // bit mask over kernel classes (1 << class index); -1 = all
+    return 0;
+}
+
+extern "C" int nlg_prof_reset(nlg_ctx *ctx) {
+    NLG_CHECK(ctx, "nlg_prof_reset: NULL ctx");
+    prof_flush(ctx);
+    for (int id = 0; id < P_COUNT; ++id) {
+        ctx->prof[id].total_ms = 0.0;
+        ctx->prof[id].count = 0;
+    }
+    return 0;
+}
+
+extern "C" int nlg_prof_get(nlg_ctx *ctx, const char *name, int64_t *count, double *total_ms) {
+    NLG_CHECK(ctx && name, "nlg_prof_get: NULL argument");
+    prof_flush(ctx);
+    for (int id = 0; id < P_COUNT; ++id)
+        if (strcmp(name, kProfNames[id]) == 0) {
+            if (count) *count = ctx->prof[id].count;
+            if (total_ms) *total_ms = ctx->prof[id].total_ms;
+            return 0;
+        }
+    set_error("nlg_prof_get: unknown kernel class '%s'", name);
+    return 1;
+}
 
 extern "C" {
 

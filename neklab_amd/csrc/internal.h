@@ -55,7 +55,19 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace nlg
 
+// kernel classes that can be timed with HIP events on the launch stream (bench.py roofline leg)
+enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_COUNT };
+
+struct nlg_prof_slot {
+    std::vector<hipEvent_t> ev;   // pairs (begin, end)
+    int used = 0;
+    double total_ms = 0.0;
+    int64_t count = 0;
+};
+
 struct nlg_ctx {
+    int prof_on = 0;
+    nlg_prof_slot prof[P_COUNT];
     int device = 0;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
@@ -150,6 +162,21 @@ struct nlg_basis {
 
 namespace nlg {
 
+// ---- ctx.hip: optional per-kernel-class event timing ----
+void prof_begin(nlg_ctx *ctx, int id);
+void prof_end(nlg_ctx *ctx, int id);
+int prof_flush(nlg_ctx *ctx);
+struct ProfScope {
+    nlg_ctx *c;
+    int id;
+    ProfScope(nlg_ctx *ctx, int i) : c(ctx), id(i) {
+        if (c->prof_on & (1 << id)) prof_begin(c, id);
+    }
+    ~ProfScope() {
+        if (c->prof_on & (1 << id)) prof_end(c, id);
+    }
+};
+
 // ---- vec.hip ----
 int reduce_ws_reserve(nlg_ctx *ctx, int nvec);
 // weighted dot over the inner-product part, result left on device at ctx->d_scalars[slot]; allreduced
@@ -167,7 +194,7 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2);
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w);
-int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale);
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr);
 int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out);
 int sem_ediag(nlg_mesh *m, double *out);

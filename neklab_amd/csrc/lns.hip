@@ -338,6 +338,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         if (launched + todo > P.maxit) todo = P.maxit - launched;
         for (int it = 0; it < todo; ++it) {
             NLG_TRY(apply(s));
+            ProfScope ps(ctx, P_CGVEC);
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
             hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 1, s + S_T0, 1);
             NLG_TRY(allreduce_sum(ctx, s + S_T0, 1));

@@ -614,9 +614,11 @@ __global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, const double *__rest
 
 // ---- opdiv 3-D: out = scale * sum_i sum_j g_ji o (T_j u_i) ------------------------------------------
 // Im / Dm are I12 / D12 (N2 x N row-major).
+// `wt` (may hold nulls) is an optional pointwise weight applied to u_i while loading: with
+// wt_i = mask_i * binvm1 the opbinv scaling of the consistent Poisson operator is fused in.
 template <int N>
 __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, const double *__restrict__ Img,
-                                               const double *__restrict__ Dmg, CF9 g, CF3 u,
+                                               const double *__restrict__ Dmg, CF9 g, CF3 u, CF3 wt,
                                                double *__restrict__ out, double scale) {
     constexpr int N2 = N - 2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
@@ -637,7 +639,11 @@ __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, const double *__restri
     for (int r = 0; r < NACC; ++r) acc[r] = 0.0;
     for (int i = 0; i < 3; ++i) {
         __syncthreads();
-        for (int q = tid; q < NP1; q += NT) sU[q] = u.p[i][e * NP1 + q];
+        if (wt.p[i]) {
+            for (int q = tid; q < NP1; q += NT) sU[q] = u.p[i][e * NP1 + q] * wt.p[i][e * NP1 + q];
+        } else {
+            for (int q = tid; q < NP1; q += NT) sU[q] = u.p[i][e * NP1 + q];
+        }
         __syncthreads();
         // x stage: B0 = D_x u, B1 = I_x u
         contract<N, N, N, 0, N2, false>(sU, sB[0], sD, tid, NT);
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(NT) void k_opgradt2(int64_t E, const double *__rest
 
 template <int N>
 __global__ __launch_bounds__(NT) void k_opdiv2(int64_t E, const double *__restrict__ Img,
-                                               const double *__restrict__ Dmg, CF9 g, CF3 u,
+                                               const double *__restrict__ Dmg, CF9 g, CF3 u, CF3 wt,
                                                double *__restrict__ out, double scale) {
     constexpr int N2 = N - 2;
     constexpr int NP2 = N2 * N2, NP1 = N * N, SB = N2 * N;
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(NT) void k_opdiv2(int64_t E, const double *__restri
     double acc = 0.0;
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
-        if (act) sU[le][lt] = u.p[i][e * NP1 + lt];
+        if (act) sU[le][lt] = u.p[i][e * NP1 + lt] * (wt.p[i] ? wt.p[i][e * NP1 + lt] : 1.0);
         __syncthreads();
         if (act && lt < SB) {
             const int a = lt % N2, b = lt / N2;   // (a2, b)
@@ -947,6 +953,7 @@ double *sem_scratch2(nlg_mesh *m, int i) {
 
 int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
     if (m->gs.ngroups == 0) return 0;
+    ProfScope ps(m->ctx, P_GS);
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
     const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
     if (nf == 1)
@@ -965,6 +972,7 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
 
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
+    ProfScope ps(m->ctx, P_AXHELM);
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
     F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
     hipStream_t s = m->ctx->stream;
@@ -1021,6 +1029,7 @@ static CF9 rst2w_ptrs(const nlg_mesh *m) {
 }
 
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
+    ProfScope ps(m->ctx, P_OPGRADT);
     F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
@@ -1042,12 +1051,14 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
     return 0;
 }
 
-int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale) {
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts) {
+    ProfScope ps(m->ctx, P_OPDIV);
     CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
+    CF3 wt = {{wts ? wts[0] : nullptr, wts ? wts[1] : nullptr, (wts && m->dim == 3) ? wts[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
-#define DV3(N_) hipLaunchKernelGGL((k_opdiv3<N_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, m->d_I12, m->d_D12, g, cu, out, scale)
+#define DV3(N_) hipLaunchKernelGGL((k_opdiv3<N_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, m->d_I12, m->d_D12, g, cu, wt, out, scale)
         NLG_FOR_N(DV3)
 #undef DV3
     } else {
@@ -1055,7 +1066,7 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale) {
     {                                                                                                      \
         constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                       \
         hipLaunchKernelGGL((k_opdiv2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
-                           m->d_I12, m->d_D12, g, cu, out, scale);                                         \
+                           m->d_I12, m->d_D12, g, cu, wt, out, scale);                                     \
     }
         NLG_FOR_N(DV2)
 #undef DV2
@@ -1066,6 +1077,7 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale) {
 
 int sem_opbinv(nlg_mesh *m, double *const *w) {
     NLG_TRY(sem_gs(m, w, m->dim));
+    ProfScope ps(m->ctx, P_COLMUL);
     F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
     CF3 wt = {{m->d_mbinv[0], m->d_mbinv[1], m->d_mbinv[2]}};
     if (m->dim == 3)
@@ -1080,8 +1092,8 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out) {
     double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
     NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
     NLG_TRY(sem_opgradt(m, p, w));
-    NLG_TRY(sem_opbinv(m, w));
-    NLG_TRY(sem_opdiv(m, w, out, 1.0));
+    NLG_TRY(sem_gs(m, w, m->dim));
+    NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv));   // mask * binvm1 fused into the load
     return 0;
 }
 
@@ -1154,6 +1166,7 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
 
 // out_i = weak linearised convective term (B-weighted, element-local), see oracle/sem.py lns_conv_weak
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
+    ProfScope ps(m->ctx, P_CONV);
     const int dim = m->dim;
     double *uf[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
     double *du[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), dim == 3 ? sem_scratchd(m, 5) : nullptr};
@@ -1608,7 +1621,7 @@ int nlg_op_opdiv(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {
     NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m, "nlg_op_opdiv: bad arguments");
     double *u[3];
     vel_ptrs(in, u);
-    return sem_opdiv(m, u, out->pr(), 1.0);
+    return sem_opdiv(m, u, out->pr(), 1.0, nullptr);
 }
 
 int nlg_op_opgradt(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {

@@ -520,6 +520,7 @@ int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_o
     const int nblk = dot_nblk(v0);
     const int nper = nblk * v0->ncomp;
     NLG_TRY(reduce_ws_reserve(ctx, k));
+    ProfScope ps(ctx, P_BLOCKDOT);
     hipLaunchKernelGGL(k_block_dot<KB>, dim3(nblk, v0->ncomp, (k + KB - 1) / KB), dim3(NT), 0, ctx->stream, b->d,
                        b->stride, k, w->d, b->mesh->d_bm1, b->mesh->lvs, nblk, nper, ctx->d_partial);
     if (ctx->nranks > 1) {
@@ -538,6 +539,7 @@ int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_o
 int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign) {
     nlg_ctx *ctx = b->mesh->ctx;
     const int64_t n2 = w->main_len / 2;
+    ProfScope ps(ctx, P_BLOCKAXPY);
     hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride, k,
                        d_h, w->d, n2, w->nrst, n2, g_axpby_consistent, sign);
     NLG_HIP(hipGetLastError());

@@ -1,0 +1,109 @@
+"""ORACLE-side CPU baseline for bench.py (test/measurement infrastructure, never the product).
+
+Times the CPU restatement of the reference path, structured the way neklab + LightKrylov + Nek5000
+structure it (SURVEY.md §8d "CPU baseline beside it"):
+  * Gram-Schmidt as k separate dots (one mass-weighted reduction per field component,
+    /root/reference/src/vectors/real_vectors.f90:217-224) and k separate two-sweep axpbys (:168-183),
+  * element-local operator applies + gather-scatter for the Helmholtz and pressure operators,
+  * dealiased convective term once per time step.
+A whole matvec at E = 10k on the CPU takes minutes, so the baseline times a BOUNDED SAMPLE -- a few
+applications of each unit -- and composes the matvec time from the unit times and the iteration counts
+the GPU run actually needed (same tolerances, same solver).  `kind` is "port": this is the project's own
+restatement, not reference code (the reference cannot be built here).
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from .sem import SEM
+
+
+def _time(fn, budget_s, min_rep=1, max_rep=5):
+    fn()                        # warm
+    reps, t0 = 0, time.perf_counter()
+    while reps < max_rep:
+        fn()
+        reps += 1
+        if time.perf_counter() - t0 > budget_s and reps >= min_rep:
+            break
+    return (time.perf_counter() - t0) / reps
+
+
+def run(mesh, U_fields, re, dt, kdim, v_iters, p_iters, steps_per_matvec, budget_s=20.0):
+    cores = os.cpu_count() or 1
+    t_setup = time.perf_counter()
+    sem = SEM(mesh)
+    dim = sem.dim
+    rng = np.random.default_rng(0)
+    U = [np.asarray(u).reshape(sem.shape1) for u in U_fields]
+    u = [rng.standard_normal(sem.shape1) for _ in range(dim)]
+    p = rng.standard_normal(sem.shape2)
+    t_setup = time.perf_counter() - t_setup
+    nu, h2 = 1.0 / re, 11.0 / 6.0 / dt
+    per = budget_s / 6.0
+
+    def helm():
+        return [sem.mask[i] * sem.gs(sem.axhelm_local(u[i], nu, h2)) for i in range(dim)]
+
+    def eop():
+        return sem.cdabdtp(p)
+
+    def conv():
+        return sem.lns_conv_weak(U, u)
+
+    # vector-space units, per basis vector, exactly the reference's loop structure
+    def dot1():
+        return sum(sem.glsc3(u[i], U[i]) for i in range(dim))      # one reduction per component
+
+    w = [a.copy() for a in u]
+    pw = p.copy()
+
+    def axpby1():
+        for i in range(dim):
+            w[i] *= 1.0                                             # scal(beta) sweep
+            w[i] += 0.3 * u[i]                                      # add2s2 sweep
+        pw[...] *= 1.0
+        pw[...] += 0.3 * p
+
+    def cgvec_v():
+        # x += a p ; r -= a w ; z = M^-1 r ; two reductions ; p = z + b p   (per Helmholtz iteration)
+        for i in range(dim):
+            w[i] += 0.1 * u[i]
+            w[i] -= 0.1 * U[i]
+            z = sem.vmult * w[i]
+            float(np.sum(z * w[i] * sem.vmult))
+            float(np.sum(u[i] * w[i] * sem.vmult))
+            w[i] = z + 0.5 * w[i]
+
+    def cgvec_p():
+        pw[...] += 0.1 * p
+        pw[...] -= 0.1 * p
+        z = sem.bm2 * pw
+        float(np.sum(z * pw))
+        float(np.sum(p * pw))
+        pw[...] = z + 0.5 * pw
+
+    t_h = _time(helm, per)
+    t_e = _time(eop, per)
+    t_c = _time(conv, per, max_rep=2)
+    t_dot = _time(dot1, per / 4)
+    t_axp = _time(axpby1, per / 4)
+    t_cv = _time(cgvec_v, per / 4)
+    t_cp = _time(cgvec_p, per / 4)
+    t_step = t_c + v_iters * (t_h + t_cv) + p_iters * (t_e + t_cp) + 2 * t_e + 2 * t_h
+    t_matvec = steps_per_matvec * t_step
+    t_orth = 2 * kdim * (t_dot + t_axp) + t_dot + t_axp          # CGS2: two passes of k dots + k axpbys, norm, scale
+    total = t_matvec + t_orth
+    return {
+        "value": 1.0 / total, "unit": "matvecs/s", "cores": cores, "kind": "port",
+        "implementation": "numpy restatement (oracle/), BLAS threads on all host cores",
+        "sample": ("unit times on the same E=%d lx1=%d mesh: Helmholtz apply(3 comp)=%.3fs, E apply=%.3fs, "
+                   "dealiased convection=%.3fs, per-vector dot=%.4fs, per-vector axpby=%.4fs, CG vector work "
+                   "v=%.3fs p=%.4fs; composed with the GPU run's counts (%.1f time steps/matvec, %d Helmholtz and "
+                   "%d pressure iterations per step) and k=%d separate dots+axpbys per Gram-Schmidt pass"
+                   % (sem.E, sem.n, t_h, t_e, t_c, t_dot, t_axp, t_cv, t_cp, steps_per_matvec, v_iters, p_iters, kdim)),
+        "matvec_s": t_matvec, "orthogonalisation_s": t_orth, "setup_s": t_setup,
+    }
