@@ -74,10 +74,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
-        import torch
+        # Control plane only (rendezvous, unique-id broadcast, barrier, max-over-ranks): gloo on CPU tensors.
+        # The data-path collectives are RCCL calls inside libneklab_gpu.so (one communicator per process);
+        # torch's bundled HIP runtime is deliberately never initialised next to the system one the library links.
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
     from neklab_amd import host
     from neklab_amd.mesh import box_mesh, partition_elements
@@ -87,7 +88,6 @@ def main():
     E = int(np.prod(nel))
     ctx = host.Context(local_rank)
     if world > 1:
-        import torch
         uid = [host.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, world, uid[0])
@@ -172,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st2 = A.stats()

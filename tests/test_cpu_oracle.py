@@ -1,0 +1,195 @@
+"""CPU suite: the oracle against its golden vectors and against independent mathematical facts."""
+import os
+
+import numpy as np
+import pytest
+
+from neklab_amd.mesh import box_mesh, gll_points
+from oracle.sem import SEM, gl, gll
+from oracle.vectors import NekDVector
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+import sys
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg  # noqa: E402
+
+
+def golden(case):
+    return np.load(os.path.join(HERE, "golden", "golden_%s.npz" % case))
+
+
+def close(a, b, tol=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) <= tol * max(np.max(np.abs(b)), 1e-300)
+
+
+def test_quadrature_rules():
+    for n in range(3, 14):
+        x, w = gll(n)
+        assert abs(w.sum() - 2.0) < 1e-14 and np.allclose(x, gll_points(n), atol=1e-15)
+        # GLL integrates degree 2n-3 exactly
+        for d in range(0, 2 * n - 2, 2):
+            assert abs(np.sum(w * x ** d) - 2.0 / (d + 1)) < 1e-13
+        xg, wg = gl(n)
+        for d in range(0, 2 * n, 2):
+            assert abs(np.sum(wg * xg ** d) - 2.0 / (d + 1)) < 1e-13
+
+
+@pytest.mark.parametrize("case", ["2d", "3d"])
+def test_operators_match_golden(case):
+    g = golden(case)
+    hm, sem = mg.build(case)
+    dim = sem.dim
+    u = [g["in_u"][i] for i in range(dim)]
+    w = [g["in_w"][i] for i in range(dim)]
+    assert close(sem.bm1, g["bm1"]) and close(sem.binvm1, g["binvm1"]) and close(sem.vmult, g["vmult"])
+    assert close(np.stack([sem.axhelm_local(u[i], 0.7, 3.0) for i in range(dim)]), g["axhelm"])
+    assert close(np.stack([sem.gs(u[i]) for i in range(dim)]), g["gs"])
+    assert close(sem.opdiv(u), g["opdiv"])
+    assert close(np.stack(sem.opgradt(g["in_p"])), g["opgradt"])
+    assert close(sem.cdabdtp(g["in_p"]), g["cdabdtp"])
+    assert close(sem.e_diag(), g["ediag"])
+    assert close(np.stack(sem.lns_conv_weak(w, u)), g["conv_dir"])
+    assert close(np.stack(sem.lns_conv_weak(w, u, adjoint=True)), g["conv_adj"])
+    assert abs(sem.compute_cfl(w, 0.01) - float(g["cfl"])) < 1e-12 * float(g["cfl"])
+
+
+@pytest.mark.parametrize("case", ["2d", "3d"])
+def test_operator_identities(case):
+    """Independent facts: symmetry, adjointness, exactness on polynomials, partition of unity."""
+    hm, sem = mg.build(case)
+    dim = sem.dim
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(sem.shape1), rng.standard_normal(sem.shape1)
+    assert abs(np.sum(v * sem.axhelm_local(u, 1.0, 0.3)) - np.sum(u * sem.axhelm_local(v, 1.0, 0.3))) < 1e-11
+    p = rng.standard_normal(sem.shape2)
+    w = [rng.standard_normal(sem.shape1) for _ in range(dim)]
+    lhs = np.sum(p * sem.opdiv(w))
+    rhs = sum(np.sum(w[i] * gi) for i, gi in enumerate(sem.opgradt(p)))
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+    # E symmetric positive semi-definite
+    q = rng.standard_normal(sem.shape2)
+    assert abs(np.sum(q * sem.cdabdtp(p)) - np.sum(p * sem.cdabdtp(q))) < 1e-10
+    assert np.sum(p * sem.cdabdtp(p)) > 0
+    # exact diagonal entries
+    ed = sem.e_diag()
+    e = np.zeros(sem.shape2)
+    idx = (0,) + (1,) * dim
+    e[idx] = 1.0
+    assert abs(sem.cdabdtp(e)[idx] - ed[idx]) < 1e-12 * ed[idx]
+    hd = sem.helm_diag_local(0.5, 2.0)
+    e1 = np.zeros(sem.shape1)
+    idx1 = (1,) + (2,) * dim
+    e1[idx1] = 1.0
+    assert abs(sem.axhelm_local(e1, 0.5, 2.0)[idx1] - hd[idx1]) < 1e-12 * hd[idx1]
+    # gradient of a linear function, Laplacian of a constant, volume
+    g = sem.gradm1(2.0 * sem.X[0] - sem.X[1])
+    assert np.max(np.abs(g[0] - 2.0)) < 1e-11 and np.max(np.abs(g[1] + 1.0)) < 1e-11
+    assert np.max(np.abs(sem.axhelm_local(np.ones(sem.shape1), 1.0, 0.0))) < 1e-11
+    # gather-scatter: multiplicity and idempotence of the averaging
+    assert np.all(sem.mult >= 1) and close(sem.dsavg(sem.dsavg(u)), sem.dsavg(u), 1e-14)
+
+
+def test_vector_space_matches_golden_and_reference_semantics():
+    g = golden("2d")
+    hm, sem = mg.build("2d")
+    a, b = NekDVector(sem, 1), NekDVector(sem, 1)
+    for i in range(2):
+        a.v[i][...] = g["in_u"][i]
+        b.v[i][...] = g["in_w"][i]
+    a.pr[...] = g["in_p"]
+    b.pr[...] = g["in_q"]
+    a.theta[0][...] = g["in_ta"]
+    b.theta[0][...] = g["in_tb"]
+    assert abs(a.dot(b) - float(g["dot"])) < 1e-13 * abs(float(g["dot"]))
+    assert a.get_size() == int(g["size"]) == 3 * sem.lvn + sem.lpn
+    # pressure is NOT part of the inner product (real_vectors.f90:217-224)
+    c = a.copy()
+    c.pr[...] = 0.0
+    assert c.dot(b) == a.dot(b)
+    a.save_rst(b, 1)
+    with pytest.raises(ValueError):
+        a.save_rst(b, 3)                                  # irst == torder is an error (:264-267)
+    a.axpby(0.3, b, -1.7)
+    a.scal(1.0 / 3.0)
+    assert np.array_equal(np.stack(a.v), g["axpby_v"]) and np.array_equal(a.pr, g["axpby_pr"])
+    assert np.array_equal(a.theta[0], g["axpby_theta"])
+    # the history slot received alpha * vec's MAIN field (real_vectors.f90:188-192)
+    expect = (b.v[0] * (-1.7) + 0.3 * b.v[0]) * (1.0 / 3.0)
+    assert np.allclose(a.v_rst[0][0], g["axpby_rst1_v"][0]) and np.allclose(a.v_rst[0][0], expect)
+    a.zero()
+    assert a.nrst == 0 and a.norm() == 0.0
+
+
+def test_rand_is_continuous_masked_and_partition_independent():
+    hm, sem = mg.build("3d")
+    v = NekDVector(sem)
+    v.rand(ifnorm=True, seed=9)
+    assert abs(v.norm() - 1.0) < 1e-13
+    for i in range(3):
+        assert close(sem.dsavg(v.v[i]), v.v[i], 1e-13) and np.all(v.v[i][sem.mask[i] == 0] == 0)
+    # the raw noise of an element depends only on its GLOBAL id: a sub-mesh reproduces it
+    sub = hm.take(np.array([5, 2]))
+    ssem = SEM(sub)
+    raw_full = v.raw_noise(9, hm.elem_gid, 1)
+    raw_sub = NekDVector(ssem).raw_noise(9, sub.elem_gid, 1)
+    assert np.array_equal(raw_sub[0], raw_full[5]) and np.array_equal(raw_sub[1], raw_full[2])
+
+
+def test_matvec_and_eigs_match_golden_2d():
+    from oracle.krylov import eigs
+    from oracle.lns import ExptA, LNSConfig
+    g = golden("2d")
+    hm, sem = mg.build("2d")
+    U = mg.base_flow(sem)
+    assert close(np.stack(U), g["baseflow"])
+    A = ExptA(sem, U, LNSConfig(**mg.lns_cfg()))
+    x = NekDVector(sem)
+    for i in range(2):
+        x.v[i][...] = g["mv_in_v"][i]
+    y = A.matvec(x)
+    assert close(np.stack(y.v), g["mv_out_v"], 1e-10) and close(y.pr, g["mv_out_pr"], 1e-9) and y.nrst == 2
+    y2 = A.matvec(y)
+    assert close(np.stack(y2.v), g["mv2_out_v"], 1e-10)
+    # protocol: without restart history the first steps run at reduced order -> a different answer
+    y.clear_rst_fields()
+    y2b = A.matvec(y)
+    assert not close(np.stack(y2b.v), g["mv2_out_v"], 1e-8)
+    cfg = mg.lns_cfg()
+    cfg.update(tau=0.1, dt=0.02, re=10.0)
+    A2 = ExptA(sem, U, LNSConfig(**cfg))
+    lam, vecs, res, nmv = eigs(A2.matvec, x, nev=2, kdim=10, tol=1e-6, max_restarts=3)
+    assert nmv == int(g["eigs_nmv"]) and np.max(np.abs(lam - g["eigs_lam"]) / np.abs(g["eigs_lam"])) < 1e-10
+
+
+def test_dt_rule_matches_reference_formula():
+    """neklab_nek_setup.f90:195-198: dt = cfl/ctarg ; nsteps = ceiling(tau/dt) ; dt = tau/nsteps."""
+    from oracle.lns import dt_rule
+    dt, ns = dt_rule(1.0, 23.7, 0.5)
+    assert ns == int(np.ceil(1.0 / (0.5 / 23.7))) and abs(dt * ns - 1.0) < 1e-15
+
+
+def test_krylov_on_known_spectrum():
+    """eigs on a diagonal operator with known eigenvalues: leading pair, restart path included."""
+    from oracle.krylov import eigs
+
+    class V:
+        def __init__(self, a):
+            self.a = np.array(a, dtype=float)
+        def copy(self):
+            return V(self.a)
+        def zero(self):
+            self.a[:] = 0
+        def dot(self, o):
+            return float(self.a @ o.a)
+        def norm(self):
+            return float(np.sqrt(self.a @ self.a))
+        def scal(self, s):
+            self.a *= s
+        def axpby(self, al, o, be):
+            self.a = al * o.a + be * self.a
+
+    d = np.concatenate([[1.5, -1.2, 1.1], np.linspace(0.0, 0.9, 57)])
+    lam, vecs, res, nmv = eigs(lambda v: V(d * v.a), V(np.ones(60)), nev=2, kdim=12, tol=1e-10, max_restarts=30)
+    assert np.allclose(np.sort(np.abs(lam))[::-1], [1.5, 1.2], atol=1e-9) and np.all(res < 1e-10)
+    assert abs(abs(vecs[0].a[0]) - 1.0) < 1e-8
