@@ -30,7 +30,9 @@ struct CF3 {
 };
 
 // solver scalar slots (doubles) inside a per-solver device block
-enum { S_RZ = 0, S_PW = 1, S_RZN = 2, S_RN2 = 3, S_DONE = 4, S_ITERS = 5, S_ALPHA = 6, S_BETA = 7, S_T0 = 8, S_T1 = 9, S_N = 16 };
+enum { S_RZ = 0, S_PW = 1, S_RZN = 2, S_RN2 = 3, S_DONE = 4, S_ITERS = 5, S_ALPHA = 6, S_BETA = 7, S_T0 = 8, S_T1 = 9, S_T2 = 10,
+       S_WMEAN = 11, S_ZMEAN = 12, S_RN20 = 13, S_N = 16 };
+constexpr double kFloor2 = 1e-28;   // stop when |r|^2 has dropped by 1e-28: further iterations only divide 0 by 0
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -55,12 +57,34 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *sm) {
     }
 }
 
-// x = 0, r = b (in place), z = pc*r, p = z ; partial sums of (r,z)_ipw and (r,r)_nw
+// three simultaneous block sums; results valid in thread 0
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *sm) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        sm[wid] = a;
+        sm[4 + wid] = b;
+        sm[8 + wid] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = sm[0] + sm[1] + sm[2] + sm[3];
+        b = sm[4] + sm[5] + sm[6] + sm[7];
+        c = sm[8] + sm[9] + sm[10] + sm[11];
+    }
+}
+
+// Projected PCG (P = I - 1 1^T / n on the mean-free subspace, see oracle/lns.py pcg_E): the means of
+// w = A p and of z = M^-1 r ride along as extra partial sums of kernels that exist anyway.
+// x = 0, r = b (in place), z = pc*r ; partial sums of (r,z)_ipw, (r,r)_nw and sum(z)
 template <int NF>
-__global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, F3 p, CF3 pc, const double *ipw,
+__global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3 pc, const double *ipw,
                                                 const double *nw, double *partial) {
-    __shared__ double sm[8];
-    double a = 0.0, b = 0.0;
+    __shared__ double sm[12];
+    double a = 0.0, b = 0.0, c3 = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
 #pragma unroll
@@ -69,15 +93,16 @@ __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, F3 
             const double zv = pc.p[c][i] * rv;
             x.p[c][i] = 0.0;
             z.p[c][i] = zv;
-            p.p[c][i] = zv;
             a += rv * zv * wi;
             b += rv * rv * wn;
+            c3 += zv;
         }
     }
-    block_sum2(a, b, sm);
+    block_sum3(a, b, c3, sm);
     if (threadIdx.x == 0) {
         partial[blockIdx.x] = a;
         partial[NB + blockIdx.x] = b;
+        partial[2 * NB + blockIdx.x] = c3;
     }
 }
 
@@ -89,31 +114,10 @@ __global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p,
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double wi = ipw ? ipw[i] : 1.0;
 #pragma unroll
-        for (int c = 0; c < NF; ++c) a += p.p[c][i] * w.p[c][i] * wi;
-    }
-    block_sum2(a, b, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = a;
-}
-
-// x += alpha p ; r -= alpha w ; z = pc r ; partial (r,z)_ipw and (r,r)_nw
-template <int NF>
-__global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3 x, F3 r, F3 z, CF3 p, CF3 w, CF3 pc,
-                                                  const double *ipw, const double *nw, double *partial) {
-    __shared__ double sm[8];
-    if (s[S_DONE] != 0.0) return;
-    const double alpha = s[S_ALPHA];
-    double a = 0.0, b = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-        const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
-#pragma unroll
         for (int c = 0; c < NF; ++c) {
-            x.p[c][i] += alpha * p.p[c][i];
-            const double rv = r.p[c][i] - alpha * w.p[c][i];
-            const double zv = pc.p[c][i] * rv;
-            r.p[c][i] = rv;
-            z.p[c][i] = zv;
-            a += rv * zv * wi;
-            b += rv * rv * wn;
+            const double wv = w.p[c][i];
+            a += p.p[c][i] * wv * wi;
+            b += wv;
         }
     }
     block_sum2(a, b, sm);
@@ -123,13 +127,43 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
     }
 }
 
+// x += alpha p ; r -= alpha (w - wmean) ; z = pc r ; partial (r,z)_ipw, (r,r)_nw, sum(z)
+template <int NF>
+__global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3 x, F3 r, F3 z, CF3 p, CF3 w, CF3 pc,
+                                                  const double *ipw, const double *nw, double *partial) {
+    __shared__ double sm[12];
+    if (s[S_DONE] != 0.0) return;
+    const double alpha = s[S_ALPHA], wmean = s[S_WMEAN];
+    double a = 0.0, b = 0.0, c3 = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            x.p[c][i] += alpha * p.p[c][i];
+            const double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
+            const double zv = pc.p[c][i] * rv;
+            r.p[c][i] = rv;
+            z.p[c][i] = zv;
+            a += rv * zv * wi;
+            b += rv * rv * wn;
+            c3 += zv;
+        }
+    }
+    block_sum3(a, b, c3, sm);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = a;
+        partial[NB + blockIdx.x] = b;
+        partial[2 * NB + blockIdx.x] = c3;
+    }
+}
+
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_pupdate(const double *s, int64_t n, F3 p, CF3 z) {
     if (s[S_DONE] != 0.0) return;
-    const double beta = s[S_BETA];
+    const double beta = s[S_BETA], zmean = s[S_ZMEAN];
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
 #pragma unroll
-        for (int c = 0; c < NF; ++c) p.p[c][i] = z.p[c][i] + beta * p.p[c][i];
+        for (int c = 0; c < NF; ++c) p.p[c][i] = (z.p[c][i] - zmean) + beta * p.p[c][i];
     }
 }
 
@@ -147,23 +181,32 @@ __global__ __launch_bounds__(NT) void k_cg_final(const double *s, const double *
     }
 }
 
-// scalar logic, one thread. mode 0: after init (T0 = rz, T1 = rn2) ; 1: after pw (T0 = pw) ; 2: after update
-__global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int maxit) {
+// scalar logic, one thread. mode 0: after init (T0 = rz, T1 = rn2, T2 = sum z) ; 1: after pw (T0 = pw, T1 = sum w) ;
+// 2: after update (T0 = rz, T1 = rn2, T2 = sum z).  inv_n = 1/n for the projected solve, 0 otherwise.
+__global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n) {
     if (mode != 0 && s[S_DONE] != 0.0) return;
     if (mode == 0) {
         s[S_RZ] = s[S_T0];
         s[S_RN2] = s[S_T1];
+        s[S_ZMEAN] = s[S_T2] * inv_n;
+        s[S_WMEAN] = 0.0;
+        s[S_BETA] = 0.0;
         s[S_ITERS] = 0.0;
-        s[S_DONE] = ((use_tol && s[S_T1] < tol2) || maxit <= 0) ? 1.0 : 0.0;
+        s[S_DONE] = 0.0;     // the first p-update must run; the convergence test happens in k_cg_post0b
+    } else if (mode == 3) {
+        s[S_RN20] = s[S_RN2];
+        s[S_DONE] = ((use_tol && s[S_RN2] < tol2) || maxit <= 0 || s[S_RN2] <= 0.0) ? 1.0 : 0.0;
     } else if (mode == 1) {
         s[S_PW] = s[S_T0];
+        s[S_WMEAN] = s[S_T1] * inv_n;
         s[S_ALPHA] = s[S_RZ] / s[S_T0];
     } else {
         s[S_BETA] = s[S_T0] / s[S_RZ];
         s[S_RZ] = s[S_T0];
         s[S_RN2] = s[S_T1];
+        s[S_ZMEAN] = s[S_T2] * inv_n;
         s[S_ITERS] += 1.0;
-        if ((use_tol && s[S_T1] < tol2) || s[S_ITERS] >= (double)maxit) s[S_DONE] = 1.0;
+        if ((use_tol && s[S_T1] < tol2) || s[S_ITERS] >= (double)maxit || s[S_T1] <= kFloor2 * s[S_RN20]) s[S_DONE] = 1.0;
     }
 }
 
@@ -313,6 +356,7 @@ struct CGProblem {
     int use_tol, maxit;
     double *s;           // device scalars
     int chunk;
+    double inv_n;        // 1/n for the mean-free projected solve, 0 = no projection
 };
 
 // Generic device-scalar PCG. `apply` computes w = A p (must itself be stream-ordered and may be gated
@@ -326,11 +370,14 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     double *partial = ctx->d_partial;
     double *s = P.s;
     F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
+    (void)x;
     CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf);
-    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, p, pc, P.ipw, P.nw, partial);
-    hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 2, s + S_T0, 0);
-    NLG_TRY(allreduce_sum(ctx, s + S_T0, 2));
-    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 0, P.tol2, P.use_tol, P.maxit);
+    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
+    hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 3, s + S_T0, 0);
+    NLG_TRY(allreduce_sum(ctx, s + S_T0, 3));
+    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 0, P.tol2, P.use_tol, P.maxit, P.inv_n);
+    launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz);   // p = z - zmean
+    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
     int launched = 0;
     int iters = 0;
     while (true) {
@@ -340,14 +387,14 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
             NLG_TRY(apply(s));
             ProfScope ps(ctx, P_CGVEC);
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
-            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 1, s + S_T0, 1);
-            NLG_TRY(allreduce_sum(ctx, s + S_T0, 1));
-            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 1, P.tol2, P.use_tol, P.maxit);
-            launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
-                      pc, P.ipw, P.nw, partial);
             hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 2, s + S_T0, 1);
             NLG_TRY(allreduce_sum(ctx, s + S_T0, 2));
-            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 2, P.tol2, P.use_tol, P.maxit);
+            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 1, P.tol2, P.use_tol, P.maxit, P.inv_n);
+            launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
+                      pc, P.ipw, P.nw, partial);
+            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 3, s + S_T0, 1);
+            NLG_TRY(allreduce_sum(ctx, s + S_T0, 3));
+            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 2, P.tol2, P.use_tol, P.maxit, P.inv_n);
             launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz);
         }
         launched += todo;
@@ -384,6 +431,7 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     P.use_tol = c.fixed_iters_v > 0 ? 0 : 1;
     P.maxit = c.fixed_iters_v > 0 ? c.fixed_iters_v : c.maxit_v;
     P.s = op->d_s;
+    P.inv_n = 0.0;
     P.chunk = std::max(4, std::min(op->last_viters + 1, 32));
     const double nu = 1.0 / c.re;
     auto apply = [&](double *s) -> int {
@@ -422,6 +470,7 @@ int pres_solve(nlg_linop *op, double scale) {
     P.use_tol = c.fixed_iters_p > 0 ? 0 : 1;
     P.maxit = c.fixed_iters_p > 0 ? c.fixed_iters_p : c.maxit_p;
     P.s = op->d_s + S_N;
+    P.inv_n = m->has_outflow ? 0.0 : 1.0 / (double)m->lpn_global;
     P.chunk = std::max(8, std::min(op->last_piters / 4 + 1, 64));
     auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w); };
     int iters = 0;
@@ -438,6 +487,8 @@ int advance(nlg_linop *op) {
     const int dim = m->dim;
     const double dt = op->dt, nu = 1.0 / op->cfg.re;
     op->istep += 1;
+    // gauge: keep the pressure mean-free (see oracle/lns.py advance)
+    NLG_TRY(sem_ortho(m, op->p));
     const int k = std::min(op->istep, op->cfg.torder);
     const double b0 = BDF_B0[k];
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
@@ -489,7 +540,6 @@ int advance(nlg_linop *op) {
     NLG_TRY(sem_opdiv(m, unew, op->pr_r, -(b0 / dt)));
     NLG_TRY(sem_ortho(m, op->pr_r));
     NLG_TRY(pres_solve(op, dt / b0));
-    NLG_TRY(sem_ortho(m, op->pr_x));
     hipLaunchKernelGGL(k_axpy1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->p, (const double *)op->pr_x, 1.0);
     NLG_TRY(sem_opgradt(m, op->pr_x, op->gp));
     NLG_TRY(sem_opbinv(m, op->gp));

@@ -26,6 +26,7 @@ from .vectors import NekDVector
 
 BDF = {1: (1.0, (1.0,)), 2: (1.5, (2.0, -0.5)), 3: (11.0 / 6.0, (3.0, -1.5, 1.0 / 3.0))}
 EXT = {1: (1.0,), 2: (2.0, -1.0), 3: (3.0, -3.0, 1.0)}
+FLOOR2 = 1e-28   # relative floor on |r|^2 below which PCG stops (same constant as csrc/lns.hip kFloor2)
 
 
 @dataclass
@@ -90,10 +91,15 @@ class ExptA:
         rz = sum(np.sum(r[i] * z[i] * s.vmult) for i in range(dim))
         it = 0
         maxit = cfg.fixed_iters_v if cfg.fixed_iters_v > 0 else cfg.maxit_v
+        rn2_0 = None
         while it < maxit:
+            rn2 = sum(np.sum(r[i] * r[i] * wnorm) for i in range(dim))
+            if rn2_0 is None:
+                rn2_0 = rn2
+            if rn2 <= FLOOR2 * rn2_0:          # converged to rounding: further iterations divide 0 by 0
+                break
             if cfg.fixed_iters_v <= 0:
-                rn = math.sqrt(sum(np.sum(r[i] * r[i] * wnorm) for i in range(dim)))
-                if rn < cfg.vtol:
+                if rn2 < cfg.vtol ** 2:
                     break
             w = self.helm_apply(p, h2)
             pw = sum(np.sum(p[i] * w[i] * s.vmult) for i in range(dim))
@@ -112,31 +118,48 @@ class ExptA:
         return x
 
     def pcg_E(self, b, scale):
-        """Solve E x = b; converged when scale*||r||_p < ptol (remaining divergence)."""
+        """Solve E x = b; converged when scale*||r||_p < ptol (remaining divergence).
+
+        Without outflow the pressure is defined up to a constant.  On deformed elements the GL(lx2)
+        quadrature does not reproduce D^T 1 = 0 exactly, so E is only NEARLY singular; iterating on it
+        amplifies the near-null mode (observed: the time stepper blows up).  The solve therefore runs
+        on P E P with P = I - 1 1^T / n restricted to the mean-free subspace (Nek5000 `ortho` applied
+        consistently to operator, preconditioner and right-hand side)."""
         s, cfg = self.sem, self.cfg
         minv = self.ediag_inv
+        proj = not s.has_outflow
+        npts = b.size
+
+        def P(a):
+            return a - np.sum(a) / npts if proj else a
+
         x = np.zeros(s.shape2)
-        r = b.copy()
+        r = P(b.copy())
         z = minv * r
-        p = z.copy()
+        p = P(z)
         rz = float(np.sum(r * z))
         it = 0
         maxit = cfg.fixed_iters_p if cfg.fixed_iters_p > 0 else cfg.maxit_p
+        rn2_0 = None
         while it < maxit:
+            rn2 = float(np.sum(r * r / s.bm2)) / s.volvm2
+            if rn2_0 is None:
+                rn2_0 = rn2
+            if rn2 <= FLOOR2 * rn2_0:
+                break
             if cfg.fixed_iters_p <= 0:
-                rn = scale * math.sqrt(float(np.sum(r * r / s.bm2)) / s.volvm2)
-                if rn < cfg.ptol:
+                if rn2 < (cfg.ptol / scale) ** 2:
                     break
             w = s.cdabdtp(p)
             pw = float(np.sum(p * w))
             alpha = rz / pw
             x += alpha * p
-            r -= alpha * w
+            r -= alpha * P(w)
             z = minv * r
             rz_new = float(np.sum(r * z))
             beta = rz_new / rz
             rz = rz_new
-            p = z + beta * p
+            p = P(z) + beta * p
             it += 1
         self.stats["p_iters"] += it
         return x
@@ -155,6 +178,10 @@ class ExptA:
         s, cfg = self.sem, self.cfg
         dim, dt = s.dim, self.dt
         self.istep += 1
+        # gauge: without outflow the pressure is defined up to a constant; keep it mean-free so that the
+        # constant mode (whose discrete gradient is not exactly zero on deformed elements) can never act
+        # on the velocity -- otherwise it shows up as a spurious eigenvalue mu = 1 of the propagator
+        self.p = s.ortho(self.p)
         k = min(self.istep, cfg.torder)
         b0, bd = BDF[k]
         ab = EXT[k]
@@ -180,7 +207,6 @@ class ExptA:
         rp = -(b0 / dt) * s.opdiv(uh)
         rp = s.ortho(rp)
         dp = self.pcg_E(rp, dt / b0)
-        dp = s.ortho(dp)
         self.p = self.p + dp
         w = s.opbinv(s.opgradt(dp))
         self.u = [uh[i] + (dt / b0) * w[i] for i in range(dim)]

@@ -155,11 +155,24 @@ def test_matvec_and_eigs_match_golden_2d():
     y.clear_rst_fields()
     y2b = A.matvec(y)
     assert not close(np.stack(y2b.v), g["mv2_out_v"], 1e-8)
+
+
+@pytest.mark.slow
+def test_eigs_matches_golden_2d():
+    from oracle.krylov import eigs
+    from oracle.lns import ExptA, LNSConfig
+    g = golden("2d")
+    hm, sem = mg.build("2d")
+    U = mg.base_flow(sem)
+    x = NekDVector(sem)
+    for i in range(2):
+        x.v[i][...] = g["mv_in_v"][i]
     cfg = mg.lns_cfg()
-    cfg.update(tau=0.1, dt=0.02, re=10.0)
+    cfg.update(tau=1.0, dt=0.025, re=10.0)
     A2 = ExptA(sem, U, LNSConfig(**cfg))
-    lam, vecs, res, nmv = eigs(A2.matvec, x, nev=2, kdim=10, tol=1e-6, max_restarts=3)
+    lam, vecs, res, nmv = eigs(A2.matvec, x, nev=2, kdim=12, tol=1e-9, max_restarts=6)
     assert nmv == int(g["eigs_nmv"]) and np.max(np.abs(lam - g["eigs_lam"]) / np.abs(g["eigs_lam"])) < 1e-10
+    assert np.all(res < 1e-9)
 
 
 def test_dt_rule_matches_reference_formula():
