@@ -1,0 +1,107 @@
+!> Demo / test driver: what a neklab `userchk` + LightKrylov would do with the shim, written against the
+!! ABSTRACT interfaces only (class(abstract_vector_rdp), class(abstract_exptA_linop_rdp)):
+!!   bf -> exptA_linop(tau, bf); exptA%init()            (examples/cylinder/stability/direct/1cyl.usr:16-20)
+!!   k steps of Arnoldi with per-vector dot / axpby       (LightKrylov's loop structure, SURVEY.md §3.1)
+!! Input : mesh.bin written by tests/test_gpu_fortran.py (ldim, lx1, nelv, coordinates, labels, masks,
+!!         base flow, start vector).  Output: the Hessenberg matrix on stdout, one entry per line.
+program arnoldi_driver
+   use iso_c_binding
+   use LightKrylov, only: dp, abstract_vector_rdp, abstract_exptA_linop_rdp
+   use neklab_gpu
+   implicit none
+   integer :: ldim, lx1, nelv, lvn, lpn, k, kdim, i, j, u
+   integer(c_int64_t), allocatable :: glo(:)
+   real(dp), allocatable :: x(:), y(:), z(:), m1(:), m2(:), m3(:), bx(:), by(:), bz(:), vx(:), vy(:), vz(:), pr(:)
+   real(dp) :: tau, re, dt, beta
+   real(dp), allocatable :: H(:, :)
+   type(nek_dvector), allocatable :: bf, Xb(:)
+   type(exptA_linop), allocatable :: exptA
+   type(nek_dvector) :: wrk
+
+   open (newunit=u, file='mesh.bin', access='stream', form='unformatted', status='old')
+   read (u) ldim, lx1, nelv, kdim
+   read (u) tau, re, dt
+   lvn = nelv*lx1**ldim
+   lpn = nelv*(lx1 - 2)**ldim
+   allocate (x(lvn), y(lvn), z(lvn), m1(lvn), m2(lvn), m3(lvn), bx(lvn), by(lvn), bz(lvn), vx(lvn), vy(lvn), vz(lvn))
+   allocate (glo(lvn), pr(lpn))
+   z = 0; m3 = 0; bz = 0; vz = 0; pr = 0
+   read (u) x, y
+   if (ldim == 3) read (u) z
+   read (u) glo
+   read (u) m1, m2
+   if (ldim == 3) read (u) m3
+   read (u) bx, by
+   if (ldim == 3) read (u) bz
+   read (u) vx, vy
+   if (ldim == 3) read (u) vz
+   close (u)
+
+   call neklab_gpu_init(0)
+   call neklab_gpu_set_mesh(ldim, lx1, nelv, x, y, z, glo, m1, m2, m3, .false.)
+
+   allocate (bf); call nek2vec_host(bf, bx, by, bz, pr, lvn, lpn, ldim == 3)
+   allocate (exptA)
+   exptA%tau = tau
+   exptA%baseflow = bf                       ! deep copy through defined assignment
+   exptA%cfg%torder = 0                      ! -> defaults, then overrides
+   call set_cfg(exptA)
+   call exptA%init()
+
+   allocate (Xb(kdim + 1))
+   call nek2vec_host(Xb(1), vx, vy, vz, pr, lvn, lpn, ldim == 3)
+   allocate (H(kdim + 1, kdim)); H = 0.0_dp
+   beta = Xb(1)%norm(); call Xb(1)%scal(1.0_dp/beta)
+   do k = 1, kdim
+      call arnoldi_step(exptA, Xb, H, k)
+   end do
+   do j = 1, kdim
+      do i = 1, kdim + 1
+         write (*, '(A,I0,1X,I0,1X,ES24.16)') 'H ', i, j, H(i, j)
+      end do
+   end do
+   ! assignment semantics: a copy must not alias
+   wrk = Xb(1)
+   call wrk%scal(2.0_dp)
+   write (*, '(A,ES24.16)') 'ALIAS ', Xb(1)%norm()
+   write (*, '(A,I0)') 'SIZE ', Xb(1)%get_size()
+   deallocate (Xb, exptA, bf)
+   call neklab_gpu_finalize()
+
+contains
+
+   subroutine set_cfg(A)
+      type(exptA_linop), intent(inout) :: A
+      A%cfg%tau = tau; A%cfg%re = re; A%cfg%cfl_limit = 0.5_dp
+      A%cfg%vtol = 1.0e-13_dp; A%cfg%ptol = 1.0e-13_dp; A%cfg%dt = dt
+      A%cfg%torder = 3; A%cfg%maxit_v = 400; A%cfg%maxit_p = 4000
+      A%cfg%fixed_iters_v = 0; A%cfg%fixed_iters_p = 0; A%cfg%reserved = 0
+   end subroutine
+
+   !> one Arnoldi step written against the abstract API only (CGS2 with k separate dots and axpbys)
+   subroutine arnoldi_step(A, X, Hm, kk)
+      class(abstract_exptA_linop_rdp), intent(inout) :: A
+      class(abstract_vector_rdp), intent(inout) :: X(:)
+      real(dp), intent(inout) :: Hm(:, :)
+      integer, intent(in) :: kk
+      integer :: ii, pass
+      real(dp) :: hij
+      call A%matvec(X(kk), X(kk + 1))
+      do pass = 1, 2
+         block
+            real(dp) :: hh(kk)
+            do ii = 1, kk
+               hh(ii) = X(ii)%dot(X(kk + 1))
+            end do
+            do ii = 1, kk
+               call X(kk + 1)%axpby(-hh(ii), X(ii), 1.0_dp)
+               Hm(ii, kk) = Hm(ii, kk) + hh(ii)
+            end do
+         end block
+      end do
+      hij = X(kk + 1)%norm()
+      Hm(kk + 1, kk) = hij
+      call X(kk + 1)%scal(1.0_dp/hij)
+   end subroutine
+
+end program arnoldi_driver

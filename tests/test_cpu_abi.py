@@ -94,3 +94,20 @@ def test_mesh_generator_properties():
     # ragged / degenerate inputs
     with pytest.raises(AssertionError):
         box_mesh((3,), 5)
+
+
+def test_fortran_shim_compiles_against_the_abstract_types():
+    """amdflang builds the ISO_C_BINDING shim + the LightKrylov abstract-type stub + the demo driver."""
+    import shutil
+    fdir = os.path.join(ROOT, "neklab_amd", "fortran")
+    if not (shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang")):
+        pytest.skip("no Fortran compiler")
+    from neklab_amd import build
+    build.build_library()
+    r = subprocess.run(["make", "-s", "-C", fdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(os.path.join(fdir, "_build", "arnoldi_driver"))
+    # every C symbol the shim binds is declared in the header
+    txt = open(os.path.join(fdir, "neklab_gpu.f90")).read()
+    bound = set(re.findall(r'name="(nlg_[a-z0-9_A-Z]+)"', txt))
+    assert bound and bound <= set(declared_symbols())
