@@ -51,6 +51,13 @@ int nlg_ctx_sync(nlg_ctx *ctx);
 int nlg_comm_unique_id(void *out128);
 int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id128);
 int nlg_ctx_rank(const nlg_ctx *ctx, int *rank, int *nranks);
+/* Host-side planning step of the multi-rank gather-scatter (gslib's gs_setup behind opdssum,
+ * src/vectors/real_vectors.f90:100): given the ascending unique labels of every rank, concatenated rank after
+ * rank (counts[q] each), return for `rank` the labels it shares with every other rank (neigh_counts[q], and the
+ * labels themselves in shared_out, neighbour after neighbour, ascending).  Pure host code, no GPU needed.
+ * Returns the total number of shared entries, or -1 if `capacity` is too small. */
+int64_t nlg_halo_plan(int rank, int nranks, const int64_t *counts, const int64_t *labels_concat,
+                      int64_t *neigh_counts, int64_t *shared_out, int64_t capacity);
 /* Per-kernel-class timing with HIP events recorded on the launch stream (the reference's counterpart
  * is LightKrylov's timer object, src/neklab_analysis.f90:66-67, :98-101).  Classes: "axhelm", "gs",
  * "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops". */

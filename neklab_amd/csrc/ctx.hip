@@ -1,5 +1,6 @@
 // Context, error reporting and the RCCL communicator of libneklab_gpu.
 #include <cstdarg>
+#include <cstdlib>
 
 #include "internal.h"
 
@@ -15,12 +16,12 @@ void set_error(const char *fmt, ...) {
 }
 
 int allreduce_sum(nlg_ctx *ctx, double *d_buf, int count) {
-    if (ctx->nranks > 1) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    if (ctx->comm) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
     return 0;
 }
 
 int allreduce_max(nlg_ctx *ctx, double *d_buf, int count) {
-    if (ctx->nranks > 1) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    if (ctx->comm) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
     return 0;
 }
 
@@ -184,7 +185,9 @@ int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id1
     NLG_HIP(hipSetDevice(ctx->device));
     ctx->rank = rank;
     ctx->nranks = nranks;
-    if (nranks == 1) return 0;
+    // a single rank needs no communicator; NLG_FORCE_COMM=1 creates one anyway so that the RCCL code paths
+    // (all-reduce, all-gather of labels) can be exercised on a one-GPU box
+    if (nranks == 1 && !getenv("NLG_FORCE_COMM")) return 0;
     ncclUniqueId id;
     memcpy(&id, unique_id128, sizeof(id));
     NLG_NCCL(ncclCommInitRank(&ctx->comm, nranks, id, rank));

@@ -1,0 +1,243 @@
+// Multi-GPU part of the gather-scatter: exchange of the dofs shared between element partitions.
+//
+// Reference behaviour being replaced: Nek5000's gslib `gs_op` behind `opdssum`/`dsavg`
+// (/root/reference/src/vectors/real_vectors.f90:100-104) and behind every `dssum` inside `nek_advance`
+// (SURVEY.md §2b); elements are block-distributed over ranks.
+//
+// Protocol (placement-independent, deterministic):
+//   set-up : every rank gathers the sorted unique element-boundary labels of all ranks (ncclAllGather),
+//            intersects them with its own -> per neighbour a list of shared labels in ascending label order
+//            (the same order on both sides), see nlg_halo_plan (pure host code, unit-tested on CPU).
+//   gs_op  : local gather-scatter -> pack one representative value per (neighbour, shared label)
+//            -> grouped ncclSend/ncclRecv with every neighbour -> unpack: one thread per shared label sums
+//            the received contributions in ascending neighbour order and adds the sum to all local copies.
+#include <algorithm>
+#include <numeric>
+
+#include "internal.h"
+
+using namespace nlg;
+
+namespace {
+
+constexpr int NT = 256;
+
+struct F3 {
+    double *p[3];
+};
+
+template <int NF>
+__global__ __launch_bounds__(NT) void k_halo_pack(const int *__restrict__ send_idx, int64_t ntot, F3 f,
+                                                  double *__restrict__ buf) {
+    const int64_t e = blockIdx.x * (int64_t)NT + threadIdx.x;
+    if (e >= ntot) return;
+    const int i = send_idx[e];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) buf[c * ntot + e] = f.p[c][i];
+}
+
+template <int NF>
+__global__ __launch_bounds__(NT) void k_halo_unpack(int64_t nlab, const int *__restrict__ roff,
+                                                    const int *__restrict__ rpos, const int *__restrict__ coff,
+                                                    const int *__restrict__ cidx, int64_t ntot,
+                                                    const double *__restrict__ buf, F3 f) {
+    const int64_t l = blockIdx.x * (int64_t)NT + threadIdx.x;
+    if (l >= nlab) return;
+    double s[NF];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) s[c] = 0.0;
+    for (int q = roff[l]; q < roff[l + 1]; ++q) {
+        const int e = rpos[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) s[c] += buf[c * ntot + e];
+    }
+    for (int q = coff[l]; q < coff[l + 1]; ++q) {
+        const int i = cidx[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) f.p[c][i] += s[c];
+    }
+}
+
+}  // namespace
+
+// Pure host: which labels does `rank` share with every other rank?  labels_concat holds, rank after rank, the
+// ascending unique labels of each rank (counts[q] of them).  On return neigh_counts[q] = number of labels shared
+// with rank q (0 for q == rank) and shared_out holds those labels, neighbour after neighbour in ascending rank
+// order, each list ascending.  Returns the total number of shared entries, or -1 if capacity is too small.
+extern "C" int64_t nlg_halo_plan(int rank, int nranks, const int64_t *counts, const int64_t *labels_concat,
+                                 int64_t *neigh_counts, int64_t *shared_out, int64_t capacity) {
+    std::vector<int64_t> off(nranks + 1, 0);
+    for (int q = 0; q < nranks; ++q) off[q + 1] = off[q] + counts[q];
+    const int64_t *mine = labels_concat + off[rank];
+    const int64_t nm = counts[rank];
+    int64_t tot = 0;
+    for (int q = 0; q < nranks; ++q) {
+        neigh_counts[q] = 0;
+        if (q == rank) continue;
+        const int64_t *oth = labels_concat + off[q];
+        const int64_t no = counts[q];
+        int64_t i = 0, j = 0, cnt = 0;
+        while (i < nm && j < no) {
+            if (mine[i] < oth[j])
+                ++i;
+            else if (mine[i] > oth[j])
+                ++j;
+            else {
+                if (tot + cnt >= capacity) return -1;
+                shared_out[tot + cnt] = mine[i];
+                ++cnt;
+                ++i;
+                ++j;
+            }
+        }
+        neigh_counts[q] = cnt;
+        tot += cnt;
+    }
+    return tot;
+}
+
+namespace nlg {
+
+int halo_setup(nlg_mesh *m, const int64_t *glo) {
+    nlg_ctx *ctx = m->ctx;
+    nlg_halo &h = m->halo;
+    h.active = false;
+    if (!ctx->comm) return 0;
+    hipStream_t st = ctx->stream;
+    const int nr = ctx->nranks, me = ctx->rank;
+    const int n = m->n, dim = m->dim, np1 = m->np1;
+    // ---- local element-boundary labels -> sorted unique, with the list of local copies of each
+    std::vector<int> bidx;
+    bidx.reserve((size_t)m->lvn / 2);
+    for (int64_t e = 0; e < m->E; ++e)
+        for (int p = 0; p < np1; ++p) {
+            const int i = p % n, j = (p / n) % n, k = p / (n * n);
+            const bool onb = i == 0 || i == n - 1 || j == 0 || j == n - 1 || (dim == 3 && (k == 0 || k == n - 1));
+            if (onb) bidx.push_back((int)(e * np1 + p));
+        }
+    std::sort(bidx.begin(), bidx.end(), [glo](int a, int b) { return glo[a] < glo[b] || (glo[a] == glo[b] && a < b); });
+    std::vector<int64_t> ulab;
+    std::vector<int> ubeg;   // begin of each unique label's copies in bidx
+    for (size_t q = 0; q < bidx.size(); ++q)
+        if (q == 0 || glo[bidx[q]] != glo[bidx[q - 1]]) {
+            ulab.push_back(glo[bidx[q]]);
+            ubeg.push_back((int)q);
+        }
+    ubeg.push_back((int)bidx.size());
+    // ---- gather counts and labels of all ranks (device buffers, RCCL)
+    int64_t *d_cnt = nullptr;
+    NLG_HIP(hipMalloc(&d_cnt, sizeof(int64_t) * (nr + 1)));
+    int64_t mycnt = (int64_t)ulab.size();
+    NLG_HIP(hipMemcpy(d_cnt + nr, &mycnt, sizeof(int64_t), hipMemcpyHostToDevice));
+    NLG_NCCL(ncclAllGather(d_cnt + nr, d_cnt, 1, ncclInt64, ctx->comm, st));
+    std::vector<int64_t> counts(nr);
+    NLG_HIP(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int64_t) * nr, hipMemcpyDeviceToHost, st));
+    NLG_HIP(hipStreamSynchronize(st));
+    const int64_t maxc = *std::max_element(counts.begin(), counts.end());
+    int64_t *d_lab = nullptr;
+    NLG_HIP(hipMalloc(&d_lab, sizeof(int64_t) * (size_t)maxc * (nr + 1)));
+    NLG_HIP(hipMemsetAsync(d_lab, 0xff, sizeof(int64_t) * (size_t)maxc * (nr + 1), st));
+    NLG_HIP(hipMemcpyAsync(d_lab + (size_t)maxc * nr, ulab.data(), sizeof(int64_t) * ulab.size(), hipMemcpyHostToDevice, st));
+    NLG_NCCL(ncclAllGather(d_lab + (size_t)maxc * nr, d_lab, maxc, ncclInt64, ctx->comm, st));
+    std::vector<int64_t> padded((size_t)maxc * nr), concat;
+    NLG_HIP(hipMemcpyAsync(padded.data(), d_lab, sizeof(int64_t) * padded.size(), hipMemcpyDeviceToHost, st));
+    NLG_HIP(hipStreamSynchronize(st));
+    hipFree(d_cnt);
+    hipFree(d_lab);
+    for (int q = 0; q < nr; ++q) concat.insert(concat.end(), padded.begin() + (size_t)q * maxc, padded.begin() + (size_t)q * maxc + counts[q]);
+    // ---- plan
+    std::vector<int64_t> ncnt(nr), shared((size_t)mycnt * std::max(nr - 1, 1) + 1);
+    const int64_t tot = nlg_halo_plan(me, nr, counts.data(), concat.data(), ncnt.data(), shared.data(), (int64_t)shared.size());
+    NLG_CHECK(tot >= 0, "halo_setup: plan capacity exceeded");
+    h.neigh.clear();
+    h.noff.clear();
+    h.ncnt.clear();
+    int64_t off = 0;
+    for (int q = 0; q < nr; ++q)
+        if (ncnt[q] > 0) {
+            h.neigh.push_back(q);
+            h.noff.push_back(off);
+            h.ncnt.push_back(ncnt[q]);
+            off += ncnt[q];
+        }
+    h.ntot = tot;
+    if (tot == 0) return 0;
+    // ---- index lists
+    std::vector<int> send_idx((size_t)tot);
+    // label -> position in ulab
+    auto find_lab = [&](int64_t lab) { return (int)(std::lower_bound(ulab.begin(), ulab.end(), lab) - ulab.begin()); };
+    std::vector<std::vector<int>> rpos_of(ulab.size());   // per unique label: entry positions, ascending neighbour
+    for (int64_t e = 0; e < tot; ++e) {
+        const int u = find_lab(shared[e]);
+        send_idx[e] = bidx[ubeg[u]];
+        rpos_of[u].push_back((int)e);
+    }
+    std::vector<int> roff{0}, rpos, coff{0}, cidx;
+    int64_t nlab = 0;
+    for (size_t u = 0; u < ulab.size(); ++u) {
+        if (rpos_of[u].empty()) continue;
+        ++nlab;
+        rpos.insert(rpos.end(), rpos_of[u].begin(), rpos_of[u].end());
+        roff.push_back((int)rpos.size());
+        for (int q = ubeg[u]; q < ubeg[u + 1]; ++q) cidx.push_back(bidx[q]);
+        coff.push_back((int)cidx.size());
+    }
+    h.nlab = nlab;
+    auto up = [&](const std::vector<int> &v, int **d) -> int {
+        NLG_HIP(hipMalloc(d, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        NLG_HIP(hipMemcpy(*d, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    NLG_TRY(up(send_idx, &h.d_send_idx));
+    NLG_TRY(up(roff, &h.d_roff));
+    NLG_TRY(up(rpos, &h.d_rpos));
+    NLG_TRY(up(coff, &h.d_coff));
+    NLG_TRY(up(cidx, &h.d_cidx));
+    NLG_HIP(hipMalloc(&h.d_send, sizeof(double) * (size_t)tot * 3));
+    NLG_HIP(hipMalloc(&h.d_recv, sizeof(double) * (size_t)tot * 3));
+    h.active = true;
+    return 0;
+}
+
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf) {
+    nlg_halo &h = m->halo;
+    if (!h.active) return 0;
+    nlg_ctx *ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
+    const int g1 = (int)((h.ntot + NT - 1) / NT);
+    if (nf == 1)
+        hipLaunchKernelGGL(k_halo_pack<1>, dim3(g1), dim3(NT), 0, st, h.d_send_idx, h.ntot, f, h.d_send);
+    else if (nf == 2)
+        hipLaunchKernelGGL(k_halo_pack<2>, dim3(g1), dim3(NT), 0, st, h.d_send_idx, h.ntot, f, h.d_send);
+    else
+        hipLaunchKernelGGL(k_halo_pack<3>, dim3(g1), dim3(NT), 0, st, h.d_send_idx, h.ntot, f, h.d_send);
+    NLG_NCCL(ncclGroupStart());
+    for (size_t q = 0; q < h.neigh.size(); ++q)
+        for (int c = 0; c < nf; ++c) {
+            NLG_NCCL(ncclSend(h.d_send + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
+            NLG_NCCL(ncclRecv(h.d_recv + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
+        }
+    NLG_NCCL(ncclGroupEnd());
+    const int g2 = (int)((h.nlab + NT - 1) / NT);
+    if (nf == 1)
+        hipLaunchKernelGGL(k_halo_unpack<1>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.ntot, h.d_recv, f);
+    else if (nf == 2)
+        hipLaunchKernelGGL(k_halo_unpack<2>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.ntot, h.d_recv, f);
+    else
+        hipLaunchKernelGGL(k_halo_unpack<3>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.ntot, h.d_recv, f);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+void halo_free(nlg_mesh *m) {
+    nlg_halo &h = m->halo;
+    int *ip[] = {h.d_send_idx, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx};
+    for (int *p : ip)
+        if (p) hipFree(p);
+    if (h.d_send) hipFree(h.d_send);
+    if (h.d_recv) hipFree(h.d_recv);
+    h = nlg_halo();
+}
+
+}  // namespace nlg

@@ -100,7 +100,19 @@ struct nlg_gs {
     int *d_indices = nullptr;   // [nshared] local dof index
 };
 
+struct nlg_halo {
+    bool active = false;
+    std::vector<int> neigh;          // neighbour ranks (ascending)
+    std::vector<int64_t> noff, ncnt; // offset / count of each neighbour's shared labels in the packed buffers
+    int64_t ntot = 0, nlab = 0;
+    int *d_send_idx = nullptr;       // [ntot] representative local dof per (neighbour, label)
+    int *d_roff = nullptr, *d_rpos = nullptr;   // per distinct shared label: positions in the recv buffer
+    int *d_coff = nullptr, *d_cidx = nullptr;   // per distinct shared label: all local copies
+    double *d_send = nullptr, *d_recv = nullptr;
+};
+
 struct nlg_mesh {
+    nlg_halo halo;
     nlg_ctx *ctx = nullptr;
     int dim = 3, n = 8, n2 = 6, nd = 12;
     int64_t E = 0;
@@ -188,6 +200,11 @@ int allreduce_max(nlg_ctx *ctx, double *d_buf, int count);
 int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc);
 int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign);
 int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
+
+// ---- halo.hip ----
+int halo_setup(nlg_mesh *m, const int64_t *glo_num);
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf);
+void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
 int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place QQ^T

@@ -952,22 +952,24 @@ double *sem_scratch2(nlg_mesh *m, int i) {
 }
 
 int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
-    if (m->gs.ngroups == 0) return 0;
+    if (m->gs.ngroups == 0 && !m->halo.active) return 0;
     ProfScope ps(m->ctx, P_GS);
-    F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
-    const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-    if (nf == 1)
-        hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
-    else if (nf == 2)
-        hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
-    else if (nf == 3)
-        hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
-    else {
+    if (nf < 1 || nf > 3) {
         set_error("sem_gs: nf=%d unsupported", nf);
         return 1;
     }
-    NLG_HIP(hipGetLastError());
-    return 0;
+    if (m->gs.ngroups > 0) {
+        F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
+        const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
+        if (nf == 1)
+            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+        else if (nf == 2)
+            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+        else
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+        NLG_HIP(hipGetLastError());
+    }
+    return halo_exchange(m, fields, nf);   // no-op on a single rank
 }
 
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2) {
@@ -1387,6 +1389,7 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         NLG_HIP(hipMemcpy(m->gs.d_offsets, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
         if (!idx.empty()) NLG_HIP(hipMemcpy(m->gs.d_indices, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
     }
+    NLG_TRY(halo_setup(m, d->glo_num));
     // ---- multiplicity, assembled inverse mass, fused opbinv weights
     {
         hipLaunchKernelGGL(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, 1.0, m->lvn);
@@ -1428,6 +1431,15 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         for (int64_t q = 0; q < m->lpn; ++q) v += h[q];
         m->volvm2 = v;
         m->lpn_global = m->lpn;
+        if (ctx->comm) {   // global volumes and pressure dof count
+            double hv[3] = {m->volvm1, m->volvm2, (double)m->lpn}, *dv = ctx->d_scalars + 4010;
+            NLG_HIP(hipMemcpyAsync(dv, hv, sizeof(hv), hipMemcpyHostToDevice, s));
+            NLG_TRY(allreduce_sum(ctx, dv, 3));
+            NLG_TRY(scalars_to_host(ctx, 4010, 3, hv));
+            m->volvm1 = hv[0];
+            m->volvm2 = hv[1];
+            m->lpn_global = (int64_t)(hv[2] + 0.5);
+        }
     }
 
     // ---- names for read-back
@@ -1481,6 +1493,7 @@ int nlg_mesh_destroy(nlg_mesh *m) {
     for (int q = 0; q < 6; ++q)
         if (m->d_G[q]) hipFree(m->d_G[q]);
     if (m->d_lglel) hipFree(m->d_lglel);
+    halo_free(m);
     if (m->gs.d_offsets) hipFree(m->gs.d_offsets);
     if (m->gs.d_indices) hipFree(m->gs.d_indices);
     for (double *p : m->scratch1) hipFree(p);

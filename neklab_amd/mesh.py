@@ -91,12 +91,16 @@ class BoxMesh:
 
 def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
              periodic: Sequence[bool] | None = None, deform: float = 0.05,
-             origin: Sequence[float] | None = None, outflow_xmax: bool = False) -> BoxMesh:
+             origin: Sequence[float] | None = None, outflow_xmax: bool = False,
+             last_range: Sequence[int] | None = None) -> BoxMesh:
     """Structured, smoothly deformed box of `prod(nel)` elements with `n` GLL points/direction.
 
     Elements are numbered lexicographically (x fastest) so that contiguous element blocks are
     spatially compact slabs.  Non-periodic boundaries are no-slip walls (all velocity masks 0)
     except `outflow_xmax`, which leaves the x-max face natural (Nek 'O').
+    `last_range=(k0, k1)` generates only the element layers k0 <= k < k1 of the LAST direction, with the
+    labels, element ids, coordinates and deformation of the full box: the element block one rank owns
+    under the contiguous block distribution, without ever building the global mesh.
     """
     dim = len(nel)
     assert dim in (2, 3)
@@ -105,14 +109,17 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
     periodic = tuple(bool(p) for p in (periodic if periodic is not None else [False] * dim))
     origin = tuple(float(o) for o in (origin if origin is not None else [0.0] * dim))
     xi = gll_points(n)
-    E = int(np.prod(nel))
     N = n - 1
+    k0, k1 = (0, nel[-1]) if last_range is None else (int(last_range[0]), int(last_range[1]))
+    assert 0 <= k0 < k1 <= nel[-1]
+    nloc = tuple(nel[:-1]) + (k1 - k0,)
+    E = int(np.prod(nloc))
 
     # 1-D global grid indices and undeformed coordinates per direction
     gidx, coord, ngrid = [], [], []
     for d in range(dim):
         h = lengths[d] / nel[d]
-        e = np.arange(nel[d])
+        e = np.arange(nel[d]) if d < dim - 1 else np.arange(k0, k1)
         gi = e[:, None] * N + np.arange(n)[None, :]              # (nel_d, n)
         c = origin[d] + h * (e[:, None] + 0.5 * (xi[None, :] + 1.0))
         ng = nel[d] * N + (0 if periodic[d] else 1)
@@ -124,7 +131,7 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
 
     # element lexicographic numbering, x fastest; point numbering ix fastest
     if dim == 2:
-        ey, ex = np.meshgrid(np.arange(nel[1]), np.arange(nel[0]), indexing="ij")
+        ey, ex = np.meshgrid(np.arange(nloc[1]), np.arange(nloc[0]), indexing="ij")
         ex, ey = ex.ravel(), ey.ravel()
         X = np.broadcast_to(coord[0][ex][:, None, :], (E, n, n))
         Y = np.broadcast_to(coord[1][ey][:, :, None], (E, n, n))
@@ -134,7 +141,7 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
         coords0 = [np.array(X, dtype=np.float64), np.array(Y, dtype=np.float64)]
         G = [GI, GJ]
     else:
-        ez, ey, ex = np.meshgrid(np.arange(nel[2]), np.arange(nel[1]), np.arange(nel[0]), indexing="ij")
+        ez, ey, ex = np.meshgrid(np.arange(nloc[2]), np.arange(nloc[1]), np.arange(nloc[0]), indexing="ij")
         ex, ey, ez = ex.ravel(), ey.ravel(), ez.ravel()
         X = np.broadcast_to(coord[0][ex][:, None, None, :], (E, n, n, n))
         Y = np.broadcast_to(coord[1][ey][:, None, :, None], (E, n, n, n))
@@ -177,7 +184,7 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
         glo_num=np.ascontiguousarray(glo.reshape(E, -1)),
         mask=[m.copy() for _ in range(dim)], tmask=m.copy(),
         periodic=periodic, lengths=lengths, has_outflow=bool(outflow_xmax),
-        elem_gid=np.arange(E, dtype=np.int64),
+        elem_gid=np.arange(E, dtype=np.int64) + k0 * int(np.prod(nel[:-1])),
     )
     return mesh
 
