@@ -164,7 +164,7 @@ typedef struct nlg_exptA_config {
     int maxit_p;
     int fixed_iters_v; /* > 0: run exactly this many PCG iterations (parity / benchmarking mode)      */
     int fixed_iters_p;
-    int reserved;
+    int pprecond;      /* pressure preconditioner: 0 = two-level (element FDM + coarse V-cycle), 1 = Jacobi   */
 } nlg_exptA_config;
 
 int nlg_exptA_config_default(nlg_exptA_config *cfg);

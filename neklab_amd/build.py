@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libneklab_gpu.so")
-SOURCES = ["ctx.hip", "vec.hip", "sem.hip", "halo.hip", "lns.hip", "krylov.hip", "dense_eig.cpp"]
+SOURCES = ["ctx.hip", "vec.hip", "sem.hip", "halo.hip", "pprec.hip", "lns.hip", "krylov.hip", "dense_eig.cpp"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "neklab_gpu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

@@ -56,7 +56,7 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 }  // namespace nlg
 
 // kernel classes that can be timed with HIP events on the launch stream (bench.py roofline leg)
-enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_COUNT };
+enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_PPREC, P_COUNT };
 
 struct nlg_prof_slot {
     std::vector<hipEvent_t> ev;   // pairs (begin, end)
@@ -111,7 +111,20 @@ struct nlg_halo {
     double *d_send = nullptr, *d_recv = nullptr;
 };
 
+// two-level preconditioner of the pressure operator (pprec.hip)
+struct nlg_pprec {
+    bool ready = false;
+    int na = 0;                                  // aggregates
+    double *d_S = nullptr, *d_invden = nullptr;  // FDM: [E][3][n2*n2] eigenvector matrices, [E][n2^dim] 1/(sum of eigenvalues)
+    int *d_rp = nullptr, *d_ci = nullptr;        // A_c in CSR
+    double *d_av = nullptr, *d_dinv = nullptr;
+    int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;
+    double *d_Ainv = nullptr;                    // dense inverse on the aggregates
+    double *d_rc = nullptr, *d_x = nullptr, *d_t = nullptr, *d_ra = nullptr, *d_xa = nullptr;
+};
+
 struct nlg_mesh {
+    nlg_pprec pprec;
     nlg_halo halo;
     nlg_ctx *ctx = nullptr;
     int dim = 3, n = 8, n2 = 6, nd = 12;
@@ -200,6 +213,11 @@ int allreduce_max(nlg_ctx *ctx, double *d_buf, int count);
 int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc);
 int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign);
 int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
+
+// ---- pprec.hip ----
+int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d);
+int pprec_apply(nlg_mesh *m, const double *flag, const double *r, double *z);
+void pprec_free(nlg_mesh *m);
 
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);

@@ -12,6 +12,7 @@
 // host only reads the flag once per chunk of launched iterations, and every kernel of an iteration
 // returns immediately once the flag is set, so the result is identical to stopping at convergence.
 #include <cmath>
+#include <functional>
 
 #include "internal.h"
 
@@ -90,12 +91,14 @@ __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             const double rv = r.p[c][i];
-            const double zv = pc.p[c][i] * rv;
             x.p[c][i] = 0.0;
-            z.p[c][i] = zv;
-            a += rv * zv * wi;
             b += rv * rv * wn;
-            c3 += zv;
+            if (pc.p[c]) {      // pointwise (Jacobi) preconditioner; otherwise z comes from an operator
+                const double zv = pc.p[c][i] * rv;
+                z.p[c][i] = zv;
+                a += rv * zv * wi;
+                c3 += zv;
+            }
         }
     }
     block_sum3(a, b, c3, sm);
@@ -141,12 +144,14 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
         for (int c = 0; c < NF; ++c) {
             x.p[c][i] += alpha * p.p[c][i];
             const double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
-            const double zv = pc.p[c][i] * rv;
             r.p[c][i] = rv;
-            z.p[c][i] = zv;
-            a += rv * zv * wi;
             b += rv * rv * wn;
-            c3 += zv;
+            if (pc.p[c]) {
+                const double zv = pc.p[c][i] * rv;
+                z.p[c][i] = zv;
+                a += rv * zv * wi;
+                c3 += zv;
+            }
         }
     }
     block_sum3(a, b, c3, sm);
@@ -154,6 +159,29 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
         partial[blockIdx.x] = a;
         partial[NB + blockIdx.x] = b;
         partial[2 * NB + blockIdx.x] = c3;
+    }
+}
+
+// partial sums of (r,z)_ipw and sum(z) when z was produced by a preconditioning operator
+template <int NF>
+__global__ __launch_bounds__(NT) void k_cg_rz(const double *s, int gate, int64_t n, CF3 r, CF3 z, const double *ipw,
+                                              double *partial) {
+    __shared__ double sm[8];
+    if (gate && s[S_DONE] != 0.0) return;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double wi = ipw ? ipw[i] : 1.0;
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double zv = z.p[c][i];
+            a += r.p[c][i] * zv * wi;
+            b += zv;
+        }
+    }
+    block_sum2(a, b, sm);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = a;
+        partial[2 * NB + blockIdx.x] = b;
     }
 }
 
@@ -357,6 +385,7 @@ struct CGProblem {
     double *s;           // device scalars
     int chunk;
     double inv_n;        // 1/n for the mean-free projected solve, 0 = no projection
+    std::function<int(const double *flag, const double *r, double *z)> precond;   // non-pointwise M^-1 (nf = 1)
 };
 
 // Generic device-scalar PCG. `apply` computes w = A p (must itself be stream-ordered and may be gated
@@ -372,7 +401,12 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
     (void)x;
     CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf);
+    CF3 cr = cf3(P.r, nf);
     launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
+    if (P.precond) {
+        NLG_TRY(P.precond(nullptr, P.r[0], P.z[0]));
+        launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, partial);
+    }
     hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 3, s + S_T0, 0);
     NLG_TRY(allreduce_sum(ctx, s + S_T0, 3));
     hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 0, P.tol2, P.use_tol, P.maxit, P.inv_n);
@@ -385,13 +419,18 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         if (launched + todo > P.maxit) todo = P.maxit - launched;
         for (int it = 0; it < todo; ++it) {
             NLG_TRY(apply(s));
-            ProfScope ps(ctx, P_CGVEC);
+            if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
             hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 2, s + S_T0, 1);
             NLG_TRY(allreduce_sum(ctx, s + S_T0, 2));
             hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 1, P.tol2, P.use_tol, P.maxit, P.inv_n);
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
                       pc, P.ipw, P.nw, partial);
+            if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
+            if (P.precond) {
+                NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0]));
+                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, partial);
+            }
             hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 3, s + S_T0, 1);
             NLG_TRY(allreduce_sum(ctx, s + S_T0, 3));
             hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 2, P.tol2, P.use_tol, P.maxit, P.inv_n);
@@ -471,6 +510,11 @@ int pres_solve(nlg_linop *op, double scale) {
     P.maxit = c.fixed_iters_p > 0 ? c.fixed_iters_p : c.maxit_p;
     P.s = op->d_s + S_N;
     P.inv_n = m->has_outflow ? 0.0 : 1.0 / (double)m->lpn_global;
+    double *nopc[1] = {nullptr};
+    if (c.pprecond == 0) {   // two-level FDM + coarse V-cycle (pprec.hip); 1 = Jacobi on diag(E), as in the oracle
+        P.pc = nopc;
+        P.precond = [m](const double *flag, const double *rr, double *zz) -> int { return pprec_apply(m, flag, rr, zz); };
+    }
     P.chunk = std::max(8, std::min(op->last_piters / 4 + 1, 64));
     auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w); };
     int iters = 0;

@@ -1,0 +1,530 @@
+// Two-level preconditioner of the consistent Poisson operator E = D (mask B^-1 QQ^T) D^T (gfx950).
+//
+// Role in the reference: `preconditioner = semg_xxt` of the pressure solve inside nek_advance
+// (/root/reference/examples/cylinder/stability/direct/1cyl.par:21); Nek5000's implementation is not in the
+// reference tree.  This is a restatement of the published idea (Fischer 1997; Lottes & Fischer 2005) in its
+// simplest robust form, chosen from a numpy prototype (scripts/precond_proto.py: Jacobi 680 iterations,
+// element-wise FDM 192, FDM + exact piecewise-constant coarse grid 81, FDM + the V-cycle below 110, all at
+// E = 512, independent of E for the two-level variants):
+//   M^-1 r = sum_e R_e^T Etilde_e^-1 R_e r                     (element-wise fast diagonalisation, additive)
+//          + R_0^T  V(A_c) R_0 r                               (piecewise-constant-per-element coarse space)
+//   Etilde_e : E restricted to element e with the element replaced by a box of its mean edge lengths and the
+//              neighbours' mass lumped on shared faces: separable, inverted exactly by 1-D generalised
+//              eigen-decompositions (n2 x n2 per direction).
+//   A_c = R_0 E R_0^T : sparse E x E (27-point on structured meshes), assembled exactly on the host.
+//   V(A_c)  : one symmetric V-cycle: damped-Jacobi sweep, exact solve on greedy aggregates of elements (dense
+//             inverse), damped-Jacobi sweep.  When E is small the aggregates are the elements (exact solve).
+// M is a fixed symmetric positive (semi-)definite operator, so plain PCG stays valid.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <unordered_map>
+
+#include "internal.h"
+
+using namespace nlg;
+
+namespace {
+
+constexpr int NT = 256;
+
+template <int S0, int S1, int S2, int AX, int NOUT, bool TRANS>
+__device__ __forceinline__ void contract(const double *__restrict__ in, double *__restrict__ out,
+                                         const double *__restrict__ M, int tid, int nth) {
+    // out[.., o, ..] = sum_l Mop[o][l] in[.., l, ..] ; Mop = M (NOUT x NIN row-major) or its transpose
+    constexpr int NIN = AX == 0 ? S0 : (AX == 1 ? S1 : S2);
+    constexpr int O0 = AX == 0 ? NOUT : S0, O1 = AX == 1 ? NOUT : S1, O2 = AX == 2 ? NOUT : S2;
+    for (int p = tid; p < O0 * O1 * O2; p += nth) {
+        const int a = p % O0, b = (p / O0) % O1, c = p / (O0 * O1);
+        const int o = AX == 0 ? a : (AX == 1 ? b : c);
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < NIN; ++l) {
+            const int q = AX == 0 ? (l + S0 * (b + S1 * c)) : (AX == 1 ? (a + S0 * (l + S1 * c)) : (a + S0 * (b + S1 * l)));
+            s += (TRANS ? M[l * NOUT + o] : M[o * NIN + l]) * in[q];
+        }
+        out[p] = s;
+    }
+}
+
+// z_e = (Sz x Sy x Sx) [ invden o ((Sz x Sy x Sx)^T r_e) ] + xc[e]      (S stored row-major [point][mode])
+template <int N2, int DIM>
+__global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
+                                            const double *__restrict__ invden, const double *__restrict__ r,
+                                            const double *__restrict__ xc, double *__restrict__ z) {
+    constexpr int NP = DIM == 3 ? N2 * N2 * N2 : N2 * N2;
+    constexpr int NZ = DIM == 3 ? N2 : 1;
+    __shared__ double sS[3][N2 * N2];
+    __shared__ double sA[NP], sB[NP];
+    if (flag && flag[0] != 0.0) return;
+    const int tid = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    for (int q = tid; q < DIM * N2 * N2; q += NT) sS[q / (N2 * N2)][q % (N2 * N2)] = S[e * (3 * N2 * N2) + q];
+    for (int q = tid; q < NP; q += NT) sA[q] = r[e * NP + q];
+    __syncthreads();
+    // forward: modes = S^T points
+    contract<N2, N2, NZ, 0, N2, true>(sA, sB, sS[0], tid, NT);
+    __syncthreads();
+    contract<N2, N2, NZ, 1, N2, true>(sB, sA, sS[1], tid, NT);
+    __syncthreads();
+    if constexpr (DIM == 3) {
+        contract<N2, N2, NZ, 2, N2, true>(sA, sB, sS[2], tid, NT);
+        __syncthreads();
+        for (int q = tid; q < NP; q += NT) sB[q] *= invden[e * NP + q];
+        __syncthreads();
+        contract<N2, N2, NZ, 2, N2, false>(sB, sA, sS[2], tid, NT);
+        __syncthreads();
+    } else {
+        for (int q = tid; q < NP; q += NT) sA[q] *= invden[e * NP + q];
+        __syncthreads();
+    }
+    contract<N2, N2, NZ, 1, N2, false>(sA, sB, sS[1], tid, NT);
+    __syncthreads();
+    contract<N2, N2, NZ, 0, N2, false>(sB, sA, sS[0], tid, NT);
+    __syncthreads();
+    const double c = xc ? xc[e] : 0.0;
+    for (int q = tid; q < NP; q += NT) z[e * NP + q] = sA[q] + c;
+}
+
+// rc[e] = sum of r over the pressure points of element e   (R_0 r)
+__global__ __launch_bounds__(NT) void k_restrict0(const double *__restrict__ flag, int64_t E, int np2,
+                                                  const double *__restrict__ r, double *__restrict__ rc) {
+    if (flag && flag[0] != 0.0) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 4 + wid;
+    if (e >= E) return;
+    double a = 0.0;
+    for (int q = lane; q < np2; q += 64) a += r[e * np2 + q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if (lane == 0) rc[e] = a;
+}
+
+// x = om * dinv * b
+__global__ void k_jac0(const double *flag, int64_t n, const double *dinv, const double *b, double om, double *x) {
+    if (flag && flag[0] != 0.0) return;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] = om * dinv[i] * b[i];
+}
+
+// mode 0: out = b - A x ; mode 1: x_new = x + om dinv (b - A x) written to out
+__global__ void k_spmv(const double *flag, int64_t n, const int *__restrict__ rp, const int *__restrict__ ci,
+                       const double *__restrict__ av, const double *__restrict__ x, const double *__restrict__ b,
+                       const double *__restrict__ dinv, double om, int mode, double *__restrict__ out) {
+    if (flag && flag[0] != 0.0) return;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int q = rp[i]; q < rp[i + 1]; ++q) s += av[q] * x[ci[q]];
+    const double res = b[i] - s;
+    out[i] = mode == 0 ? res : x[i] + om * dinv[i] * res;
+}
+
+// ra[a] = sum of rr over the members of aggregate a
+__global__ void k_agg_restrict(const double *flag, int na, const int *__restrict__ ap, const int *__restrict__ am,
+                               const double *__restrict__ rr, double *__restrict__ ra) {
+    if (flag && flag[0] != 0.0) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= na) return;
+    double s = 0.0;
+    for (int q = ap[a]; q < ap[a + 1]; ++q) s += rr[am[q]];
+    ra[a] = s;
+}
+
+// xa = Ainv ra (dense, row-major), one wave per row
+__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, const double *__restrict__ Ainv,
+                                                   const double *__restrict__ ra, double *__restrict__ xa) {
+    if (flag && flag[0] != 0.0) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= na) return;
+    double s = 0.0;
+    for (int j = lane; j < na; j += 64) s += Ainv[(size_t)row * na + j] * ra[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) xa[row] = s;
+}
+
+__global__ void k_prolong_add(const double *flag, int64_t n, const int *__restrict__ agg, const double *__restrict__ xa,
+                              double *__restrict__ x) {
+    if (flag && flag[0] != 0.0) return;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] += xa[agg[i]];
+}
+
+// ---- host helpers -------------------------------------------------------------------------------------
+// symmetric eigen-decomposition by cyclic Jacobi rotations (n <= 16): A = V diag(w) V^T
+void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &V, std::vector<double> &w) {
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq;
+                    A[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk;
+                    A[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                    V[(size_t)k * n + p] = c * vkp - s * vkq;
+                    V[(size_t)k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
+}
+
+// generalised symmetric problem A s = lam B s, B SPD: S^T B S = I, S^T A S = diag(lam). S row-major [point][mode].
+int gen_eig(int n, const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &S,
+            std::vector<double> &lam) {
+    std::vector<double> L((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double d = B[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return 1;
+        L[(size_t)j * n + j] = std::sqrt(d);
+        for (int i = j + 1; i < n; ++i) {
+            double s = B[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / L[(size_t)j * n + j];
+        }
+    }
+    // Linv (lower)
+    std::vector<double> Li((size_t)n * n, 0.0);
+    for (int c = 0; c < n; ++c) {
+        Li[(size_t)c * n + c] = 1.0 / L[(size_t)c * n + c];
+        for (int i = c + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = c; k < i; ++k) s += L[(size_t)i * n + k] * Li[(size_t)k * n + c];
+            Li[(size_t)i * n + c] = -s / L[(size_t)i * n + i];
+        }
+    }
+    std::vector<double> T((size_t)n * n, 0.0), Cm((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += Li[(size_t)i * n + k] * A[(size_t)k * n + j];
+            T[(size_t)i * n + j] = s;
+        }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += T[(size_t)i * n + k] * Li[(size_t)j * n + k];
+            Cm[(size_t)i * n + j] = s;
+        }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) Cm[(size_t)i * n + j] = Cm[(size_t)j * n + i] = 0.5 * (Cm[(size_t)i * n + j] + Cm[(size_t)j * n + i]);
+    std::vector<double> V;
+    jacobi_eig(n, Cm, V, lam);
+    S.assign((size_t)n * n, 0.0);   // S = Li^T V
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += Li[(size_t)k * n + i] * V[(size_t)k * n + j];
+            S[(size_t)i * n + j] = s;
+        }
+    return 0;
+}
+
+// dense SPD inverse by Cholesky (in place, row-major); returns non-zero if not positive definite
+int spd_inverse(int n, std::vector<double> &A) {
+    std::vector<double> L((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return 1;
+        L[(size_t)j * n + j] = std::sqrt(d);
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / L[(size_t)j * n + j];
+        }
+    }
+    std::vector<double> Li((size_t)n * n, 0.0);
+    for (int c = 0; c < n; ++c) {
+        Li[(size_t)c * n + c] = 1.0 / L[(size_t)c * n + c];
+        for (int i = c + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = c; k < i; ++k) s += L[(size_t)i * n + k] * Li[(size_t)k * n + c];
+            Li[(size_t)i * n + c] = -s / L[(size_t)i * n + i];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int k = i; k < n; ++k) s += Li[(size_t)k * n + i] * Li[(size_t)k * n + j];
+            A[(size_t)i * n + j] = A[(size_t)j * n + i] = s;
+        }
+    return 0;
+}
+
+template <typename T>
+int up(const std::vector<T> &v, T **d) {
+    NLG_HIP(hipMalloc(d, sizeof(T) * std::max<size_t>(v.size(), 1)));
+    if (!v.empty()) NLG_HIP(hipMemcpy(*d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+namespace nlg {
+
+int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
+    nlg_pprec &P = m->pprec;
+    nlg_ctx *ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    const int dim = m->dim, n = m->n, n2 = m->n2, np1 = m->np1, np2 = m->np2;
+    const int64_t E = m->E;
+    const nlg_ops1d &o = m->ops;
+    // ---- host copies of what the set-up needs
+    std::vector<double> vmult((size_t)m->lvn), binv((size_t)m->lvn);
+    NLG_HIP(hipMemcpyAsync(vmult.data(), m->d_vmult, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, st));
+    NLG_HIP(hipMemcpyAsync(binv.data(), m->d_binvm1, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, st));
+    NLG_HIP(hipStreamSynchronize(st));
+    const double *X[3] = {d->xm1, d->ym1, d->zm1};
+    const double *msk[3] = {d->v1mask, d->v2mask, d->v3mask};
+    // ---- 1. element-wise fast diagonalisation
+    std::vector<double> Dh((size_t)n2 * n), Ih((size_t)n2 * n);
+    for (int k = 0; k < n2; ++k)
+        for (int j = 0; j < n; ++j) {
+            Dh[(size_t)k * n + j] = o.w2[k] * o.D12[(size_t)k * n + j];
+            Ih[(size_t)k * n + j] = o.w2[k] * o.I12[(size_t)k * n + j];
+        }
+    std::vector<double> hS((size_t)E * 3 * n2 * n2, 0.0), hden((size_t)E * np2, 0.0);
+    std::vector<double> lam3((size_t)3 * n2);
+    const int mid = n / 2;
+    double denmax = 0.0;
+    for (int64_t e = 0; e < E; ++e) {
+        for (int dd = 0; dd < dim; ++dd) {
+            // face centres in direction dd
+            double c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+            int cnt = 0;
+            for (int p = 0; p < np1; ++p) {
+                const int ijk[3] = {p % n, (p / n) % n, p / (n * n)};
+                if (ijk[dd] == 0) {
+                    for (int c = 0; c < dim; ++c) c0[c] += X[c][e * np1 + p];
+                    ++cnt;
+                } else if (ijk[dd] == n - 1) {
+                    for (int c = 0; c < dim; ++c) c1[c] += X[c][e * np1 + p];
+                }
+            }
+            double l = 0.0;
+            for (int c = 0; c < dim; ++c) l += (c1[c] - c0[c]) * (c1[c] - c0[c]) / ((double)cnt * cnt);
+            l = std::sqrt(l);
+            std::vector<double> bi(n);
+            for (int i = 0; i < n; ++i) bi[i] = 1.0 / (0.5 * l * o.w1[i]);
+            for (int side = 0; side < 2; ++side) {
+                int ijk[3] = {mid, mid, dim == 3 ? mid : 0};
+                ijk[dd] = side == 0 ? 0 : n - 1;
+                const int64_t q = e * np1 + ijk[0] + n * (ijk[1] + n * ijk[2]);
+                const int k = side == 0 ? 0 : n - 1;
+                bi[k] = (msk[dd][q] == 0.0) ? 0.0 : bi[k] * vmult[q];
+            }
+            std::vector<double> A((size_t)n2 * n2), B((size_t)n2 * n2), S, lam;
+            for (int a = 0; a < n2; ++a)
+                for (int b = 0; b < n2; ++b) {
+                    double sa = 0.0, sb = 0.0;
+                    for (int j = 0; j < n; ++j) {
+                        sa += Dh[(size_t)a * n + j] * bi[j] * Dh[(size_t)b * n + j];
+                        sb += Ih[(size_t)a * n + j] * bi[j] * Ih[(size_t)b * n + j];
+                    }
+                    A[(size_t)a * n2 + b] = sa;
+                    B[(size_t)a * n2 + b] = 0.25 * l * l * sb;
+                }
+            NLG_CHECK(gen_eig(n2, A, B, S, lam) == 0, "pprec_setup: 1-D mass matrix not positive definite (element %lld)", (long long)e);
+            for (int q = 0; q < n2 * n2; ++q) hS[((size_t)e * 3 + dd) * n2 * n2 + q] = S[q];
+            for (int a = 0; a < n2; ++a) lam3[(size_t)dd * n2 + a] = std::max(lam[a], 0.0);
+        }
+        for (int q = 0; q < np2; ++q) {
+            const int a = q % n2, b = (q / n2) % n2, c = q / (n2 * n2);
+            double den = lam3[a] + lam3[n2 + b] + (dim == 3 ? lam3[2 * n2 + c] : 0.0);
+            hden[(size_t)e * np2 + q] = den;
+            denmax = std::max(denmax, den);
+        }
+    }
+    for (auto &v : hden) v = (v > 1e-12 * denmax) ? 1.0 / v : 0.0;
+    NLG_TRY(up(hS, &P.d_S));
+    NLG_TRY(up(hden, &P.d_invden));
+
+    // ---- 2. coarse operator A_c = R_0 E R_0^T (exact), from the local vectors G_e = D_e^T 1
+    std::vector<std::vector<double>> G(dim, std::vector<double>((size_t)m->lvn));
+    {
+        double *ones = sem_scratch2(m, 0);
+        double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), dim == 3 ? sem_scratch1(m, 2) : nullptr};
+        NLG_CHECK(ones && w[0] && w[1], "pprec_setup: scratch allocation failed");
+        std::vector<double> h1((size_t)m->lpn, 1.0);
+        NLG_HIP(hipMemcpyAsync(ones, h1.data(), sizeof(double) * (size_t)m->lpn, hipMemcpyHostToDevice, st));
+        NLG_TRY(sem_opgradt(m, ones, w));
+        for (int c = 0; c < dim; ++c)
+            NLG_HIP(hipMemcpyAsync(G[c].data(), w[c], sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<std::unordered_map<int, double>> rows((size_t)E);
+    {
+        // diagonal contributions of every local dof, cross terms through the groups of shared labels
+        for (int64_t q = 0; q < m->lvn; ++q) {
+            const int e = (int)(q / np1);
+            double s = 0.0;
+            for (int c = 0; c < dim; ++c) s += msk[c][q] * binv[q] * G[c][q] * G[c][q];
+            if (s != 0.0) rows[e][e] += s;
+        }
+        std::vector<int> order((size_t)m->lvn);
+        std::iota(order.begin(), order.end(), 0);
+        const int64_t *glo = d->glo_num;
+        std::sort(order.begin(), order.end(), [glo](int a, int b) { return glo[a] < glo[b] || (glo[a] == glo[b] && a < b); });
+        int64_t b = 0;
+        while (b < m->lvn) {
+            int64_t e2 = b + 1;
+            while (e2 < m->lvn && glo[order[e2]] == glo[order[b]]) ++e2;
+            for (int64_t i = b; i < e2; ++i)
+                for (int64_t j = b; j < e2; ++j) {
+                    if (i == j) continue;
+                    const int qa = order[i], qb = order[j];
+                    double s = 0.0;
+                    for (int c = 0; c < dim; ++c) s += msk[c][qa] * binv[qa] * G[c][qa] * G[c][qb];
+                    if (s != 0.0) rows[qa / np1][qb / np1] += s;
+                }
+            b = e2;
+        }
+    }
+    std::vector<int> rp((size_t)E + 1, 0), ci;
+    std::vector<double> av, dinv((size_t)E, 0.0);
+    for (int64_t e = 0; e < E; ++e) {
+        std::vector<std::pair<int, double>> r(rows[e].begin(), rows[e].end());
+        std::sort(r.begin(), r.end());
+        for (auto &kv : r) {
+            ci.push_back(kv.first);
+            av.push_back(kv.second);
+            if (kv.first == e) dinv[e] = kv.second > 0 ? 1.0 / kv.second : 0.0;
+        }
+        rp[e + 1] = (int)ci.size();
+    }
+    // ---- 3. aggregates and the dense inverse on them
+    std::vector<int> agg((size_t)E, -1);
+    int na = 0;
+    if (E <= 1024) {
+        for (int64_t e = 0; e < E; ++e) agg[e] = (int)e;
+        na = (int)E;
+    } else {
+        for (int64_t e = 0; e < E; ++e) {
+            if (agg[e] >= 0) continue;
+            bool free_all = true;
+            for (int q = rp[e]; q < rp[e + 1]; ++q)
+                if (agg[ci[q]] >= 0) free_all = false;
+            if (!free_all) continue;
+            for (int q = rp[e]; q < rp[e + 1]; ++q) agg[ci[q]] = na;
+            ++na;
+        }
+        for (int64_t e = 0; e < E; ++e) {
+            if (agg[e] >= 0) continue;
+            int best = -1;
+            double bv = -1.0;
+            for (int q = rp[e]; q < rp[e + 1]; ++q)
+                if (ci[q] != e && agg[ci[q]] >= 0 && std::fabs(av[q]) > bv) {
+                    bv = std::fabs(av[q]);
+                    best = agg[ci[q]];
+                }
+            agg[e] = best >= 0 ? best : na++;
+        }
+    }
+    std::vector<double> Acc((size_t)na * na, 0.0);
+    for (int64_t e = 0; e < E; ++e)
+        for (int q = rp[e]; q < rp[e + 1]; ++q) Acc[(size_t)agg[e] * na + agg[ci[q]]] += av[q];
+    for (int i = 0; i < na; ++i)
+        for (int j = i + 1; j < na; ++j) Acc[(size_t)i * na + j] = Acc[(size_t)j * na + i] = 0.5 * (Acc[(size_t)i * na + j] + Acc[(size_t)j * na + i]);
+    if (!m->has_outflow && !ctx->comm) {
+        // constant null space: shift it so that the inverse acts as the pseudo-inverse on mean-free data
+        double tr = 0.0;
+        for (int i = 0; i < na; ++i) tr += Acc[(size_t)i * na + i];
+        const double alpha = tr / na / na;   // the null vector of R_1 A_c R_1^T is the vector of ones
+        for (int i = 0; i < na; ++i)
+            for (int j = 0; j < na; ++j) Acc[(size_t)i * na + j] += alpha;
+    }
+    NLG_CHECK(spd_inverse(na, Acc) == 0, "pprec_setup: aggregate operator is not positive definite");
+    std::vector<int> ap((size_t)na + 1, 0), am((size_t)E);
+    for (int64_t e = 0; e < E; ++e) ap[agg[e] + 1]++;
+    for (int a = 0; a < na; ++a) ap[a + 1] += ap[a];
+    {
+        std::vector<int> pos(ap.begin(), ap.end() - 1);
+        for (int64_t e = 0; e < E; ++e) am[pos[agg[e]]++] = (int)e;
+    }
+    P.na = na;
+    NLG_TRY(up(rp, &P.d_rp));
+    NLG_TRY(up(ci, &P.d_ci));
+    NLG_TRY(up(av, &P.d_av));
+    NLG_TRY(up(dinv, &P.d_dinv));
+    NLG_TRY(up(agg, &P.d_agg));
+    NLG_TRY(up(ap, &P.d_ap));
+    NLG_TRY(up(am, &P.d_am));
+    NLG_TRY(up(Acc, &P.d_Ainv));
+    for (double **v : {&P.d_rc, &P.d_x, &P.d_t}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)E));
+    for (double **v : {&P.d_ra, &P.d_xa}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(na, 1)));
+    P.ready = true;
+    return 0;
+}
+
+// z = M^-1 r ; `flag` (may be null) is the device convergence flag of the surrounding PCG
+int pprec_apply(nlg_mesh *m, const double *flag, const double *r, double *z) {
+    nlg_pprec &P = m->pprec;
+    NLG_CHECK(P.ready, "pprec_apply: preconditioner not set up");
+    hipStream_t st = m->ctx->stream;
+    ProfScope ps(m->ctx, P_PPREC);
+    const int64_t E = m->E;
+    const double om = 0.7;
+    const int gE = (int)((E + 255) / 256);
+    hipLaunchKernelGGL(k_restrict0, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->np2, r, P.d_rc);
+    hipLaunchKernelGGL(k_jac0, dim3(gE), dim3(256), 0, st, flag, E, P.d_dinv, P.d_rc, om, P.d_x);
+    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 0, P.d_t);
+    hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 255) / 256), dim3(256), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_t, P.d_ra);
+    hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_Ainv, P.d_ra, P.d_xa);
+    hipLaunchKernelGGL(k_prolong_add, dim3(gE), dim3(256), 0, st, flag, E, P.d_agg, P.d_xa, P.d_x);
+    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 1, P.d_t);
+#define FDM_CASE(N_)                                                                                                  \
+    if (m->dim == 3)                                                                                                  \
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)E), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, P.d_t, z); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)E), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, P.d_t, z);
+    switch (m->n) {
+        case 4: FDM_CASE(4); break;
+        case 5: FDM_CASE(5); break;
+        case 6: FDM_CASE(6); break;
+        case 7: FDM_CASE(7); break;
+        case 8: FDM_CASE(8); break;
+        case 9: FDM_CASE(9); break;
+        case 10: FDM_CASE(10); break;
+        case 12: FDM_CASE(12); break;
+        default: set_error("pprec_apply: unsupported lx1 = %d", m->n); return 1;
+    }
+#undef FDM_CASE
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+void pprec_free(nlg_mesh *m) {
+    nlg_pprec &P = m->pprec;
+    double *dp[] = {P.d_S, P.d_invden, P.d_av, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_t, P.d_ra, P.d_xa};
+    for (double *p : dp)
+        if (p) hipFree(p);
+    int *ip[] = {P.d_rp, P.d_ci, P.d_agg, P.d_ap, P.d_am};
+    for (int *p : ip)
+        if (p) hipFree(p);
+    P = nlg_pprec();
+}
+
+}  // namespace nlg

@@ -1468,6 +1468,8 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
             }
     }
     NLG_HIP(hipStreamSynchronize(s));
+    NLG_TRY(pprec_setup(m, d));
+    NLG_HIP(hipStreamSynchronize(s));
     *out = m;
     return 0;
 }
@@ -1494,6 +1496,7 @@ int nlg_mesh_destroy(nlg_mesh *m) {
         if (m->d_G[q]) hipFree(m->d_G[q]);
     if (m->d_lglel) hipFree(m->d_lglel);
     halo_free(m);
+    pprec_free(m);
     if (m->gs.d_offsets) hipFree(m->gs.d_offsets);
     if (m->gs.d_indices) hipFree(m->gs.d_indices);
     for (double *p : m->scratch1) hipFree(p);

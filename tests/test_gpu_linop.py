@@ -13,7 +13,7 @@ from oracle.vectors import NekDVector
 pytestmark = pytest.mark.gpu
 
 
-def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.04):
+def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.04, pprecond=0):
     if dim == 2:
         hm = box_mesh((4, 3), n, lengths=(4.0, 2.0), periodic=(True, False), deform=deform)
     else:
@@ -34,7 +34,7 @@ def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.
         kw.update(fixed_iters_v=30, fixed_iters_p=600)   # converged: unconverged CG amplifies rounding differences
     ocfg = LNSConfig(**kw)
     oA = ExptA(sem, ob.v, ocfg)
-    gA = host.exptA_linop(tau, gb, **{k: v for k, v in kw.items() if k != "tau"})
+    gA = host.exptA_linop(tau, gb, pprecond=pprecond, **{k: v for k, v in kw.items() if k != "tau"})
     gA.init()
     return hm, sem, gm, oA, gA, rng
 
@@ -63,8 +63,8 @@ def cmp_vec(gv, ov, tol, what=""):
 @pytest.mark.parametrize("dim", [2, 3])
 @pytest.mark.parametrize("adjoint", [False, True])
 def test_matvec_fixed_iterations(gpu_ctx, dim, adjoint):
-    """Identical discrete operator, identical iteration counts -> agreement to rounding."""
-    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, dim)
+    """Identical discrete operator, identical solver (Jacobi-PCG as in the oracle) -> agreement to rounding."""
+    hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, dim, pprecond=1)
     info = gA.info()
     assert info["nsteps"] == oA.nsteps and abs(info["dt"] - oA.dt) < 1e-15
     ov, gv = load_pair(sem, gm, rng)
@@ -86,6 +86,25 @@ def test_matvec_fixed_iterations(gpu_ctx, dim, adjoint):
     assert st["steps"] == oA.stats["steps"]
     assert abs(st["p_iters"] - oA.stats["p_iters"]) <= 0.02 * oA.stats["p_iters"] + 2
     assert abs(st["v_iters"] - oA.stats["v_iters"]) <= 0.02 * oA.stats["v_iters"] + 2
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_two_level_pressure_preconditioner(gpu_ctx, dim):
+    """The FDM + coarse-grid preconditioner changes the iteration count, not the answer."""
+    hm, sem, gm, oA, gJ, rng = setup_case(gpu_ctx, dim, fixed=False, pprecond=1)
+    _, _, _, _, g2, _ = setup_case(gpu_ctx, dim, fixed=False, pprecond=0)
+    ov, gv = load_pair(sem, gm, rng)
+    gv2 = host.nek_dvector(g2.mesh)
+    for i in range(dim):
+        gv2.set_field(i, ov.v[i])
+    gv2.set_field(host.PR, ov.pr)
+    oJ, o2 = host.nek_dvector(gm), host.nek_dvector(g2.mesh)
+    gJ.matvec(gv, oJ)
+    g2.matvec(gv2, o2)
+    sc = max(np.abs(oJ.get_field(i)).max() for i in range(dim))
+    for i in range(dim):
+        assert np.max(np.abs(oJ.get_field(i) - o2.get_field(i))) < 1e-9 * sc
+    assert g2.stats()["p_iters"] < 0.5 * gJ.stats()["p_iters"]
 
 
 def test_matvec_tolerance_mode(gpu_ctx):
