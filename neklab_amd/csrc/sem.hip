@@ -385,73 +385,69 @@ __global__ __launch_bounds__(NT) void k_colmul(F3 w, CF3 wt, int64_t n) {
 // 3-D: (N x N) threads per element sweep the k-slabs; u column and w column live in registers,
 // the r/s contractions go through an LDS slab, geometric factors are read once for NF fields.
 // =================================================================================================
-template <int N, int NF>
-__global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) void k_axhelm3(
-    int64_t E, const double *__restrict__ Dg, const double *__restrict__ G0, const double *__restrict__ G1,
-    const double *__restrict__ G2, const double *__restrict__ G3, const double *__restrict__ G4,
-    const double *__restrict__ G5, const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2) {
-    constexpr int EPB = (NT / (N * N)) > 0 ? (NT / (N * N)) : 1;
-    constexpr int NP = N * N * N;
-    __shared__ double sD[N * N];
-    __shared__ double sU[EPB][NF][N * N];
-    __shared__ double sR[EPB][NF][N * N];
-    __shared__ double sS[EPB][NF][N * N];
+// One thread per (i, j, field), runtime sweep over the k-slabs.  The element's u and the three metric-weighted
+// derivative fields live in LDS cubes, so no register array is indexed by k (a fully unrolled register-column
+// version made hipcc allocate 256 VGPRs and spill ~200 more: 1.9 ms per launch at E = 10k instead of ~0.15 ms).
+// The fields of one element sit in different waves of the same block: the metric factors come from HBM once and
+// are served to the other fields by L1.
+template <int N>
+__global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, const double *__restrict__ Dg,
+                                                const double *__restrict__ G0, const double *__restrict__ G1,
+                                                const double *__restrict__ G2, const double *__restrict__ G3,
+                                                const double *__restrict__ G4, const double *__restrict__ G5,
+                                                const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2) {
+    constexpr int NP = N * N * N, NS = N * N;
+    extern __shared__ double smem[];
+    double *sD = smem;                   // N*N
     const int tid = threadIdx.x;
-    const int le = tid / (N * N);
-    const int ij = tid % (N * N);
+    const int slot = tid / NS;           // (element, field) slot inside the block
+    const int ij = tid % NS;
     const int i = ij % N, j = ij / N;
-    for (int p = tid; p < N * N; p += EPB * N * N) sD[p] = Dg[p];
-    const int64_t e = (int64_t)blockIdx.x * EPB + le;
+    double *sU = smem + NS + (size_t)slot * 4 * NP;
+    double *sR = sU + NP, *sS = sR + NP, *sT = sS + NP;
+    for (int p = tid; p < NS; p += blockDim.x) sD[p] = Dg[p];
+    const int64_t gslot = (int64_t)blockIdx.x * epb + slot;   // epb = (element, field) slots per block
+    const int64_t e = gslot / nf;
+    const int c = (int)(gslot % nf);
     const bool act = e < E;
     const int64_t base = (act ? e : 0) * NP;
-    double ru[NF][N], rw[NF][N];
-#pragma unroll
-    for (int c = 0; c < NF; ++c)
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            ru[c][k] = act ? u.p[c][base + ij + k * N * N] : 0.0;
-            rw[c][k] = 0.0;
-        }
+    const double *uc = c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]);
+    double *wc = c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2]);
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) sU[ij + k * NS] = act ? uc[base + ij + k * NS] : 0.0;
     __syncthreads();
+    double di[N], dj[N], dti[N], dtj[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int64_t q = base + ij + k * N * N;
-        const double g0 = G0[q], g1 = G1[q], g2 = G2[q], g3 = G3[q], g4 = G4[q], g5 = G5[q], bm = bm1[q];
-#pragma unroll
-        for (int c = 0; c < NF; ++c) sU[le][c][ij] = ru[c][k];
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NF; ++c) {
-            double ur = 0.0, us = 0.0, ut = 0.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
-                ur += sD[i * N + l] * sU[le][c][l + N * j];
-                us += sD[j * N + l] * sU[le][c][i + N * l];
-                ut += sD[k * N + l] * ru[c][l];
-            }
-            const double gr = h1 * (g0 * ur + g1 * us + g2 * ut);
-            const double gs = h1 * (g1 * ur + g3 * us + g4 * ut);
-            const double gt = h1 * (g2 * ur + g4 * us + g5 * ut);
-            sR[le][c][ij] = gr;
-            sS[le][c][ij] = gs;
-#pragma unroll
-            for (int l = 0; l < N; ++l) rw[c][l] += sD[k * N + l] * gt;   // D^T along t
-            rw[c][k] += h2 * bm * ru[c][k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NF; ++c) {
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) a += sD[l * N + i] * sR[le][c][l + N * j] + sD[l * N + j] * sS[le][c][i + N * l];
-            rw[c][k] += a;
-        }
+    for (int l = 0; l < N; ++l) {
+        di[l] = sD[i * N + l];
+        dj[l] = sD[j * N + l];
+        dti[l] = sD[l * N + i];
+        dtj[l] = sD[l * N + j];
     }
-    if (act) {
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+        const int64_t q = base + ij + k * NS;
+        const double g0 = G0[q], g1 = G1[q], g2 = G2[q], g3 = G3[q], g4 = G4[q], g5 = G5[q];
+        double ur = 0.0, us = 0.0, ut = 0.0;
 #pragma unroll
-        for (int c = 0; c < NF; ++c)
+        for (int l = 0; l < N; ++l) {
+            ur += di[l] * sU[l + N * j + k * NS];
+            us += dj[l] * sU[i + N * l + k * NS];
+            ut += sD[k * N + l] * sU[ij + l * NS];
+        }
+        sR[ij + k * NS] = h1 * (g0 * ur + g1 * us + g2 * ut);
+        sS[ij + k * NS] = h1 * (g1 * ur + g3 * us + g4 * ut);
+        sT[ij + k * NS] = h1 * (g2 * ur + g4 * us + g5 * ut);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+        const int64_t q = base + ij + k * NS;
+        double a = h2 * bm1[q] * sU[ij + k * NS];
 #pragma unroll
-            for (int k = 0; k < N; ++k) w.p[c][base + ij + k * N * N] = rw[c][k];
+        for (int l = 0; l < N; ++l)
+            a += dti[l] * sR[l + N * j + k * NS] + dtj[l] * sS[i + N * l + k * NS] + sD[l * N + k] * sT[ij + l * NS];
+        if (act) wc[q] = a;
     }
 }
 
@@ -981,17 +977,16 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
     if (m->dim == 3) {
 #define AX3(N_)                                                                                                       \
     {                                                                                                                 \
-        constexpr int EPB = (NT / (N_ * N_)) > 0 ? (NT / (N_ * N_)) : 1;                                              \
-        const int grid = (int)((m->E + EPB - 1) / EPB);                                                               \
-        if (nf == 1)                                                                                                  \
-            hipLaunchKernelGGL((k_axhelm3<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2);      \
-        else if (nf == 2)                                                                                             \
-            hipLaunchKernelGGL((k_axhelm3<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2);      \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_axhelm3<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2);      \
+        int nslot = 512 / (N_ * N_);                                                                                  \
+        const int lds_cap = (int)((64 * 1024 / 8 - N_ * N_) / (4 * N_ * N_ * N_));                                    \
+        if (nslot > lds_cap) nslot = lds_cap;                                                                         \
+        if (nslot > 6) nslot = 6;                                                                                     \
+        if (nslot < 1) nslot = 1;                                                                                     \
+        const int64_t tot = m->E * nf;                                                                                \
+        const int grid = (int)((tot + nslot - 1) / nslot);                                                            \
+        const size_t lds = sizeof(double) * (size_t)(N_ * N_ + nslot * 4 * N_ * N_ * N_);                             \
+        hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2); \
     }
         NLG_FOR_N(AX3)
 #undef AX3
