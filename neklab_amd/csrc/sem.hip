@@ -555,116 +555,220 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
     }
 }
 
-// ---- opgradt 3-D: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise) -------------
-// It / Dt are the transposes (N x N2 row-major) of I12 / D12.
+// ---- pressure-mesh <-> velocity-mesh operators, 3-D ------------------------------------------------------------
+// Each thread owns whole 1-D columns: it loads the N2 (or N) entries of a column once into registers and produces
+// all outputs of the contraction from them; the small interpolation / derivative matrices arrive as BY-VALUE kernel
+// arguments, i.e. in the scalar kernarg segment, so the matrix operand of every FMA is an SGPR pair and costs no
+// LDS or vector-memory traffic.  NC = velocity components processed per pass (3 when the LDS image of all three
+// fits, else 1).
 template <int N>
-__global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, const double *__restrict__ Itg,
-                                                 const double *__restrict__ Dtg, CF9 g, const double *__restrict__ p,
-                                                 F3 w) {
-    constexpr int N2 = N - 2;
+struct PMats {
+    double It[N * (N - 2)];   // I12^T  (N x N2 row-major)
+    double Dt[N * (N - 2)];   // D12^T
+    double Im[(N - 2) * N];   // I12    (N2 x N row-major)
+    double Dm[(N - 2) * N];   // D12
+};
+
+// opgradt: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise)
+template <int N, int NC>
+__global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w) {
+    constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SA = N2 * N2 * N, SB = N2 * N * N;
-    __shared__ double sI[N * N2], sDt[N * N2];
-    __shared__ double sP[NP2];
-    __shared__ double sQ[3][NP2];
-    __shared__ double sA[3][SA];
-    __shared__ double sB[2][SB];
+    __shared__ double sA[NC * 3][SA];
+    __shared__ double sB[NC * 2][SB];
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
-    for (int q = tid; q < N * N2; q += NT) {
-        sI[q] = Itg[q];
-        sDt[q] = Dtg[q];
-    }
-    for (int q = tid; q < NP2; q += NT) sP[q] = p[e * NP2 + q];
-    __syncthreads();
-    for (int i = 0; i < 3; ++i) {
-        // q_j = g_ji * p  (j = 0,1,2)
-        for (int q = tid; q < NP2; q += NT) {
-            const double pv = sP[q];
-            sQ[0][q] = g.p[0 * 3 + i][e * NP2 + q] * pv;
-            sQ[1][q] = g.p[1 * 3 + i][e * NP2 + q] * pv;
-            sQ[2][q] = g.p[2 * 3 + i][e * NP2 + q] * pv;
-        }
-        __syncthreads();
-        // z stage
-        contract<N2, N2, N2, 2, N, false>(sQ[0], sA[0], sI, tid, NT);
-        contract<N2, N2, N2, 2, N, false>(sQ[1], sA[1], sI, tid, NT);
-        contract<N2, N2, N2, 2, N, false>(sQ[2], sA[2], sDt, tid, NT);
-        __syncthreads();
-        // y stage: B0 = I^T_y A0 ; B1 = D^T_y A1 + I^T_y A2
-        contract<N2, N2, N, 1, N, false>(sA[0], sB[0], sI, tid, NT);
-        contract<N2, N2, N, 1, N, false>(sA[1], sB[1], sDt, tid, NT);
-        contract<N2, N2, N, 1, N, true>(sA[2], sB[1], sI, tid, NT);
-        __syncthreads();
-        // x stage: w = D^T_x B0 + I^T_x B1
-        for (int q = tid; q < NP1; q += NT) {
-            const int a = q % N, bc = q / N;
-            double s = 0.0;
+    const double *pe = p + e * NP2;
+    for (int c0 = 0; c0 < 3; c0 += NC) {
+        if (c0 > 0) __syncthreads();
+        // z stage, arrays j = 0,1 (interpolation along z)
+        for (int t = tid; t < NC * 2 * NS2; t += NT) {
+            const int arr = t / NS2, col = t % NS2;
+            const int ci = arr >> 1, j = arr & 1, i = c0 + ci;
+            const double *gp = (i == 0 ? g.p[j * 3 + 0] : (i == 1 ? g.p[j * 3 + 1] : g.p[j * 3 + 2])) + e * NP2;
+            double q[N2];
 #pragma unroll
-            for (int l = 0; l < N2; ++l) s += sDt[a * N2 + l] * sB[0][l + N2 * bc] + sI[a * N2 + l] * sB[1][l + N2 * bc];
-            w.p[i][e * NP1 + q] = s;
+            for (int k2 = 0; k2 < N2; ++k2) q[k2] = gp[col + NS2 * k2] * pe[col + NS2 * k2];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                double a = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) a += M.It[k * N2 + k2] * q[k2];
+                sA[ci * 3 + j][col + NS2 * k] = a;
+            }
+        }
+        // z stage, array j = 2 (derivative along z)
+        for (int t = tid; t < NC * NS2; t += NT) {
+            const int ci = t / NS2, col = t % NS2, i = c0 + ci;
+            const double *gp = (i == 0 ? g.p[6] : (i == 1 ? g.p[7] : g.p[8])) + e * NP2;
+            double q[N2];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) q[k2] = gp[col + NS2 * k2] * pe[col + NS2 * k2];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                double a = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) a += M.Dt[k * N2 + k2] * q[k2];
+                sA[ci * 3 + 2][col + NS2 * k] = a;
+            }
         }
         __syncthreads();
+        // y stage: B0 = I^T_y A0 ; B1 = D^T_y A1 + I^T_y A2     (columns over (i2, k))
+        for (int t = tid; t < NC * N2 * N; t += NT) {
+            const int ci = t / (N2 * N), col = t % (N2 * N);
+            const int i2 = col % N2, k = col / N2;
+            double a0[N2], a1[N2], a2[N2];
+#pragma unroll
+            for (int j2 = 0; j2 < N2; ++j2) {
+                const int q = i2 + N2 * (j2 + N2 * k);
+                a0[j2] = sA[ci * 3 + 0][q];
+                a1[j2] = sA[ci * 3 + 1][q];
+                a2[j2] = sA[ci * 3 + 2][q];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int j2 = 0; j2 < N2; ++j2) {
+                    b0 += M.It[j * N2 + j2] * a0[j2];
+                    b1 += M.Dt[j * N2 + j2] * a1[j2] + M.It[j * N2 + j2] * a2[j2];
+                }
+                sB[ci * 2 + 0][i2 + N2 * (j + N * k)] = b0;
+                sB[ci * 2 + 1][i2 + N2 * (j + N * k)] = b1;
+            }
+        }
+        __syncthreads();
+        // x stage: w = D^T_x B0 + I^T_x B1, written straight to HBM (N contiguous doubles per thread)
+        for (int t = tid; t < NC * N * N; t += NT) {
+            const int ci = t / (N * N), bc = t % (N * N), i = c0 + ci;
+            double b0[N2], b1[N2];
+#pragma unroll
+            for (int i2 = 0; i2 < N2; ++i2) {
+                b0[i2] = sB[ci * 2 + 0][i2 + N2 * bc];
+                b1[i2] = sB[ci * 2 + 1][i2 + N2 * bc];
+            }
+            double *wp = (i == 0 ? w.p[0] : (i == 1 ? w.p[1] : w.p[2])) + e * NP1 + (int64_t)N * bc;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double v = 0.0;
+#pragma unroll
+                for (int i2 = 0; i2 < N2; ++i2) v += M.Dt[a * N2 + i2] * b0[i2] + M.It[a * N2 + i2] * b1[i2];
+                wp[a] = v;
+            }
+        }
     }
 }
 
-// ---- opdiv 3-D: out = scale * sum_i sum_j g_ji o (T_j u_i) ------------------------------------------
-// Im / Dm are I12 / D12 (N2 x N row-major).
-// `wt` (may hold nulls) is an optional pointwise weight applied to u_i while loading: with
-// wt_i = mask_i * binvm1 the opbinv scaling of the consistent Poisson operator is fused in.
-template <int N>
-__global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, const double *__restrict__ Img,
-                                               const double *__restrict__ Dmg, CF9 g, CF3 u, CF3 wt,
-                                               double *__restrict__ out, double scale) {
-    constexpr int N2 = N - 2;
+// opdiv: out = scale * sum_i sum_j g_ji o (T_j (wt_i o u_i)); wt (may hold nulls) fuses mask * binvm1 into the load
+template <int N, int NC>
+__global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
+                                               double scale) {
+    constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SB = N2 * N * N, SC = N2 * N2 * N;
-    __shared__ double sI[N2 * N], sD[N2 * N];
-    __shared__ double sU[NP1];
-    __shared__ double sB[2][SB];
-    __shared__ double sC[3][SC];
+    constexpr int SBTOT = NC * 2 * SB, SPTOT = NC * 3 * NP2;
+    __shared__ double sBP[SBTOT > SPTOT ? SBTOT : SPTOT];   // x-stage output, later the per-array products
+    __shared__ double sC[NC * 3][SC];
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
-    for (int q = tid; q < N * N2; q += NT) {
-        sI[q] = Img[q];
-        sD[q] = Dmg[q];
-    }
     constexpr int NACC = (NP2 + NT - 1) / NT;
     double acc[NACC];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) acc[r] = 0.0;
-    for (int i = 0; i < 3; ++i) {
+    for (int c0 = 0; c0 < 3; c0 += NC) {
         __syncthreads();
-        if (wt.p[i]) {
-            for (int q = tid; q < NP1; q += NT) sU[q] = u.p[i][e * NP1 + q] * wt.p[i][e * NP1 + q];
-        } else {
-            for (int q = tid; q < NP1; q += NT) sU[q] = u.p[i][e * NP1 + q];
+        // x stage from HBM: B0 = D_x u, B1 = I_x u   (columns over (j, k); N contiguous doubles per thread)
+        for (int t = tid; t < NC * N * N; t += NT) {
+            const int ci = t / (N * N), bc = t % (N * N), i = c0 + ci;
+            const double *up = (i == 0 ? u.p[0] : (i == 1 ? u.p[1] : u.p[2])) + e * NP1 + (int64_t)N * bc;
+            const double *wp = (i == 0 ? wt.p[0] : (i == 1 ? wt.p[1] : wt.p[2]));
+            double uu[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) uu[a] = up[a];
+            if (wp) {
+                wp += e * NP1 + (int64_t)N * bc;
+#pragma unroll
+                for (int a = 0; a < N; ++a) uu[a] *= wp[a];
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < N2; ++i2) {
+                double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    b0 += M.Dm[i2 * N + a] * uu[a];
+                    b1 += M.Im[i2 * N + a] * uu[a];
+                }
+                sBP[(ci * 2 + 0) * SB + i2 + N2 * bc] = b0;
+                sBP[(ci * 2 + 1) * SB + i2 + N2 * bc] = b1;
+            }
         }
         __syncthreads();
-        // x stage: B0 = D_x u, B1 = I_x u
-        contract<N, N, N, 0, N2, false>(sU, sB[0], sD, tid, NT);
-        contract<N, N, N, 0, N2, false>(sU, sB[1], sI, tid, NT);
+        // y stage: C0 = I_y B0 ; C1 = D_y B1 ; C2 = I_y B1     (columns over (i2, k))
+        for (int t = tid; t < NC * N2 * N; t += NT) {
+            const int ci = t / (N2 * N), col = t % (N2 * N);
+            const int i2 = col % N2, k = col / N2;
+            double b0[N], b1[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                b0[j] = sBP[(ci * 2 + 0) * SB + i2 + N2 * (j + N * k)];
+                b1[j] = sBP[(ci * 2 + 1) * SB + i2 + N2 * (j + N * k)];
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < N2; ++j2) {
+                double c0v = 0.0, c1v = 0.0, c2v = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    c0v += M.Im[j2 * N + j] * b0[j];
+                    c1v += M.Dm[j2 * N + j] * b1[j];
+                    c2v += M.Im[j2 * N + j] * b1[j];
+                }
+                const int q = i2 + N2 * (j2 + N2 * k);
+                sC[ci * 3 + 0][q] = c0v;
+                sC[ci * 3 + 1][q] = c1v;
+                sC[ci * 3 + 2][q] = c2v;
+            }
+        }
         __syncthreads();
-        // y stage: C0 = I_y B0 ; C1 = D_y B1 ; C2 = I_y B1
-        contract<N2, N, N, 1, N2, false>(sB[0], sC[0], sI, tid, NT);
-        contract<N2, N, N, 1, N2, false>(sB[1], sC[1], sD, tid, NT);
-        contract<N2, N, N, 1, N2, false>(sB[1], sC[2], sI, tid, NT);
+        // z stage fused with the metric product: arrays j = 0,1 use I_z, array j = 2 uses D_z; products go to LDS
+        for (int t = tid; t < NC * 2 * NS2; t += NT) {
+            const int arr = t / NS2, col = t % NS2;
+            const int ci = arr >> 1, j = arr & 1, i = c0 + ci;
+            const double *gp = (i == 0 ? g.p[j * 3 + 0] : (i == 1 ? g.p[j * 3 + 1] : g.p[j * 3 + 2])) + e * NP2;
+            double cc[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) cc[k] = sC[ci * 3 + j][col + NS2 * k];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) a += M.Im[k2 * N + k] * cc[k];
+                sBP[(ci * 3 + j) * NP2 + col + NS2 * k2] = gp[col + NS2 * k2] * a;
+            }
+        }
+        for (int t = tid; t < NC * NS2; t += NT) {
+            const int ci = t / NS2, col = t % NS2, i = c0 + ci;
+            const double *gp = (i == 0 ? g.p[6] : (i == 1 ? g.p[7] : g.p[8])) + e * NP2;
+            double cc[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) cc[k] = sC[ci * 3 + 2][col + NS2 * k];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) a += M.Dm[k2 * N + k] * cc[k];
+                sBP[(ci * 3 + 2) * NP2 + col + NS2 * k2] = gp[col + NS2 * k2] * a;
+            }
+        }
         __syncthreads();
-        // z stage fused with metric contraction
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const int q = tid + r * NT;
             if (q < NP2) {
-                const int ab = q % (N2 * N2), c = q / (N2 * N2);
-                double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+                double a = 0.0;
 #pragma unroll
-                for (int l = 0; l < N; ++l) {
-                    t0 += sI[c * N + l] * sC[0][ab + N2 * N2 * l];
-                    t1 += sI[c * N + l] * sC[1][ab + N2 * N2 * l];
-                    t2 += sD[c * N + l] * sC[2][ab + N2 * N2 * l];
-                }
-                const int64_t gq = e * NP2 + q;
-                acc[r] += g.p[0 * 3 + i][gq] * t0 + g.p[1 * 3 + i][gq] * t1 + g.p[2 * 3 + i][gq] * t2;
+                for (int arr = 0; arr < NC * 3; ++arr) a += sBP[arr * NP2 + q];
+                acc[r] += a;
             }
         }
     }
@@ -1019,6 +1123,19 @@ int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2) {
     return 0;
 }
 
+template <int N>
+static void fill_pmats(const nlg_mesh *m, PMats<N> &M) {
+    const int n2 = N - 2;
+    const nlg_ops1d &o = m->ops;
+    for (int k = 0; k < n2; ++k)
+        for (int j = 0; j < N; ++j) {
+            M.Im[k * N + j] = o.I12[(size_t)k * N + j];
+            M.Dm[k * N + j] = o.D12[(size_t)k * N + j];
+            M.It[j * n2 + k] = o.I12[(size_t)k * N + j];
+            M.Dt[j * n2 + k] = o.D12[(size_t)k * N + j];
+        }
+}
+
 static CF9 rst2w_ptrs(const nlg_mesh *m) {
     CF9 g;
     for (int q = 0; q < 9; ++q) g.p[q] = m->d_rst2w[q];
@@ -1031,7 +1148,15 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
-#define GT3(N_) hipLaunchKernelGGL((k_opgradt3<N_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, m->d_I12t, m->d_D12t, g, p, cw)
+#define GT3(N_)                                                                                                        \
+    {                                                                                                                  \
+        PMats<N_> M;                                                                                                   \
+        fill_pmats<N_>(m, M);                                                                                          \
+        if (N_ <= 8)                                                                                                   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);          \
+    }
         NLG_FOR_N(GT3)
 #undef GT3
     } else {
@@ -1055,7 +1180,15 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
-#define DV3(N_) hipLaunchKernelGGL((k_opdiv3<N_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, m->d_I12, m->d_D12, g, cu, wt, out, scale)
+#define DV3(N_)                                                                                                        \
+    {                                                                                                                  \
+        PMats<N_> M;                                                                                                   \
+        fill_pmats<N_>(m, M);                                                                                          \
+        if (N_ <= 8)                                                                                                   \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+    }
         NLG_FOR_N(DV3)
 #undef DV3
     } else {
