@@ -98,6 +98,11 @@ struct nlg_gs {
     int64_t nshared = 0;
     int *d_offsets = nullptr;   // [ngroups + 1]
     int *d_indices = nullptr;   // [nshared] local dof index
+    // the same groups in the face-grouped element layout used for the intermediate fields of the consistent
+    // Poisson operator (3-D): element-boundary points first, face by face, so that the copies of a shared face
+    // are contiguous runs instead of stride-n points
+    int *d_offsets_fg = nullptr;
+    int *d_indices_fg = nullptr;
 };
 
 struct nlg_halo {
@@ -145,6 +150,7 @@ struct nlg_mesh {
     double *d_mask[3] = {nullptr, nullptr, nullptr};
     double *d_tmask = nullptr;
     double *d_mbinv[3] = {nullptr, nullptr, nullptr};   // mask_i * binvm1 (fused opbinv weight)
+    double *d_mbinv_fg[3] = {nullptr, nullptr, nullptr};   // the same in the face-grouped layout
     // pressure mesh
     double *d_rst2w[9] = {};   // each lpn
     double *d_bm2 = nullptr, *d_bm2inv = nullptr;
@@ -152,6 +158,7 @@ struct nlg_mesh {
     double *d_rstdw[9] = {};   // each lfn
     int64_t *d_lglel = nullptr;
     std::vector<int64_t> h_lglel;
+    std::vector<int> h_slot;   // natural point -> face-grouped slot inside an element (3-D)
     nlg_gs gs;
     double volvm1 = 0, volvm2 = 0;
     int64_t lpn_global = 0;   // global pressure dof count (ortho)
@@ -228,8 +235,8 @@ void halo_free(nlg_mesh *m);
 int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place QQ^T
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2);
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
-int sem_opgradt(nlg_mesh *m, const double *p, double *const *w);
-int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr);
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false);
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false);
 int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out);
 int sem_ediag(nlg_mesh *m, double *out);

@@ -561,6 +561,21 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
 // arguments, i.e. in the scalar kernarg segment, so the matrix operand of every FMA is an SGPR pair and costs no
 // LDS or vector-memory traffic.  NC = velocity components processed per pass (3 when the LDS image of all three
 // fits, else 1).
+// Face-grouped slot of point (a, j, k) inside an element: x- face, x+ face, y- (without x faces), y+, z-, z+,
+// then the interior.  FG = false gives the natural ix-fastest index.
+template <int N, bool FG>
+__device__ __forceinline__ int elem_slot(int a, int j, int k) {
+    if (!FG) return a + N * (j + N * k);
+    constexpr int M = N - 2, F = N * N;
+    if (a == 0) return j + N * k;
+    if (a == N - 1) return F + j + N * k;
+    if (j == 0) return 2 * F + (a - 1) + M * k;
+    if (j == N - 1) return 2 * F + M * N + (a - 1) + M * k;
+    if (k == 0) return 2 * F + 2 * M * N + (a - 1) + M * (j - 1);
+    if (k == N - 1) return 2 * F + 2 * M * N + M * M + (a - 1) + M * (j - 1);
+    return 2 * F + 2 * M * N + 2 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
+}
+
 template <int N>
 struct PMats {
     double It[N * (N - 2)];   // I12^T  (N x N2 row-major)
@@ -570,7 +585,7 @@ struct PMats {
 };
 
 // opgradt: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise)
-template <int N, int NC>
+template <int N, int NC, bool FG>
 __global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
@@ -648,20 +663,21 @@ __global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, c
                 b0[i2] = sB[ci * 2 + 0][i2 + N2 * bc];
                 b1[i2] = sB[ci * 2 + 1][i2 + N2 * bc];
             }
-            double *wp = (i == 0 ? w.p[0] : (i == 1 ? w.p[1] : w.p[2])) + e * NP1 + (int64_t)N * bc;
+            double *wp = (i == 0 ? w.p[0] : (i == 1 ? w.p[1] : w.p[2])) + e * NP1;
+            const int jj = bc % N, kk = bc / N;
 #pragma unroll
             for (int a = 0; a < N; ++a) {
                 double v = 0.0;
 #pragma unroll
                 for (int i2 = 0; i2 < N2; ++i2) v += M.Dt[a * N2 + i2] * b0[i2] + M.It[a * N2 + i2] * b1[i2];
-                wp[a] = v;
+                wp[elem_slot<N, FG>(a, jj, kk)] = v;
             }
         }
     }
 }
 
 // opdiv: out = scale * sum_i sum_j g_ji o (T_j (wt_i o u_i)); wt (may hold nulls) fuses mask * binvm1 into the load
-template <int N, int NC>
+template <int N, int NC, bool FG>
 __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
                                                double scale) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
@@ -681,15 +697,19 @@ __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3
         // x stage from HBM: B0 = D_x u, B1 = I_x u   (columns over (j, k); N contiguous doubles per thread)
         for (int t = tid; t < NC * N * N; t += NT) {
             const int ci = t / (N * N), bc = t % (N * N), i = c0 + ci;
-            const double *up = (i == 0 ? u.p[0] : (i == 1 ? u.p[1] : u.p[2])) + e * NP1 + (int64_t)N * bc;
+            const double *up = (i == 0 ? u.p[0] : (i == 1 ? u.p[1] : u.p[2])) + e * NP1;
             const double *wp = (i == 0 ? wt.p[0] : (i == 1 ? wt.p[1] : wt.p[2]));
+            const int jj = bc % N, kk = bc / N;
+            int sl[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) sl[a] = elem_slot<N, FG>(a, jj, kk);
             double uu[N];
 #pragma unroll
-            for (int a = 0; a < N; ++a) uu[a] = up[a];
+            for (int a = 0; a < N; ++a) uu[a] = up[sl[a]];
             if (wp) {
-                wp += e * NP1 + (int64_t)N * bc;
+                wp += e * NP1;
 #pragma unroll
-                for (int a = 0; a < N; ++a) uu[a] *= wp[a];
+                for (int a = 0; a < N; ++a) uu[a] *= wp[sl[a]];
             }
 #pragma unroll
             for (int i2 = 0; i2 < N2; ++i2) {
@@ -1142,7 +1162,7 @@ static CF9 rst2w_ptrs(const nlg_mesh *m) {
     return g;
 }
 
-int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped) {
     ProfScope ps(m->ctx, P_OPGRADT);
     F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
@@ -1152,10 +1172,14 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
-        if (N_ <= 8)                                                                                                   \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);          \
+        if (N_ <= 8 && face_grouped)                                                                                   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);    \
+        else if (N_ <= 8)                                                                                              \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);   \
+        else if (face_grouped)                                                                                         \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);    \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);          \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);   \
     }
         NLG_FOR_N(GT3)
 #undef GT3
@@ -1173,7 +1197,7 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w) {
     return 0;
 }
 
-int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts) {
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts, bool face_grouped) {
     ProfScope ps(m->ctx, P_OPDIV);
     CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
     CF3 wt = {{wts ? wts[0] : nullptr, wts ? wts[1] : nullptr, (wts && m->dim == 3) ? wts[2] : nullptr}};
@@ -1184,10 +1208,14 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
-        if (N_ <= 8)                                                                                                   \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+        if (N_ <= 8 && face_grouped)                                                                                   \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale);  \
+        else if (N_ <= 8)                                                                                              \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+        else if (face_grouped)                                                                                         \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
     }
         NLG_FOR_N(DV3)
 #undef DV3
@@ -1221,6 +1249,20 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out) {
     double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
     NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
+    if (m->dim == 3 && !m->halo.active && m->gs.d_indices_fg) {
+        // single rank, 3-D: the intermediate velocity-mesh fields use the face-grouped element layout, in which
+        // the copies of a shared face are contiguous runs -> coalesced gather-scatter
+        NLG_TRY(sem_opgradt(m, p, w, true));
+        if (m->gs.ngroups > 0) {
+            ProfScope ps(m->ctx, P_GS);
+            F3 f = {{w[0], w[1], w[2]}};
+            const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, f);
+            NLG_HIP(hipGetLastError());
+        }
+        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true));
+        return 0;
+    }
     NLG_TRY(sem_opgradt(m, p, w));
     NLG_TRY(sem_gs(m, w, m->dim));
     NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv));   // mask * binvm1 fused into the load
@@ -1512,6 +1554,39 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         }
         m->gs.ngroups = (int64_t)groups.size();
         m->gs.nshared = (int64_t)idx.size();
+        if (dim == 3 && !groups.empty()) {
+            // the same groups in face-grouped numbering, re-sorted by their first index
+            const int M2 = n - 2, F = n * n;
+            std::vector<int> slot((size_t)m->np1);
+            for (int p = 0; p < m->np1; ++p) {
+                const int a = p % n, j = (p / n) % n, k = p / (n * n);
+                int sl;
+                if (a == 0) sl = j + n * k;
+                else if (a == n - 1) sl = F + j + n * k;
+                else if (j == 0) sl = 2 * F + (a - 1) + M2 * k;
+                else if (j == n - 1) sl = 2 * F + M2 * n + (a - 1) + M2 * k;
+                else if (k == 0) sl = 2 * F + 2 * M2 * n + (a - 1) + M2 * (j - 1);
+                else if (k == n - 1) sl = 2 * F + 2 * M2 * n + M2 * M2 + (a - 1) + M2 * (j - 1);
+                else sl = 2 * F + 2 * M2 * n + 2 * M2 * M2 + (a - 1) + M2 * ((j - 1) + M2 * (k - 1));
+                slot[p] = sl;
+            }
+            m->h_slot = slot;
+            std::vector<std::vector<int>> gl(groups.size());
+            for (size_t gi = 0; gi + 1 < off.size(); ++gi) {
+                for (int q = off[gi]; q < off[gi + 1]; ++q) gl[gi].push_back((idx[q] / m->np1) * m->np1 + slot[idx[q] % m->np1]);
+                std::sort(gl[gi].begin(), gl[gi].end());
+            }
+            std::sort(gl.begin(), gl.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a[0] < b[0]; });
+            std::vector<int> off2{0}, idx2;
+            for (auto &v : gl) {
+                idx2.insert(idx2.end(), v.begin(), v.end());
+                off2.push_back((int)idx2.size());
+            }
+            NLG_HIP(hipMalloc(&m->gs.d_offsets_fg, sizeof(int) * off2.size()));
+            NLG_HIP(hipMalloc(&m->gs.d_indices_fg, sizeof(int) * idx2.size()));
+            NLG_HIP(hipMemcpy(m->gs.d_offsets_fg, off2.data(), sizeof(int) * off2.size(), hipMemcpyHostToDevice));
+            NLG_HIP(hipMemcpy(m->gs.d_indices_fg, idx2.data(), sizeof(int) * idx2.size(), hipMemcpyHostToDevice));
+        }
         NLG_HIP(hipMalloc(&m->gs.d_offsets, sizeof(int) * off.size()));
         NLG_HIP(hipMalloc(&m->gs.d_indices, sizeof(int) * std::max<size_t>(idx.size(), 1)));
         NLG_HIP(hipMemcpy(m->gs.d_offsets, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
@@ -1531,6 +1606,17 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         for (int c = 0; c < dim; ++c)
             hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_mbinv[c], m->d_mask[c], m->d_binvm1, m->lvn);
         NLG_HIP(hipGetLastError());
+        if (dim == 3 && !m->h_slot.empty()) {
+            std::vector<double> h((size_t)m->lvn), hp((size_t)m->lvs, 0.0);
+            for (int c = 0; c < dim; ++c) {
+                NLG_HIP(hipMemcpyAsync(h.data(), m->d_mbinv[c], sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, s));
+                NLG_HIP(hipStreamSynchronize(s));
+                for (int64_t e = 0; e < m->E; ++e)
+                    for (int p = 0; p < m->np1; ++p) hp[(size_t)e * m->np1 + m->h_slot[p]] = h[(size_t)e * m->np1 + p];
+                NLG_HIP(hipMalloc(&m->d_mbinv_fg[c], sizeof(double) * (size_t)m->lvs));
+                NLG_HIP(hipMemcpy(m->d_mbinv_fg[c], hp.data(), sizeof(double) * (size_t)m->lvs, hipMemcpyHostToDevice));
+            }
+        }
     }
 
     // ---- pressure-mesh and fine-mesh metrics
@@ -1625,6 +1711,10 @@ int nlg_mesh_destroy(nlg_mesh *m) {
     if (m->d_lglel) hipFree(m->d_lglel);
     halo_free(m);
     pprec_free(m);
+    if (m->gs.d_offsets_fg) hipFree(m->gs.d_offsets_fg);
+    if (m->gs.d_indices_fg) hipFree(m->gs.d_indices_fg);
+    for (int c = 0; c < 3; ++c)
+        if (m->d_mbinv_fg[c]) hipFree(m->d_mbinv_fg[c]);
     if (m->gs.d_offsets) hipFree(m->gs.d_offsets);
     if (m->gs.d_indices) hipFree(m->gs.d_indices);
     for (double *p : m->scratch1) hipFree(p);
