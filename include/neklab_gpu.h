@@ -128,8 +128,13 @@ int nlg_vec_nrst(const nlg_vec *self, int *out);
  * array and the vector.  field = NLG_VX.., irst = 0 main field, 1..lorder-1 history slot. */
 int nlg_vec_set_field(nlg_vec *self, int field, int irst, const double *host, int64_t count);
 int nlg_vec_get_field(const nlg_vec *self, int field, int irst, double *host, int64_t count);
-/* 0: reproduce real_vectors.f90:188-192 (history += alpha * vec's MAIN field) -- default;
- * 1: mathematically consistent (history += alpha * vec's history). Process-wide switch. */
+/* Restart history in axpby / block updates.
+ * 1 (default): history slot r of self receives alpha * (history slot r of vec).
+ * 0           : literal reading of real_vectors.f90:188-192: every slot receives alpha * vec's MAIN field.
+ * The literal reading does not reproduce the reference's own known answer (cylinder Re = 50, |mu_1| = 1.0156
+ * +- 1e-4, test/neklabTests.py:43-45): it gives 1.0194 (dt = 0.01) / 1.0177 (dt = 0.005), an O(dt) pollution of
+ * the BDF start-up of every matvec, while mode 1 gives 1.01578 independent of dt.
+ * Process-wide switch. */
 int nlg_set_axpby_rst_consistent(int flag);
 
 /* ---------------------------------------------------------------------------------------------- */

@@ -97,9 +97,18 @@ class NekDVector:
                 a *= alpha
 
     # -- reference: real_vectors.f90:162-206
-    def axpby(self, alpha, vec, beta, consistent_rst=False):
-        """self <- alpha*vec + beta*self.  History slots receive alpha * vec's MAIN field
-        (reference behaviour, real_vectors.f90:188-192) unless consistent_rst=True."""
+    # Default treatment of the restart history in axpby.  A literal reading of real_vectors.f90:188-192 adds
+    # alpha * vec's MAIN field to every history slot (CONSISTENT_RST = False).  With that reading the reference's
+    # own known answer is NOT reproduced (cylinder Re = 50: |mu_1| = 1.0194 at dt = 0.01, 1.0177 at dt = 0.005,
+    # an O(dt) pollution), whereas combining vec's history slots gives 1.01578, dt-independent, against the
+    # published 1.0156 +- 1e-4 (test/neklabTests.py:43-45; scripts/cyl_sens.py).  The default therefore is the
+    # variant that reproduces the reference's published output; the literal one stays available.
+    CONSISTENT_RST = True
+
+    def axpby(self, alpha, vec, beta, consistent_rst=None):
+        """self <- alpha*vec + beta*self on all fields and on the nrst valid history slots of self."""
+        if consistent_rst is None:
+            consistent_rst = NekDVector.CONSISTENT_RST
         self.scal(beta)
         for a, b in zip(self.main_fields(), vec.main_fields()):
             a += alpha * b

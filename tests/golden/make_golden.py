@@ -81,7 +81,7 @@ def generate(case):
     out["dot"] = np.array(a.dot(b))
     out["size"] = np.array(a.get_size())
     a.save_rst(b, 1)
-    a.axpby(0.3, b, -1.7)
+    a.axpby(0.3, b, -1.7, consistent_rst=False)     # literal reading of real_vectors.f90:188-192
     a.scal(1.0 / 3.0)
     out["axpby_v"] = np.stack(a.v)
     out["axpby_pr"] = a.pr

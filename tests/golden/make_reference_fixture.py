@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Extracts a DATA fixture from the reference's own test case (no reference source is copied):
+/root/reference/examples/cylinder/stability/direct/BF_1cyl0.f00001 -- the Nek5000 base-flow field file
+(format "#std 8 6 6 1 1996 ..."; fields X, U, P in fp64) that the reference's only integration test loads
+(test/neklabTests.py:16-47, 1cyl.usr:15).  It is the output of Nek5000's own discretisation: a steady
+Navier-Stokes solution at Re = 50 on the curved cylinder mesh.  tests/test_cpu_reference_data.py checks the
+oracle's operators against it (discrete divergence ~1e-11, steady momentum residual ~1e-7).
+
+Run from the repo root (needs /root/reference):  python tests/golden/make_reference_fixture.py
+"""
+import os
+
+import numpy as np
+
+SRC = "/root/reference/examples/cylinder/stability/direct/BF_1cyl0.f00001"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_cyl_baseflow.npz")
+
+
+def read_fld(path):
+    raw = open(path, "rb").read()
+    hdr = raw[:132].decode().split()
+    wd, nx, ny, nz, nel = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4]), int(hdr[5])
+    assert hdr[0] == "#std" and hdr[11] == "XUP" and nz == 1
+    assert abs(np.frombuffer(raw[132:136], dtype=np.float32)[0] - 6.54321) < 1e-5    # endianness tag
+    off = 136 + 4 * nel
+    dt = np.float64 if wd == 8 else np.float32
+    npt = nx * ny * nz
+
+    def rd(nc):
+        nonlocal off
+        a = np.frombuffer(raw[off: off + wd * nel * nc * npt], dtype=dt).reshape(nel, nc, npt)
+        off += wd * nel * nc * npt
+        return a.astype(np.float64)
+
+    X, U, P = rd(2), rd(2), rd(1)
+    return nx, X, U, P
+
+
+if __name__ == "__main__":
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from neklab_amd.nekio import read_fld as rf, read_re2_bcs
+    n, X, U, P = read_fld(SRC)
+    elmap = rf(SRC)["elmap"]
+    nel, dim, bcs = read_re2_bcs(SRC.replace("BF_1cyl0.f00001", "1cyl.re2"))
+    assert nel == X.shape[0] and dim == 2
+    np.savez_compressed(OUT, n=np.array(n), x=X[:, 0], y=X[:, 1], ux=U[:, 0], uy=U[:, 1], p=P[:, 0],
+                        re=np.array(50.0), lxd=np.array(9), elmap=elmap,
+                        bc_elem=np.array([b[0] for b in bcs]), bc_face=np.array([b[1] for b in bcs]),
+                        bc_tag=np.array([b[2] for b in bcs]))
+    print(OUT, os.path.getsize(OUT), "bytes")

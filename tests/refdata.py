@@ -1,0 +1,39 @@
+"""Shared loader for the reference-data fixture (tests/golden/reference_cyl_baseflow.npz)."""
+import os
+
+import numpy as np
+
+from neklab_amd.mesh import BoxMesh
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_cylinder(with_bcs=False):
+    """with_bcs=False: connectivity from coincident coordinates only, no masks (operator-level checks).
+    with_bcs=True : the boundary conditions of 1cyl.re2 applied: 'v' / 'W' faces Dirichlet-masked, 'O' natural,
+    'P' faces (y = -16 <-> y = +16) identified in the global numbering."""
+    from neklab_amd.nekio import face_nodes
+    d = np.load(os.path.join(HERE, "golden", "reference_cyl_baseflow.npz"))
+    n = int(d["n"])
+    x, y = d["x"].copy(), d["y"].copy()
+    E = x.shape[0]
+    yk = y.copy()
+    if with_bcs:
+        yk = np.where(np.abs(y - 16.0) < 1e-9, -16.0, y)      # periodic identification
+    # global numbering from coincident coordinates (the field file carries no connectivity)
+    key = np.round(np.stack([x.ravel(), yk.ravel()], 1) / 1e-8).astype(np.int64)
+    _, glo = np.unique(key, axis=0, return_inverse=True)
+    ones = np.ones((E, n * n))
+    mask = [ones.copy(), ones.copy()]
+    if with_bcs:
+        pos = {int(g): k for k, g in enumerate(d["elmap"])}    # global element id -> position in the field file
+        for ge, fc, tag in zip(d["bc_elem"], d["bc_face"], d["bc_tag"]):
+            if str(tag) in ("v", "W"):
+                nodes = face_nodes(n, 2, int(fc))
+                for m in mask:
+                    m[pos[int(ge)], nodes] = 0.0
+    hm = BoxMesh(dim=2, n=n, nel=(E, 1), x=x, y=y, z=None, glo_num=glo.reshape(E, n * n).astype(np.int64),
+                 mask=mask, tmask=ones.copy(), has_outflow=True, elem_gid=np.arange(E, dtype=np.int64))
+    rr = np.hypot(x, y)
+    interior = (x > -16 + 1e-6) & (x < 50 - 1e-6) & (np.abs(y) < 16 - 1e-6) & (rr > 0.5 + 1e-6)
+    return hm, d["ux"].copy(), d["uy"].copy(), d["p"].copy(), float(d["re"]), int(d["lxd"]), interior

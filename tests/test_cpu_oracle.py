@@ -110,13 +110,21 @@ def test_vector_space_matches_golden_and_reference_semantics():
     a.save_rst(b, 1)
     with pytest.raises(ValueError):
         a.save_rst(b, 3)                                  # irst == torder is an error (:264-267)
-    a.axpby(0.3, b, -1.7)
+    a.axpby(0.3, b, -1.7, consistent_rst=False)
     a.scal(1.0 / 3.0)
     assert np.array_equal(np.stack(a.v), g["axpby_v"]) and np.array_equal(a.pr, g["axpby_pr"])
     assert np.array_equal(a.theta[0], g["axpby_theta"])
     # the history slot received alpha * vec's MAIN field (real_vectors.f90:188-192)
     expect = (b.v[0] * (-1.7) + 0.3 * b.v[0]) * (1.0 / 3.0)
     assert np.allclose(a.v_rst[0][0], g["axpby_rst1_v"][0]) and np.allclose(a.v_rst[0][0], expect)
+    # default (consistent) treatment: the slot receives alpha * vec's slot
+    c2, d2 = NekDVector(sem, 1), NekDVector(sem, 1)
+    c2.v[0][...] = 1.0
+    d2.v[0][...] = 2.0
+    c2.save_rst(c2, 1)
+    d2.save_rst(c2, 1)
+    c2.axpby(0.5, d2, 1.0)
+    assert np.allclose(c2.v[0], 2.0) and np.allclose(c2.v_rst[0][0], 1.5)
     a.zero()
     assert a.nrst == 0 and a.norm() == 0.0
 

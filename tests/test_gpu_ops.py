@@ -123,6 +123,15 @@ def test_vector_space(gpu_ctx, case):
     assert ga.nrst == 2 and ga.has_rst_fields()
     with pytest.raises(host.NlgError):
         ga.save_rst(gb, 3)
+    # both treatments of the history in axpby (include/neklab_gpu.h: nlg_set_axpby_rst_consistent), bit-exact
+    for mode in (0, 1):
+        host.check(gm.lib.nlg_set_axpby_rst_consistent(mode))
+        g2, o2 = ga.copy(), oa.copy()
+        g2.axpby(0.25, gb, 2.0); o2.axpby(0.25, ob, 2.0, consistent_rst=bool(mode))
+        for r in (1, 2):
+            assert np.array_equal(g2.get_field(0, r), o2.v_rst[r - 1][0].ravel())
+    host.check(gm.lib.nlg_set_axpby_rst_consistent(1))
+    gb.save_rst(ga, 1); ob.save_rst(oa, 1)
     ga.axpby(0.3, gb, -1.7); oa.axpby(0.3, ob, -1.7)
     ga.scal(1.0 / 3.0); oa.scal(1.0 / 3.0)
     for i in range(sem.dim):
