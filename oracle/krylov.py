@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure only) -- Arnoldi / Krylov-Schur eigensolver over the abstract
 vector API, restated in numpy.  Never imported by the product.
 
-PARITY UNPINNED: the algorithm is LightKrylov's `eigs` (nekStab/LightKrylov @ main, un-pinned,
+PARITY UNPINNED at the level of LightKrylov's internals (restart policy, selection); the converged eigenvalues do
+not depend on them and are pinned end to end.  The algorithm is LightKrylov's `eigs` (nekStab/LightKrylov @ main, un-pinned,
 /root/reference/LightKrylov_setup.sh:55-57), absent from `/root/reference`.  Its call site and the
 post-processing ARE in the tree and are followed here:
 /root/reference/src/neklab_analysis.f90:77-93 (`zero_basis`, `eigs(exptA, eigvecs, eigvals, residuals,

@@ -9,8 +9,10 @@ In-tree protocol followed (what the reference DOES pin):
   at exponential_propagator.f90:9-12),
 * operator terms of L (/root/reference/src/linops/neklab_linops.f90:268-426).
 
-PARITY UNPINNED for the time integrator itself: `nek_advance` is Nek5000 code (absent, un-pinned).  It
-is restated from the published Pn-Pn-2 BDFk/EXTk splitting (Fischer 1997; Deville-Fischer-Mund ch. 6):
+The time integrator itself (`nek_advance`) is Nek5000 code (absent, un-pinned); no fixture pins it step by
+step.  End to end it is pinned by the reference's published eigenvalue (cylinder Re = 50: 1.015780 here vs
+1.0156 +- 1e-4, tests/test_gpu_known_answer.py) and by the Orr-Sommerfeld value for Poiseuille flow
+(DESIGN.md section 2).  It is restated from the published Pn-Pn-2 BDFk/EXTk splitting (Fischer 1997; Deville-Fischer-Mund ch. 6):
 tentative Helmholtz solve in residual form with the lagged pressure, consistent-Poisson pressure
 correction, velocity update.  Solver details that Nek5000 hides (one joint Jacobi-PCG over the
 velocity components, Jacobi-PCG on E) are this project's own and are documented in DESIGN.md.

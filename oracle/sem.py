@@ -2,10 +2,12 @@
 neklab hot path.  Never imported by the product (`neklab_amd/`); only `tests/`, `bench.py`'s
 cpu_baseline leg and `__graft_entry__.smoke()` may use it.
 
-PARITY UNPINNED: the arithmetic of this layer lives in Nek5000 (un-vendored, un-pinned,
-`/root/reference/Nek5000_setup.sh:56-58`), absent from `/root/reference`.  What the reference tree
-does pin is *which* operators are composed and how (citations below); the operators themselves are
-restated from the published Nek5000 algorithm (Deville, Fischer & Mund 2002; Fischer 1997):
+PARITY PINNED AGAINST REFERENCE DATA (not against reference code): the arithmetic of this layer lives in
+Nek5000 (un-vendored, un-pinned, `/root/reference/Nek5000_setup.sh:56-58`), absent from `/root/reference`, so it
+is restated from the published algorithm (Deville, Fischer & Mund 2002; Fischer 1997).  The restatement is
+checked against the Nek5000-generated base flow the reference ships (tests/test_cpu_reference_data.py: discrete
+divergence 6e-12, steady momentum residual 2e-7 with these operators) -- see DESIGN.md section 2.  What the
+reference tree itself pins is *which* operators are composed and how:
 
 * Laplacian as `grad -> metric -> grad^T` with `rxm1..tzm1`, `jacmi`
   (reference: src/linops/neklab_linops.f90:332-366 `lap_1D`),
