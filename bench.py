@@ -134,7 +134,7 @@ def main():
     ctx.sync()
     setup_s = time.time() - t0
     H = np.zeros((m + 2, m + 1), order="F")
-    names = ["axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops"]
+    names = ["axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops", "pprec"]
 
     def step():
         host.arnoldi_step(A, B, m - 1, H)

@@ -142,6 +142,9 @@ int nlg_ctx_create(int device, nlg_ctx **out) {
     nlg_ctx *ctx = new nlg_ctx();
     ctx->device = device;
     NLG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    NLG_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    NLG_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    NLG_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     ctx->n_scalars = 4096;
     NLG_HIP(hipMalloc(&ctx->d_scalars, sizeof(double) * ctx->n_scalars));
     NLG_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(double) * ctx->n_scalars, ctx->stream));
@@ -159,6 +162,9 @@ int nlg_ctx_destroy(nlg_ctx *ctx) {
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->d_scalars) hipFree(ctx->d_scalars);
     if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

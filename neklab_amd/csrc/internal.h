@@ -70,6 +70,8 @@ struct nlg_ctx {
     nlg_prof_slot prof[P_COUNT];
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: coarse-grid branch of the pressure preconditioner
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     // reduction workspace
@@ -223,7 +225,8 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
 
 // ---- pprec.hip ----
 int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d);
-int pprec_apply(nlg_mesh *m, const double *flag, const double *r, double *z);
+int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc);
+int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z);
 void pprec_free(nlg_mesh *m);
 
 // ---- halo.hip ----

@@ -163,17 +163,20 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
 }
 
 // partial sums of (r,z)_ipw and sum(z) when z was produced by a preconditioning operator
+// `xc`/`npe` (xc may be null): the coarse-grid part of z, one value per element of npe points, kept separate so
+// that the coarse branch can run concurrently with the element-wise solves: z_total = z + xc[i / npe]
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_rz(const double *s, int gate, int64_t n, CF3 r, CF3 z, const double *ipw,
-                                              double *partial) {
+                                              const double *xc, int npe, double *partial) {
     __shared__ double sm[8];
     if (gate && s[S_DONE] != 0.0) return;
     double a = 0.0, b = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double wi = ipw ? ipw[i] : 1.0;
+        const double xv = xc ? xc[i / npe] : 0.0;
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
-            const double zv = z.p[c][i];
+            const double zv = z.p[c][i] + xv;
             a += r.p[c][i] * zv * wi;
             b += zv;
         }
@@ -186,12 +189,13 @@ __global__ __launch_bounds__(NT) void k_cg_rz(const double *s, int gate, int64_t
 }
 
 template <int NF>
-__global__ __launch_bounds__(NT) void k_cg_pupdate(const double *s, int64_t n, F3 p, CF3 z) {
+__global__ __launch_bounds__(NT) void k_cg_pupdate(const double *s, int64_t n, F3 p, CF3 z, const double *xc, int npe) {
     if (s[S_DONE] != 0.0) return;
     const double beta = s[S_BETA], zmean = s[S_ZMEAN];
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double xv = xc ? xc[i / npe] : 0.0;
 #pragma unroll
-        for (int c = 0; c < NF; ++c) p.p[c][i] = (z.p[c][i] - zmean) + beta * p.p[c][i];
+        for (int c = 0; c < NF; ++c) p.p[c][i] = (z.p[c][i] + xv - zmean) + beta * p.p[c][i];
     }
 }
 
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_cg_final(const double *s, const double *
 
 // scalar logic, one thread. mode 0: after init (T0 = rz, T1 = rn2, T2 = sum z) ; 1: after pw (T0 = pw, T1 = sum w) ;
 // 2: after update (T0 = rz, T1 = rn2, T2 = sum z).  inv_n = 1/n for the projected solve, 0 otherwise.
-__global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n) {
+__device__ __forceinline__ void cg_post_logic(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n) {
     if (mode != 0 && s[S_DONE] != 0.0) return;
     if (mode == 0) {
         s[S_RZ] = s[S_T0];
@@ -220,7 +224,7 @@ __global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int max
         s[S_WMEAN] = 0.0;
         s[S_BETA] = 0.0;
         s[S_ITERS] = 0.0;
-        s[S_DONE] = 0.0;     // the first p-update must run; the convergence test happens in k_cg_post0b
+        s[S_DONE] = 0.0;     // the first p-update must run; the convergence test happens in mode 3
     } else if (mode == 3) {
         s[S_RN20] = s[S_RN2];
         s[S_DONE] = ((use_tol && s[S_RN2] < tol2) || maxit <= 0 || s[S_RN2] <= 0.0) ? 1.0 : 0.0;
@@ -236,6 +240,25 @@ __global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int max
         s[S_ITERS] += 1.0;
         if ((use_tol && s[S_T1] < tol2) || s[S_ITERS] >= (double)maxit || s[S_T1] <= kFloor2 * s[S_RN20]) s[S_DONE] = 1.0;
     }
+}
+
+__global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n) {
+    cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
+}
+
+// single rank: second-stage reduction and scalar logic in one launch (no all-reduce in between)
+__global__ __launch_bounds__(NT) void k_cg_final_post(double *s, const double *partial, int nblk, int nsums, int gate,
+                                                      int mode, double tol2, int use_tol, int maxit, double inv_n) {
+    __shared__ double sm[8];
+    if (gate && s[S_DONE] != 0.0) return;
+    for (int q = 0; q < nsums; ++q) {
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += NT) a += partial[q * NB + i];
+        block_sum2(a, b, sm);
+        if (threadIdx.x == 0) s[S_T0 + q] = a;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
 }
 
 // generic pointwise helpers
@@ -385,7 +408,9 @@ struct CGProblem {
     double *s;           // device scalars
     int chunk;
     double inv_n;        // 1/n for the mean-free projected solve, 0 = no projection
-    std::function<int(const double *flag, const double *r, double *z)> precond;   // non-pointwise M^-1 (nf = 1)
+    // non-pointwise M^-1 (nf = 1): writes the element-wise part to z and returns the coarse part per element in *xc
+    std::function<int(const double *flag, const double *r, double *z, const double **xc)> precond;
+    int npe = 1;         // points per element (for the per-element coarse part)
 };
 
 // Generic device-scalar PCG. `apply` computes w = A p (must itself be stream-ordered and may be gated
@@ -402,15 +427,25 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     (void)x;
     CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf);
     CF3 cr = cf3(P.r, nf);
+    auto reduce_post = [&](int nsums, int gate, int mode) -> int {
+        if (!ctx->comm) {
+            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NT), 0, st, s, (const double *)partial, g, nsums, gate, mode,
+                               P.tol2, P.use_tol, P.maxit, P.inv_n);
+        } else {
+            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, nsums, s + S_T0, gate);
+            NLG_TRY(allreduce_sum(ctx, s + S_T0, nsums));
+            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n);
+        }
+        return 0;
+    };
     launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
+    const double *xc = nullptr;
     if (P.precond) {
-        NLG_TRY(P.precond(nullptr, P.r[0], P.z[0]));
-        launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, partial);
+        NLG_TRY(P.precond(nullptr, P.r[0], P.z[0], &xc));
+        launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, xc, P.npe, partial);
     }
-    hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 3, s + S_T0, 0);
-    NLG_TRY(allreduce_sum(ctx, s + S_T0, 3));
-    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 0, P.tol2, P.use_tol, P.maxit, P.inv_n);
-    launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz);   // p = z - zmean
+    NLG_TRY(reduce_post(3, 0, 0));
+    launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
     hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
     int launched = 0;
     int iters = 0;
@@ -421,20 +456,16 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
             NLG_TRY(apply(s));
             if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
-            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 2, s + S_T0, 1);
-            NLG_TRY(allreduce_sum(ctx, s + S_T0, 2));
-            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 1, P.tol2, P.use_tol, P.maxit, P.inv_n);
+            NLG_TRY(reduce_post(2, 1, 1));
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
                       pc, P.ipw, P.nw, partial);
             if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
             if (P.precond) {
-                NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0]));
-                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, partial);
+                NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
+                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
             }
-            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, 3, s + S_T0, 1);
-            NLG_TRY(allreduce_sum(ctx, s + S_T0, 3));
-            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 2, P.tol2, P.use_tol, P.maxit, P.inv_n);
-            launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz);
+            NLG_TRY(reduce_post(3, 1, 2));
+            launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
         }
         launched += todo;
         NLG_HIP(hipGetLastError());
@@ -513,7 +544,17 @@ int pres_solve(nlg_linop *op, double scale) {
     double *nopc[1] = {nullptr};
     if (c.pprecond == 0) {   // two-level FDM + coarse V-cycle (pprec.hip); 1 = Jacobi on diag(E), as in the oracle
         P.pc = nopc;
-        P.precond = [m](const double *flag, const double *rr, double *zz) -> int { return pprec_apply(m, flag, rr, zz); };
+        P.npe = m->np2;
+        P.precond = [m](const double *flag, const double *rr, double *zz, const double **xc) -> int {
+            // one stream: a fork/join through events costs more than it hides (measured: 98 vs 84 us per apply)
+            nlg_ctx *c = m->ctx;
+            ProfScope ps(c, P_PPREC);
+            const double *coarse = nullptr;
+            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse));
+            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz));   // z = FDM(r) + coarse[e]
+            *xc = nullptr;
+            return 0;
+        };
     }
     P.chunk = std::max(8, std::min(op->last_piters / 4 + 1, 64));
     auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w); };

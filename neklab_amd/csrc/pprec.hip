@@ -48,47 +48,84 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
 }
 
 // z_e = (Sz x Sy x Sx) [ invden o ((Sz x Sy x Sx)^T r_e) ] + xc[e]      (S stored row-major [point][mode])
+// One wave per element, four elements per block: the six 1-D transforms of an element are tiny (N2^3 points), so
+// the kernel is bound by launch/barrier latency, not by bytes; each lane owns whole columns and keeps them in
+// registers between the load and the N2 outputs.
+template <int N2, int DIM, bool FWD, int AX>
+__device__ __forceinline__ void fdm_stage(const double *__restrict__ in, double *__restrict__ out,
+                                          const double *__restrict__ S, int lane) {
+    constexpr int NZ = DIM == 3 ? N2 : 1;
+    constexpr int NCOL = (N2 * N2 * NZ) / N2;
+    for (int col = lane; col < NCOL; col += 64) {
+        // column base index and stride along axis AX of an [NZ][N2][N2] array
+        int base, stride;
+        if (AX == 0) {
+            base = col * N2;
+            stride = 1;
+        } else if (AX == 1) {
+            base = (col % N2) + N2 * N2 * (col / N2);
+            stride = N2;
+        } else {
+            base = col;
+            stride = N2 * N2;
+        }
+        double v[N2];
+#pragma unroll
+        for (int l = 0; l < N2; ++l) v[l] = in[base + stride * l];
+#pragma unroll
+        for (int o = 0; o < N2; ++o) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N2; ++l) a += (FWD ? S[l * N2 + o] : S[o * N2 + l]) * v[l];
+            out[base + stride * o] = a;
+        }
+    }
+}
+
 template <int N2, int DIM>
 __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                             const double *__restrict__ invden, const double *__restrict__ r,
                                             const double *__restrict__ xc, double *__restrict__ z) {
     constexpr int NP = DIM == 3 ? N2 * N2 * N2 : N2 * N2;
-    constexpr int NZ = DIM == 3 ? N2 : 1;
-    __shared__ double sS[3][N2 * N2];
-    __shared__ double sA[NP], sB[NP];
+    __shared__ double sS[4][3][N2 * N2];
+    __shared__ double sA[4][NP], sB[4][NP];
     if (flag && flag[0] != 0.0) return;
-    const int tid = threadIdx.x;
-    const int64_t e = blockIdx.x;
-    for (int q = tid; q < DIM * N2 * N2; q += NT) sS[q / (N2 * N2)][q % (N2 * N2)] = S[e * (3 * N2 * N2) + q];
-    for (int q = tid; q < NP; q += NT) sA[q] = r[e * NP + q];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 4 + wv;
+    const bool act = e < E;
+    const int64_t ee = act ? e : 0;
+    for (int q = lane; q < DIM * N2 * N2; q += 64) sS[wv][q / (N2 * N2)][q % (N2 * N2)] = S[ee * (3 * N2 * N2) + q];
+    for (int q = lane; q < NP; q += 64) sA[wv][q] = r[ee * NP + q];
     __syncthreads();
-    // forward: modes = S^T points
-    contract<N2, N2, NZ, 0, N2, true>(sA, sB, sS[0], tid, NT);
+    fdm_stage<N2, DIM, true, 0>(sA[wv], sB[wv], sS[wv][0], lane);
     __syncthreads();
-    contract<N2, N2, NZ, 1, N2, true>(sB, sA, sS[1], tid, NT);
+    fdm_stage<N2, DIM, true, 1>(sB[wv], sA[wv], sS[wv][1], lane);
     __syncthreads();
     if constexpr (DIM == 3) {
-        contract<N2, N2, NZ, 2, N2, true>(sA, sB, sS[2], tid, NT);
+        fdm_stage<N2, DIM, true, 2>(sA[wv], sB[wv], sS[wv][2], lane);
         __syncthreads();
-        for (int q = tid; q < NP; q += NT) sB[q] *= invden[e * NP + q];
+        for (int q = lane; q < NP; q += 64) sB[wv][q] *= invden[ee * NP + q];
         __syncthreads();
-        contract<N2, N2, NZ, 2, N2, false>(sB, sA, sS[2], tid, NT);
+        fdm_stage<N2, DIM, false, 2>(sB[wv], sA[wv], sS[wv][2], lane);
         __syncthreads();
     } else {
-        for (int q = tid; q < NP; q += NT) sA[q] *= invden[e * NP + q];
+        for (int q = lane; q < NP; q += 64) sA[wv][q] *= invden[ee * NP + q];
         __syncthreads();
     }
-    contract<N2, N2, NZ, 1, N2, false>(sA, sB, sS[1], tid, NT);
+    fdm_stage<N2, DIM, false, 1>(sA[wv], sB[wv], sS[wv][1], lane);
     __syncthreads();
-    contract<N2, N2, NZ, 0, N2, false>(sB, sA, sS[0], tid, NT);
+    fdm_stage<N2, DIM, false, 0>(sB[wv], sA[wv], sS[wv][0], lane);
     __syncthreads();
-    const double c = xc ? xc[e] : 0.0;
-    for (int q = tid; q < NP; q += NT) z[e * NP + q] = sA[q] + c;
+    if (act) {
+        const double c = xc ? xc[e] : 0.0;
+        for (int q = lane; q < NP; q += 64) z[e * NP + q] = sA[wv][q] + c;
+    }
 }
 
 // rc[e] = sum of r over the pressure points of element e   (R_0 r)
 __global__ __launch_bounds__(NT) void k_restrict0(const double *__restrict__ flag, int64_t E, int np2,
-                                                  const double *__restrict__ r, double *__restrict__ rc) {
+                                                  const double *__restrict__ r, double *__restrict__ rc,
+                                                  const double *__restrict__ dinv, double om, double *__restrict__ x) {
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 4 + wid;
@@ -97,7 +134,10 @@ __global__ __launch_bounds__(NT) void k_restrict0(const double *__restrict__ fla
     for (int q = lane; q < np2; q += 64) a += r[e * np2 + q];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    if (lane == 0) rc[e] = a;
+    if (lane == 0) {
+        rc[e] = a;
+        x[e] = om * dinv[e] * a;   // first damped-Jacobi sweep from a zero guess
+    }
 }
 
 // x = om * dinv * b
@@ -108,27 +148,49 @@ __global__ void k_jac0(const double *flag, int64_t n, const double *dinv, const 
 }
 
 // mode 0: out = b - A x ; mode 1: x_new = x + om dinv (b - A x) written to out
-__global__ void k_spmv(const double *flag, int64_t n, const int *__restrict__ rp, const int *__restrict__ ci,
-                       const double *__restrict__ av, const double *__restrict__ x, const double *__restrict__ b,
-                       const double *__restrict__ dinv, double om, int mode, double *__restrict__ out) {
+// `xa`/`agg` (may be null): the aggregate-level correction, prolonged on the fly: x_eff = x + xa[agg].
+// Eight lanes per row: the ~27 scattered reads of a row are issued together instead of one after another.
+__global__ __launch_bounds__(NT) void k_spmv(const double *flag, int64_t n, const int *__restrict__ rp,
+                                             const int *__restrict__ ci, const double *__restrict__ av,
+                                             const double *__restrict__ x, const double *__restrict__ b,
+                                             const double *__restrict__ dinv, double om, int mode,
+                                             const double *__restrict__ xa, const int *__restrict__ agg,
+                                             double *__restrict__ out) {
     if (flag && flag[0] != 0.0) return;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int sub = threadIdx.x & 7;
+    const int64_t i = (blockIdx.x * (int64_t)NT + threadIdx.x) >> 3;
     double s = 0.0;
-    for (int q = rp[i]; q < rp[i + 1]; ++q) s += av[q] * x[ci[q]];
-    const double res = b[i] - s;
-    out[i] = mode == 0 ? res : x[i] + om * dinv[i] * res;
+    if (i < n) {
+        const int b0 = rp[i], e0 = rp[i + 1];
+        if (xa) {
+            for (int q = b0 + sub; q < e0; q += 8) s += av[q] * (x[ci[q]] + xa[agg[ci[q]]]);
+        } else {
+            for (int q = b0 + sub; q < e0; q += 8) s += av[q] * x[ci[q]];
+        }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (i < n && sub == 0) {
+        const double res = b[i] - s;
+        const double xi = xa ? x[i] + xa[agg[i]] : x[i];
+        out[i] = mode == 0 ? res : xi + om * dinv[i] * res;
+    }
 }
 
-// ra[a] = sum of rr over the members of aggregate a
-__global__ void k_agg_restrict(const double *flag, int na, const int *__restrict__ ap, const int *__restrict__ am,
-                               const double *__restrict__ rr, double *__restrict__ ra) {
+// ra[a] = sum of rr over the members of aggregate a, one wave per aggregate
+__global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na, const int *__restrict__ ap,
+                                                     const int *__restrict__ am, const double *__restrict__ rr,
+                                                     double *__restrict__ ra) {
     if (flag && flag[0] != 0.0) return;
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int a = blockIdx.x * 4 + wid;
     if (a >= na) return;
     double s = 0.0;
-    for (int q = ap[a]; q < ap[a + 1]; ++q) s += rr[am[q]];
-    ra[a] = s;
+    for (int q = ap[a] + lane; q < ap[a + 1]; q += 64) s += rr[am[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) ra[a] = s;
 }
 
 // xa = Ainv ra (dense, row-major), one wave per row
@@ -479,27 +541,35 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     return 0;
 }
 
-// z = M^-1 r ; `flag` (may be null) is the device convergence flag of the surrounding PCG
-int pprec_apply(nlg_mesh *m, const double *flag, const double *r, double *z) {
+// Coarse part of M^-1 r: xc[e] (one value per element) = V(A_c) R_0 r, launched on `st`.
+int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc) {
     nlg_pprec &P = m->pprec;
-    NLG_CHECK(P.ready, "pprec_apply: preconditioner not set up");
-    hipStream_t st = m->ctx->stream;
-    ProfScope ps(m->ctx, P_PPREC);
+    NLG_CHECK(P.ready, "pprec: preconditioner not set up");
     const int64_t E = m->E;
     const double om = 0.7;
-    const int gE = (int)((E + 255) / 256);
-    hipLaunchKernelGGL(k_restrict0, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->np2, r, P.d_rc);
-    hipLaunchKernelGGL(k_jac0, dim3(gE), dim3(256), 0, st, flag, E, P.d_dinv, P.d_rc, om, P.d_x);
-    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 0, P.d_t);
-    hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 255) / 256), dim3(256), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_t, P.d_ra);
+    const int gE = (int)((E * 8 + 255) / 256);   // eight lanes per row
+    hipLaunchKernelGGL(k_restrict0, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->np2, r, P.d_rc, P.d_dinv, om, P.d_x);
+    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 0,
+                       (const double *)nullptr, (const int *)nullptr, P.d_t);
+    hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_t, P.d_ra);
     hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_Ainv, P.d_ra, P.d_xa);
-    hipLaunchKernelGGL(k_prolong_add, dim3(gE), dim3(256), 0, st, flag, E, P.d_agg, P.d_xa, P.d_x);
-    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 1, P.d_t);
+    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 1,
+                       (const double *)P.d_xa, (const int *)P.d_agg, P.d_t);
+    NLG_HIP(hipGetLastError());
+    *xc = P.d_t;
+    return 0;
+}
+
+// Fine part: z = sum_e R_e^T Etilde_e^-1 R_e r (+ xc[e] when xc is given), launched on `st`.
+int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z) {
+    nlg_pprec &P = m->pprec;
+    NLG_CHECK(P.ready, "pprec: preconditioner not set up");
+    const int64_t E = m->E;
 #define FDM_CASE(N_)                                                                                                  \
     if (m->dim == 3)                                                                                                  \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)E), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, P.d_t, z); \
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z); \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)E), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, P.d_t, z);
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z);
     switch (m->n) {
         case 4: FDM_CASE(4); break;
         case 5: FDM_CASE(5); break;
@@ -509,7 +579,7 @@ int pprec_apply(nlg_mesh *m, const double *flag, const double *r, double *z) {
         case 9: FDM_CASE(9); break;
         case 10: FDM_CASE(10); break;
         case 12: FDM_CASE(12); break;
-        default: set_error("pprec_apply: unsupported lx1 = %d", m->n); return 1;
+        default: set_error("pprec: unsupported lx1 = %d", m->n); return 1;
     }
 #undef FDM_CASE
     NLG_HIP(hipGetLastError());

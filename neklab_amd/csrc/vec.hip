@@ -9,6 +9,8 @@
 // Roofline: every kernel here is HBM-bound (<= 0.25 flop/B).  Algorithmic bytes per call:
 //   scal 16 B/dof, axpby 24 B/dof, dot 24 B/dof (a, b, bm1), block_dot 8*(k+2) B per inner-product
 //   dof, block_axpy 8*(k+2) B per dof.
+#include <algorithm>
+
 #include "internal.h"
 
 using namespace nlg;
@@ -614,6 +616,12 @@ int nlg_basis_combine(const nlg_basis *b, int k, const double *c, nlg_vec *out) 
     NLG_CHECK(k >= 1 && k <= b->nvec, "nlg_basis_combine: k=%d out of range [1,%d]", k, b->nvec);
     NLG_TRY(check_same(b->views[0], out, "nlg_basis_combine"));
     NLG_TRY(nlg_vec_zero(out));
+    if (g_axpby_consistent) {
+        // consistent history: the combination carries the combined history slots of the basis vectors
+        int nr = 0;
+        for (int j = 0; j < k; ++j) nr = std::max(nr, b->views[j]->nrst);
+        out->nrst = nr;
+    }
     NLG_HIP(hipMemcpyAsync(b->d_h, c, sizeof(double) * k, hipMemcpyHostToDevice, b->mesh->ctx->stream));
     NLG_TRY(nlg::basis_block_axpy_dev(b, k, b->d_h, out, +1.0));
     NLG_HIP(hipStreamSynchronize(b->mesh->ctx->stream));

@@ -48,6 +48,18 @@ def arnoldi_step(matvec, V, H, k):
     return beta
 
 
+def lincomb(V, c, k):
+    """sum_i c[i] V[i], i < k.  With the consistent treatment of the restart history (oracle/vectors.py
+    CONSISTENT_RST) the combination also carries the combined history slots of the basis vectors."""
+    w = V[0].copy()
+    w.zero()
+    if getattr(type(w), "CONSISTENT_RST", False):
+        w.nrst = max(getattr(V[i], "nrst", 0) for i in range(k))
+    for i in range(k):
+        w.axpby(c[i], V[i], 1.0)
+    return w
+
+
 def ritz(H, k):
     """Eigen-decomposition of the leading k x k block; residuals from row k (0-based)."""
     lam, Y = np.linalg.eig(H[:k, :k])
@@ -124,11 +136,7 @@ def eigs(matvec, x0, nev, kdim, tol=None, max_restarts=50, new_vector=None, log=
         p = Q.shape[1]
         Vnew = []
         for j in range(p):
-            w = V[0].copy()
-            w.zero()
-            for i in range(k):
-                w.axpby(Q[i, j], V[i], 1.0)
-            Vnew.append(w)
+            Vnew.append(lincomb(V, Q[:, j], k))
         S = Q.T @ H[:k, :k] @ Q
         b = H[k, :k] @ Q
         vk = V[k]
@@ -145,11 +153,7 @@ def eigs(matvec, x0, nev, kdim, tol=None, max_restarts=50, new_vector=None, log=
     j = 0
     while j < nev_out:
         def comb(c):
-            w = V[0].copy()
-            w.zero()
-            for i in range(kf):
-                w.axpby(c[i], V[i], 1.0)
-            return w
+            return lincomb(V, c, kf)
         if abs(lam[j].imag) > 0:
             y = Y[:, j] if lam[j].imag > 0 else np.conj(Y[:, j])
             vecs.append(comb(y.real))
