@@ -191,6 +191,15 @@ def main():
     if abytes is not None and avg_ms > 0:
         roofline["achieved"] = abytes / (avg_ms * 1e-3) / 1e9
         roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    # HBM bytes per launch from the PMC counters: they cannot be sampled from inside this process, so the figure
+    # is the one recorded by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command on THIS
+    # configuration (profiles/r01_pmc/, corrected as MI355X_MICROARCH.md prescribes); null for any other config.
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic_per_launch.json")))
+        if tr["config"] == {"E": E, "lx1": n, "dim": dim} and dominant in tr:
+            roofline["traffic"] = tr[dominant]["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     steps_per_mv = (st2["steps"] - st1["steps"]) / max(args.steps, 1)
     p_iters = (st2["p_iters"] - st1["p_iters"]) / max(st2["steps"] - st1["steps"], 1)

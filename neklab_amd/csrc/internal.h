@@ -226,7 +226,8 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
 // ---- pprec.hip ----
 int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d);
 int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc);
-int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z);
+int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
+               double *rz_part = nullptr);
 void pprec_free(nlg_mesh *m);
 
 // ---- halo.hip ----
@@ -239,9 +240,10 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2);
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false);
-int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false);
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false,
+              const double *pdot = nullptr, double *pw_part = nullptr);
 int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
-int sem_cdabdtp(nlg_mesh *m, const double *p, double *out);
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr);
 int sem_ediag(nlg_mesh *m, double *out);
 int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, const double *Mx, const double *My,
                const double *Mz, const double *wt);

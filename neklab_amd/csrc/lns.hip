@@ -199,14 +199,19 @@ __global__ __launch_bounds__(NT) void k_cg_pupdate(const double *s, int64_t n, F
     }
 }
 
-// second stage: out[q] = sum_b partial[q*NB + b], q < nsums  (one block, fixed order)
-__global__ __launch_bounds__(NT) void k_cg_final(const double *s, const double *partial, int nblk, int nsums, double *out,
-                                                 int gate) {
+// where the first-stage partial sums of up to three reductions live (they may come from different kernels)
+struct Red {
+    const double *p[3];
+    int n[3];
+};
+
+// second stage: out[q] = sum_b rd.p[q][b], q < nsums  (one block, fixed order)
+__global__ __launch_bounds__(NT) void k_cg_final(const double *s, Red rd, int nsums, double *out, int gate) {
     __shared__ double sm[8];
     if (gate && s[S_DONE] != 0.0) return;
     for (int q = 0; q < nsums; ++q) {
         double a = 0.0, b = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += NT) a += partial[q * NB + i];
+        for (int i = threadIdx.x; i < rd.n[q]; i += NT) a += rd.p[q][i];
         block_sum2(a, b, sm);
         if (threadIdx.x == 0) out[q] = a;
         __syncthreads();
@@ -247,13 +252,13 @@ __global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int max
 }
 
 // single rank: second-stage reduction and scalar logic in one launch (no all-reduce in between)
-__global__ __launch_bounds__(NT) void k_cg_final_post(double *s, const double *partial, int nblk, int nsums, int gate,
-                                                      int mode, double tol2, int use_tol, int maxit, double inv_n) {
+__global__ __launch_bounds__(NT) void k_cg_final_post(double *s, Red rd, int nsums, int gate, int mode, double tol2,
+                                                      int use_tol, int maxit, double inv_n) {
     __shared__ double sm[8];
     if (gate && s[S_DONE] != 0.0) return;
     for (int q = 0; q < nsums; ++q) {
         double a = 0.0, b = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += NT) a += partial[q * NB + i];
+        for (int i = threadIdx.x; i < rd.n[q]; i += NT) a += rd.p[q][i];
         block_sum2(a, b, sm);
         if (threadIdx.x == 0) s[S_T0 + q] = a;
         __syncthreads();
@@ -364,6 +369,7 @@ struct nlg_linop {
     double *nwv = nullptr;     // binvm1 * vmult / volvm1
     double *nwp = nullptr;     // bm2inv / volvm2
     double *d_s = nullptr;     // solver scalars (two blocks of S_N)
+    double *d_part = nullptr;  // first-stage sums written by opdiv ([2][E]) and by the FDM kernel ([2][E/4])
     double *h_s = nullptr;     // pinned
     int istep = 0, adjoint = 0;
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
@@ -411,6 +417,11 @@ struct CGProblem {
     // non-pointwise M^-1 (nf = 1): writes the element-wise part to z and returns the coarse part per element in *xc
     std::function<int(const double *flag, const double *r, double *z, const double **xc)> precond;
     int npe = 1;         // points per element (for the per-element coarse part)
+    // first-stage sums produced by the operator / preconditioner kernels themselves (null = separate kernels)
+    const double *pw_part = nullptr;   // [2][pw_n]: sum p.w , sum w   (written by `apply`)
+    int pw_n = 0;
+    const double *rz_part = nullptr;   // [2][rz_n]: sum r.z , sum z   (written by `precond`)
+    int rz_n = 0;
 };
 
 // Generic device-scalar PCG. `apply` computes w = A p (must itself be stream-ordered and may be gated
@@ -427,12 +438,13 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     (void)x;
     CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf);
     CF3 cr = cf3(P.r, nf);
-    auto reduce_post = [&](int nsums, int gate, int mode) -> int {
+    const Red rd_std = {{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
+    auto reduce_post = [&](const Red &rd, int nsums, int gate, int mode) -> int {
         if (!ctx->comm) {
-            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NT), 0, st, s, (const double *)partial, g, nsums, gate, mode,
-                               P.tol2, P.use_tol, P.maxit, P.inv_n);
+            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NT), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
+                               P.inv_n);
         } else {
-            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, s, partial, g, nsums, s + S_T0, gate);
+            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, (const double *)s, rd, nsums, s + S_T0, gate);
             NLG_TRY(allreduce_sum(ctx, s + S_T0, nsums));
             hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n);
         }
@@ -440,11 +452,26 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     };
     launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
     const double *xc = nullptr;
+    Red rd_rz = rd_std;
     if (P.precond) {
         NLG_TRY(P.precond(nullptr, P.r[0], P.z[0], &xc));
-        launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+        if (P.rz_part) {
+            rd_rz.p[0] = P.rz_part;
+            rd_rz.n[0] = P.rz_n;
+            rd_rz.p[2] = P.rz_part + P.rz_n;
+            rd_rz.n[2] = P.rz_n;
+        } else {
+            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+        }
     }
-    NLG_TRY(reduce_post(3, 0, 0));
+    Red rd_pw = rd_std;
+    if (P.pw_part) {
+        rd_pw.p[0] = P.pw_part;
+        rd_pw.n[0] = P.pw_n;
+        rd_pw.p[1] = P.pw_part + P.pw_n;
+        rd_pw.n[1] = P.pw_n;
+    }
+    NLG_TRY(reduce_post(rd_rz, 3, 0, 0));
     launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
     hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
     int launched = 0;
@@ -455,16 +482,18 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         for (int it = 0; it < todo; ++it) {
             NLG_TRY(apply(s));
             if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
-            launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
-            NLG_TRY(reduce_post(2, 1, 1));
+            if (!P.pw_part)
+                launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
+            NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
                       pc, P.ipw, P.nw, partial);
             if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
             if (P.precond) {
                 NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
-                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+                if (!P.rz_part)
+                    launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
             }
-            NLG_TRY(reduce_post(3, 1, 2));
+            NLG_TRY(reduce_post(rd_rz, 3, 1, 2));
             launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
         }
         launched += todo;
@@ -545,19 +574,31 @@ int pres_solve(nlg_linop *op, double scale) {
     if (c.pprecond == 0) {   // two-level FDM + coarse V-cycle (pprec.hip); 1 = Jacobi on diag(E), as in the oracle
         P.pc = nopc;
         P.npe = m->np2;
-        P.precond = [m](const double *flag, const double *rr, double *zz, const double **xc) -> int {
+        double *rzp = (m->dim == 3 && !m->ctx->comm) ? op->d_part + 2 * m->E : nullptr;
+        P.precond = [m, rzp](const double *flag, const double *rr, double *zz, const double **xc) -> int {
             // one stream: a fork/join through events costs more than it hides (measured: 98 vs 84 us per apply)
             nlg_ctx *c = m->ctx;
             ProfScope ps(c, P_PPREC);
             const double *coarse = nullptr;
             NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse));
-            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz));   // z = FDM(r) + coarse[e]
+            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz, rzp));   // z = FDM(r) + coarse[e]
             *xc = nullptr;
             return 0;
         };
     }
     P.chunk = std::max(8, std::min(op->last_piters / 4 + 1, 64));
-    auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w); };
+    const bool fuse = (m->dim == 3) && !m->ctx->comm;   // the fused first-stage sums are rank-local only in layout, fine either way
+    double *pw_part = nullptr;
+    if (fuse) {
+        pw_part = op->d_part;
+        P.pw_part = pw_part;
+        P.pw_n = (int)m->E;
+        if (P.precond) {
+            P.rz_part = op->d_part + 2 * m->E;
+            P.rz_n = (int)((m->E + 3) / 4);
+        }
+    }
+    auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w, pw_part); };
     int iters = 0;
     NLG_TRY(run_pcg(op, P, apply, &iters));
     op->st_piters += iters;
@@ -765,6 +806,7 @@ int nlg_linop_destroy(nlg_linop *op) {
     fr(op->nwv);
     fr(op->nwp);
     fr(op->d_s);
+    fr(op->d_part);
     if (op->h_s) hipHostFree(op->h_s);
     nlg_vec_destroy(op->baseflow);
     delete op;
@@ -804,6 +846,7 @@ int nlg_linop_init(nlg_linop *op) {
         NLG_TRY(lalloc(op, &op->nwv, m->lvs));
         NLG_TRY(lalloc(op, &op->nwp, m->lps));
         NLG_TRY(lalloc(op, &op->d_s, 4 * S_N));
+        NLG_TRY(lalloc(op, &op->d_part, 3 * m->E + 16));
         NLG_HIP(hipHostMalloc(&op->h_s, sizeof(double) * 4 * S_N, hipHostMallocDefault));
         NLG_TRY(reduce_ws_reserve(ctx, 4));
     }

@@ -85,7 +85,8 @@ __device__ __forceinline__ void fdm_stage(const double *__restrict__ in, double 
 template <int N2, int DIM>
 __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                             const double *__restrict__ invden, const double *__restrict__ r,
-                                            const double *__restrict__ xc, double *__restrict__ z) {
+                                            const double *__restrict__ xc, double *__restrict__ z,
+                                            double *__restrict__ part) {
     constexpr int NP = DIM == 3 ? N2 * N2 * N2 : N2 * N2;
     __shared__ double sS[4][3][N2 * N2];
     __shared__ double sA[4][NP], sB[4][NP];
@@ -116,9 +117,34 @@ __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int
     __syncthreads();
     fdm_stage<N2, DIM, false, 0>(sB[wv], sA[wv], sS[wv][0], lane);
     __syncthreads();
+    double srz = 0.0, sz = 0.0;
     if (act) {
         const double c = xc ? xc[e] : 0.0;
-        for (int q = lane; q < NP; q += 64) z[e * NP + q] = sA[wv][q] + c;
+        for (int q = lane; q < NP; q += 64) {
+            const double zv = sA[wv][q] + c;
+            z[e * NP + q] = zv;
+            if (part) {
+                srz += r[e * NP + q] * zv;
+                sz += zv;
+            }
+        }
+    }
+    if (part) {   // first-stage sums of the surrounding PCG: part[blk] = sum r.z, part[nblk + blk] = sum z
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            srz += __shfl_down(srz, o, 64);
+            sz += __shfl_down(sz, o, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            sB[0][wv] = srz;
+            sB[0][4 + wv] = sz;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            part[blockIdx.x] = sB[0][0] + sB[0][1] + sB[0][2] + sB[0][3];
+            part[gridDim.x + blockIdx.x] = sB[0][4] + sB[0][5] + sB[0][6] + sB[0][7];
+        }
     }
 }
 
@@ -561,15 +587,16 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
 }
 
 // Fine part: z = sum_e R_e^T Etilde_e^-1 R_e r (+ xc[e] when xc is given), launched on `st`.
-int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z) {
+int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
+               double *rz_part) {
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
     const int64_t E = m->E;
 #define FDM_CASE(N_)                                                                                                  \
     if (m->dim == 3)                                                                                                  \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z); \
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z, rz_part); \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z);
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z, rz_part);
     switch (m->n) {
         case 4: FDM_CASE(4); break;
         case 5: FDM_CASE(5); break;

@@ -677,9 +677,11 @@ __global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, c
 }
 
 // opdiv: out = scale * sum_i sum_j g_ji o (T_j (wt_i o u_i)); wt (may hold nulls) fuses mask * binvm1 into the load
+// `pdot`/`part` (may be null): first-stage sums of the surrounding PCG, part[e] = sum_q pdot_q out_q and
+// part[E + e] = sum_q out_q over the element -- saves a separate pass over two pressure-mesh vectors.
 template <int N, int NC, bool FG>
 __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
-                                               double scale) {
+                                               double scale, const double *__restrict__ pdot, double *__restrict__ part) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SB = N2 * N * N, SC = N2 * N2 * N;
@@ -792,10 +794,36 @@ __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3
             }
         }
     }
+    double spw = 0.0, sw = 0.0;
 #pragma unroll
     for (int r = 0; r < NACC; ++r) {
         const int q = tid + r * NT;
-        if (q < NP2) out[e * NP2 + q] = scale * acc[r];
+        if (q < NP2) {
+            const double v = scale * acc[r];
+            out[e * NP2 + q] = v;
+            if (part) {
+                spw += pdot[e * NP2 + q] * v;
+                sw += v;
+            }
+        }
+    }
+    if (part) {
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            spw += __shfl_down(spw, o, 64);
+            sw += __shfl_down(sw, o, 64);
+        }
+        double *red = sBP;
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = spw;
+            red[4 + (tid >> 6)] = sw;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            part[e] = red[0] + red[1] + red[2] + red[3];
+            part[E + e] = red[4] + red[5] + red[6] + red[7];
+        }
     }
 }
 
@@ -1197,7 +1225,9 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
     return 0;
 }
 
-int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts, bool face_grouped) {
+int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts, bool face_grouped,
+              const double *pdot, double *pw_part) {
+    NLG_CHECK(!pw_part || m->dim == 3, "sem_opdiv: fused sums exist for the 3-D kernel only");
     ProfScope ps(m->ctx, P_OPDIV);
     CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
     CF3 wt = {{wts ? wts[0] : nullptr, wts ? wts[1] : nullptr, (wts && m->dim == 3) ? wts[2] : nullptr}};
@@ -1209,13 +1239,13 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part);  \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part); \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part); \
     }
         NLG_FOR_N(DV3)
 #undef DV3
@@ -1246,7 +1276,7 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
     return 0;
 }
 
-int sem_cdabdtp(nlg_mesh *m, const double *p, double *out) {
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part) {
     double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
     NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
     if (m->dim == 3 && !m->halo.active && m->gs.d_indices_fg) {
@@ -1260,12 +1290,12 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out) {
             hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, f);
             NLG_HIP(hipGetLastError());
         }
-        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true));
+        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part));
         return 0;
     }
     NLG_TRY(sem_opgradt(m, p, w));
     NLG_TRY(sem_gs(m, w, m->dim));
-    NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv));   // mask * binvm1 fused into the load
+    NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv, false, p, pw_part));   // mask * binvm1 fused into the load
     return 0;
 }
 

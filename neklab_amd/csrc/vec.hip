@@ -542,8 +542,16 @@ int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *
     nlg_ctx *ctx = b->mesh->ctx;
     const int64_t n2 = w->main_len / 2;
     ProfScope ps(ctx, P_BLOCKAXPY);
-    hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride, k,
-                       d_h, w->d, n2, w->nrst, n2, g_axpby_consistent, sign);
+    if (g_axpby_consistent) {
+        // consistent history: main block and the nrst valid history blocks are one contiguous range in which every
+        // entry receives the same linear combination -> one sweep through the unrolled path
+        const int64_t n2all = n2 * (1 + w->nrst);
+        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2all)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride,
+                           k, d_h, w->d, n2all, 0, n2, 0, sign);
+    } else {
+        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride, k,
+                           d_h, w->d, n2, w->nrst, n2, 0, sign);
+    }
     NLG_HIP(hipGetLastError());
     return 0;
 }
