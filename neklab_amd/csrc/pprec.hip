@@ -166,14 +166,6 @@ __global__ __launch_bounds__(NT) void k_restrict0(const double *__restrict__ fla
     }
 }
 
-// x = om * dinv * b
-__global__ void k_jac0(const double *flag, int64_t n, const double *dinv, const double *b, double om, double *x) {
-    if (flag && flag[0] != 0.0) return;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) x[i] = om * dinv[i] * b[i];
-}
-
-// mode 0: out = b - A x ; mode 1: x_new = x + om dinv (b - A x) written to out
 // `xa`/`agg` (may be null): the aggregate-level correction, prolonged on the fly: x_eff = x + xa[agg].
 // Eight lanes per row: the ~27 scattered reads of a row are issued together instead of one after another.
 __global__ __launch_bounds__(NT) void k_spmv(const double *flag, int64_t n, const int *__restrict__ rp,
@@ -231,13 +223,6 @@ __global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, c
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) xa[row] = s;
-}
-
-__global__ void k_prolong_add(const double *flag, int64_t n, const int *__restrict__ agg, const double *__restrict__ xa,
-                              double *__restrict__ x) {
-    if (flag && flag[0] != 0.0) return;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) x[i] += xa[agg[i]];
 }
 
 // ---- host helpers -------------------------------------------------------------------------------------
