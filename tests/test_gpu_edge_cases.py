@@ -1,0 +1,147 @@
+"""Edge cases of the C ABI: smallest / largest supported sizes, degenerate meshes, argument validation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+from oracle.sem import SEM
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("nel,n,periodic", [
+    ((1, 1, 1), 4, (False, False, False)),     # one element, smallest lx1: no shared dofs at all
+    ((1, 1, 2), 5, (True, True, False)),       # periodic directions one element wide: a dof meets itself
+    ((2, 1, 1), 12, (False, False, False)),    # largest lx1 (one velocity component per pass in the kernels)
+    ((2, 2), 10, (True, False)),               # 2-D, lx1 = 10
+    ((3, 1), 4, (False, True)),
+])
+def test_operator_parity_at_size_limits(gpu_ctx, nel, n, periodic):
+    hm = box_mesh(nel, n, periodic=periodic, deform=0.03)
+    sem = SEM(hm)
+    gm = host.Mesh(gpu_ctx, hm)
+    dim = sem.dim
+    rng = np.random.default_rng(0)
+    v, out = host.nek_dvector(gm), host.nek_dvector(gm)
+    u = [rng.standard_normal(sem.shape1) for _ in range(dim)]
+    p = rng.standard_normal(sem.shape2)
+    for i in range(dim):
+        v.set_field(i, u[i])
+    v.set_field(host.PR, p)
+    lib = gm.lib
+    assert rel(gm.get("vmult"), sem.vmult) < 1e-14
+    host.check(lib.nlg_op_helmholtz(gm.h, v.h, out.h, 0.3, 2.0, 1))
+    for i in range(dim):
+        assert rel(out.get_field(i), sem.mask[i] * sem.gs(sem.axhelm_local(u[i], 0.3, 2.0))) < 1e-12
+    host.check(lib.nlg_op_cdabdtp(gm.h, v.h, out.h))
+    assert rel(out.get_field(host.PR), sem.cdabdtp(p)) < 1e-11
+    host.check(lib.nlg_op_opdiv(gm.h, v.h, out.h))
+    assert rel(out.get_field(host.PR), sem.opdiv(u)) < 1e-12
+    host.check(lib.nlg_op_conv(gm.h, v.h, v.h, out.h, 1))
+    ref = sem.lns_conv_weak(u, u, adjoint=True)
+    sc = max(np.abs(r).max() for r in ref)
+    for i in range(dim):
+        assert np.max(np.abs(out.get_field(i) - ref[i].ravel())) < 1e-11 * sc
+
+
+def test_outflow_mesh_matvec_runs_and_is_finite(gpu_ctx):
+    """has_outflow = 1: no pressure null space, no projection; a short propagator must stay finite and contract."""
+    hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), deform=0.02, outflow_xmax=True)
+    gm = host.Mesh(gpu_ctx, hm)
+    bf = host.nek_dvector(gm)
+    bf.set_field(0, hm.mask[0] * (1.0 - (hm.y - 1.0) ** 2))
+    A = host.exptA_linop(0.05, bf, re=20.0, dt=0.01)
+    A.init()
+    x, y = host.nek_dvector(gm), host.nek_dvector(gm)
+    x.rand(True, seed=3)
+    A.matvec(x, y)
+    assert np.isfinite(y.norm()) and 0.0 < y.norm() < 1.5
+
+
+def test_argument_validation(gpu_ctx):
+    lib = host._lib.load()
+    hm = box_mesh((2, 2), 6)
+    gm = host.Mesh(gpu_ctx, hm)
+    v = host.nek_dvector(gm)
+    # unsupported sizes are refused with a message, nothing is silently emulated
+    bad = box_mesh((2, 2), 6)
+    bad.n = 11
+    with pytest.raises(host.NlgError, match="unsupported"):
+        host.Mesh(gpu_ctx, bad)
+    with pytest.raises(host.NlgError):
+        v.set_field(host.VZ, np.zeros(gm.lvn))                 # no z component on a 2-D mesh
+    with pytest.raises(host.NlgError):
+        v.set_field(host.VX, np.zeros(gm.lvn - 1))             # wrong length
+    with pytest.raises(host.NlgError):
+        v.get_field(host.THETA)                                # no scalar allocated
+    with pytest.raises(host.NlgError):
+        host.nek_dvector(gm, nscal=99)
+    with pytest.raises(host.NlgError):
+        host.KrylovBasis(gm, 0)
+    B = host.KrylovBasis(gm, 3)
+    with pytest.raises(host.NlgError):
+        B.block_dot(4, v)                                      # k > nvec
+    with pytest.raises(host.NlgError):
+        B[5]
+    bf = host.nek_dvector(gm)
+    with pytest.raises(host.NlgError):
+        host.exptA_linop(-1.0, bf)                             # tau must be positive
+    with pytest.raises(host.NlgError):
+        host.exptA_linop(1.0, bf, torder=4)
+    A = host.exptA_linop(1.0, bf)                              # zero base flow: the CFL rule cannot give a dt
+    with pytest.raises(host.NlgError, match="CFL"):
+        A.init()
+    X = [host.nek_dvector(gm)]
+    A2 = host.exptA_linop(0.02, bf, dt=0.01)
+    A2.init()
+    with pytest.raises(host.NlgError):
+        host.eigs(A2, X, kdim=1)                               # kdim must exceed nev
+    z = host.nek_dvector(gm)
+    with pytest.raises(host.NlgError, match="zero norm"):
+        host.eigs(A2, X, kdim=4, x0=z)                         # zero start vector
+    # a Jacobian of the wrong sign is caught at mesh creation
+    flipped = box_mesh((2, 2), 6)
+    flipped.x = -flipped.x
+    with pytest.raises(host.NlgError, match="Jacobian"):
+        host.Mesh(gpu_ctx, flipped)
+    # NULL handles
+    assert lib.nlg_vec_zero(None) != 0 and b"NULL" in lib.nlg_last_error()
+    out = C.c_double()
+    assert lib.nlg_vec_dot(None, None, C.byref(out)) != 0
+
+
+def test_scalar_fields_in_the_basis(gpu_ctx):
+    """nscal > 0 (temperature in the inner product, real_vectors.f90:220): block kernels with 4 components."""
+    hm = box_mesh((2, 2, 2), 6, deform=0.03)
+    sem = SEM(hm)
+    gm = host.Mesh(gpu_ctx, hm)
+    rng = np.random.default_rng(1)
+    k = 5
+    B = host.KrylovBasis(gm, k + 1, nscal=1)
+    cols = []
+    for j in range(k):
+        f = [rng.standard_normal(sem.shape1) for _ in range(4)]
+        for i in range(3):
+            B[j].set_field(i, f[i])
+        B[j].set_field(host.THETA, f[3])
+        cols.append(f)
+    w = host.nek_dvector(gm, nscal=1)
+    fw = [rng.standard_normal(sem.shape1) for _ in range(4)]
+    for i in range(3):
+        w.set_field(i, fw[i])
+    w.set_field(host.THETA, fw[3])
+    h = B.block_dot(k, w)
+    ref = np.array([sum(sem.glsc3(c[i], fw[i]) for i in range(4)) for c in cols])
+    assert np.max(np.abs(h - ref)) < 1e-13 * np.max(np.abs(ref))
+    for j in range(k):                                     # orthonormalise the columns, then project w
+        B.cgs2(j, B[j])
+    hh, beta = B.cgs2(k, w)
+    assert beta > 0 and abs(w.norm() - 1.0) < 1e-13
+    assert np.max(np.abs(B.block_dot(k, w))) < 1e-13
