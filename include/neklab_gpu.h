@@ -233,6 +233,19 @@ int nlg_eigs_opts_default(nlg_eigs_opts *o);
 int nlg_eigs(nlg_linop *op, nlg_vec **X, int nev, double *eig_re, double *eig_im, double *residuals,
              int *info, const nlg_vec *x0, const nlg_eigs_opts *opts);
 
+/* svds(A, U, S, V, residuals, info, kdim=, write_intermediate=) -- the LightKrylov call of
+ * transient_growth_analysis_fixed_point (src/neklab_analysis.f90:136; examples/back_fstep/transient_growth/
+ * bfs.usr:8-21): leading singular triplets of exp(tau L) by Lanczos bidiagonalisation with matvec + rmatvec.
+ * U[nsv] (optimal responses) and V[nsv] (optimal perturbations) are existing vectors and are overwritten;
+ * S and residuals have nsv entries; *info = number of operator applications.  opts->kdim, tol, seed,
+ * write_intermediate, logfile ("svds_output.txt") as for nlg_eigs; u0 (may be NULL) is the start vector. */
+int nlg_svds(nlg_linop *op, nlg_vec **U, nlg_vec **V, int nsv, double *S, double *residuals, int *info,
+             const nlg_vec *u0, const nlg_eigs_opts *opts);
+
+/* symmetric tridiagonal eigen-decomposition (diagonal d[n], sub-diagonal e[1..n-1]); eigenvalues ascending in d,
+ * eigenvectors as columns of the row-major n x n array Z.  Host helper of nlg_svds, exported for unit tests. */
+int nlg_symtridiag_eig(int n, double *d, double *e, double *Z);
+
 /* host-side dense helper used by nlg_eigs, exported for unit tests: eigen-decomposition of a real
  * n x n matrix (column-major, lda); vr column-major complex pairs as LAPACK dgeev. */
 int nlg_dense_eig(int n, const double *A, int lda, double *wr, double *wi, double *vr, int ldvr);

@@ -110,6 +110,8 @@ SIGNATURES = {
     "nlg_eigs_opts_default": (C.c_int, [C.POINTER(EigsOpts)]),
     "nlg_eigs": (C.c_int, [vp, C.POINTER(vp), C.c_int, c_double_p, c_double_p, c_double_p, c_int_p, vp,
                            C.POINTER(EigsOpts)]),
+    "nlg_svds": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, c_double_p, c_double_p, c_int_p, vp, C.POINTER(EigsOpts)]),
+    "nlg_symtridiag_eig": (C.c_int, [C.c_int, c_double_p, c_double_p, c_double_p]),
     "nlg_dense_eig": (C.c_int, [C.c_int, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int]),
 }
 

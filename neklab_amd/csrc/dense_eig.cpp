@@ -406,3 +406,85 @@ extern "C" int nlg_dense_eig(int n, const double *A, int lda, double *wr, double
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Symmetric tridiagonal eigen-decomposition (implicit QL, EISPACK tql2): d[n] diagonal, e[n] sub-diagonal in
+// e[1..n-1] (e[0] unused).  On return d holds the eigenvalues in ascending order, Z (row-major n x n) the
+// eigenvectors as columns.  Used for the singular values of the Lanczos bidiagonal matrix in nlg_svds.
+extern "C" int nlg_symtridiag_eig(int n, double *d, double *e_in, double *Z) {
+    if (n <= 0 || !d || !e_in || !Z) return 1;
+    std::vector<double> e(e_in, e_in + n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Z[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::pow(2.0, -52.0);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) {
+            if (std::fabs(e[m]) <= eps * tst1) break;
+            ++m;
+        }
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 200) return 2;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c;
+                const double el1 = e[l + 1];
+                double s = 0.0, s2 = 0.0;
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2;
+                    c2 = c;
+                    s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = Z[(size_t)k * n + i + 1];
+                        Z[(size_t)k * n + i + 1] = s * Z[(size_t)k * n + i] + c * h;
+                        Z[(size_t)k * n + i] = c * Z[(size_t)k * n + i] - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    // sort ascending
+    for (int i = 0; i < n - 1; ++i) {
+        int k = i;
+        double p = d[i];
+        for (int j = i + 1; j < n; ++j)
+            if (d[j] < p) {
+                k = j;
+                p = d[j];
+            }
+        if (k != i) {
+            d[k] = d[i];
+            d[i] = p;
+            for (int j = 0; j < n; ++j) std::swap(Z[(size_t)j * n + i], Z[(size_t)j * n + k]);
+        }
+    }
+    return 0;
+}

@@ -318,4 +318,133 @@ int nlg_eigs(nlg_linop *op, nlg_vec **X, int nev, double *eig_re, double *eig_im
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// svds: the LightKrylov call of transient_growth_analysis_fixed_point (src/neklab_analysis.f90:136), restated as
+// Golub-Kahan-Lanczos bidiagonalisation with full re-orthogonalisation (CGS2 against all previous left / right
+// vectors, block kernels): A^T u_k -> v_k, A v_k -> u_{k+1};  B_k (k x k upper part of the lower-bidiagonal matrix)
+// = P S Q^T, triplets (S_i, U_k p_i, V_k q_i), residual |beta_{k+1} q_i[k]|.  rmatvec is the (continuous) adjoint
+// propagator, as in the reference.
+int nlg_svds(nlg_linop *op, nlg_vec **U, nlg_vec **V, int nsv, double *S, double *residuals, int *info,
+             const nlg_vec *u0, const nlg_eigs_opts *opts_in) {
+    NLG_CHECK(op && U && V && S && residuals && info, "nlg_svds: NULL argument");
+    NLG_CHECK(nsv >= 1, "nlg_svds: nsv must be >= 1");
+    nlg_eigs_opts o;
+    nlg_eigs_opts_default(&o);
+    if (opts_in) o = *opts_in;
+    const int kdim = o.kdim > 0 ? o.kdim : 4 * nsv;
+    NLG_CHECK(kdim >= nsv, "nlg_svds: kdim=%d must be >= nsv=%d", kdim, nsv);
+    const double tol = o.tol > 0.0 ? o.tol : std::sqrt(1e-15);
+    const char *logfile = o.logfile ? o.logfile : "svds_output.txt";
+    nlg_vec *proto = U[0];
+    NLG_CHECK(proto && V[0], "nlg_svds: U[0] / V[0] is NULL");
+    nlg_mesh *mesh = proto->mesh;
+    *info = -1;
+    nlg_basis *Ub = nullptr, *Vb = nullptr;
+    NLG_TRY(nlg_basis_create(mesh, proto->nscal, proto->lorder, kdim + 1, &Ub));
+    int rc = nlg_basis_create(mesh, proto->nscal, proto->lorder, kdim, &Vb);
+    if (rc) {
+        nlg_basis_destroy(Ub);
+        return rc;
+    }
+    auto cleanup = [&]() {
+        nlg_basis_destroy(Ub);
+        nlg_basis_destroy(Vb);
+    };
+#define SVDS_TRY(call)  \
+    do {                \
+        rc = (call);    \
+        if (rc) {       \
+            cleanup();  \
+            return rc;  \
+        }               \
+    } while (0)
+    if (u0) {
+        SVDS_TRY(nlg_vec_copy(Ub->views[0], u0));
+    } else {
+        SVDS_TRY(nlg_vec_zero(Ub->views[0]));
+        SVDS_TRY(nlg_vec_rand(Ub->views[0], 0, o.seed));
+    }
+    {
+        double nrm = 0.0;
+        SVDS_TRY(nlg_vec_norm(Ub->views[0], &nrm));
+        if (!(nrm > 0.0)) {
+            cleanup();
+            set_error("nlg_svds: start vector has zero norm");
+            return 1;
+        }
+        SVDS_TRY(nlg_vec_scal(Ub->views[0], 1.0 / nrm));
+    }
+    std::vector<double> alpha(kdim, 0.0), beta(kdim + 1, 0.0), hh(kdim + 2);
+    std::vector<double> sig, Q, Pm;
+    std::vector<double> res_all;
+    int k = 0, nmv = 0;
+    bool done = false;
+    while (k < kdim && !done) {
+        double b = 0.0;
+        // right vector: v_k = A^T u_k, orthogonalised against v_0..v_{k-1}
+        SVDS_TRY(nlg_linop_rmatvec(op, Ub->views[k], Vb->views[k]));
+        SVDS_TRY(nlg_basis_cgs2(Vb, k, Vb->views[k], hh.data(), &b));
+        alpha[k] = b;
+        // left vector: u_{k+1} = A v_k, orthogonalised against u_0..u_k
+        SVDS_TRY(nlg_linop_matvec(op, Vb->views[k], Ub->views[k + 1]));
+        SVDS_TRY(nlg_basis_cgs2(Ub, k + 1, Ub->views[k + 1], hh.data(), &b));
+        beta[k + 1] = b;
+        nmv += 2;
+        ++k;
+        // SVD of the k x k part: B[i][i] = alpha_i, B[i+1][i] = beta_{i+1}  ->  T = B^T B (tridiagonal)
+        std::vector<double> d(k), e(k, 0.0), Z((size_t)k * k);
+        for (int i = 0; i < k; ++i) {
+            d[i] = alpha[i] * alpha[i] + (i + 1 < k ? beta[i + 1] * beta[i + 1] : 0.0);
+            if (i > 0) e[i] = alpha[i] * beta[i];
+        }
+        if (nlg_symtridiag_eig(k, d.data(), e.data(), Z.data()) != 0) {
+            cleanup();
+            set_error("nlg_svds: tridiagonal eigen-solver failed at k=%d", k);
+            return 1;
+        }
+        sig.assign(k, 0.0);
+        Q.assign((size_t)k * k, 0.0);
+        res_all.assign(k, 0.0);
+        int conv = 0;
+        for (int i = 0; i < k; ++i) {   // descending singular values
+            const int src = k - 1 - i;
+            sig[i] = std::sqrt(std::max(d[src], 0.0));
+            for (int r = 0; r < k; ++r) Q[(size_t)i * k + r] = Z[(size_t)r * k + src];
+            res_all[i] = std::fabs(beta[k] * Q[(size_t)i * k + (k - 1)]);
+            if (res_all[i] < tol) ++conv;
+        }
+        if (o.write_intermediate) {
+            FILE *f = fopen(logfile, "w");
+            if (f) {
+                fprintf(f, "# matvecs = %d   tolerance = %.6e\n#   i          sigma                residual   conv\n", nmv, tol);
+                for (int i = 0; i < k; ++i)
+                    fprintf(f, "%5d  %22.15e  %14.6e  %s\n", i + 1, sig[i], res_all[i], res_all[i] < tol ? "T" : "F");
+                fclose(f);
+            }
+        }
+        if (conv >= nsv) done = true;
+    }
+    // singular vectors: v_i = V_k q_i ; u_i = U_k p_i with p_i = B q_i / sigma_i (k components)
+    const int nout = std::min(nsv, k);
+    std::vector<double> c(k);
+    for (int i = 0; i < nout; ++i) {
+        for (int r = 0; r < k; ++r) c[r] = Q[(size_t)i * k + r];
+        SVDS_TRY(nlg_basis_combine(Vb, k, c.data(), V[i]));
+        for (int r = 0; r < k; ++r) {
+            double s = alpha[r] * Q[(size_t)i * k + r];
+            if (r > 0) s += beta[r] * Q[(size_t)i * k + r - 1];
+            c[r] = sig[i] > 0 ? s / sig[i] : 0.0;
+        }
+        SVDS_TRY(nlg_basis_combine(Ub, k, c.data(), U[i]));
+    }
+    for (int i = 0; i < nsv; ++i) {
+        S[i] = i < nout ? sig[i] : 0.0;
+        residuals[i] = i < nout ? res_all[i] : -1.0;
+    }
+    *info = nmv;
+    cleanup();
+#undef SVDS_TRY
+    return 0;
+}
+
 }  // extern "C"

@@ -359,6 +359,40 @@ def eigs(exptA: exptA_linop, X: list, kdim: int = 0, tol: float = 0.0, x0: nek_d
     return re + 1j * im, res, info.value
 
 
+def svds(exptA: exptA_linop, U: list, V: list, kdim: int = 0, tol: float = 0.0, u0: nek_dvector | None = None,
+         write_intermediate: bool = True, logfile: str | None = None, seed: int = 0):
+    """reference call: svds(exptA, U, S, V, residuals, info, kdim=, write_intermediate=) at neklab_analysis.f90:136.
+    Returns (S[nsv], residuals, info)."""
+    lib = exptA.lib
+    nsv = len(U)
+    assert len(V) == nsv
+    o = _lib.EigsOpts()
+    check(lib.nlg_eigs_opts_default(C.byref(o)))
+    o.kdim, o.write_intermediate, o.tol, o.seed = int(kdim), int(bool(write_intermediate)), float(tol), int(seed)
+    if logfile is not None:
+        o.logfile = logfile.encode()
+    S, res = np.zeros(nsv), np.zeros(nsv)
+    info = C.c_int()
+    au = (vp * nsv)(*[x.h for x in U])
+    av = (vp * nsv)(*[x.h for x in V])
+    check(lib.nlg_svds(exptA.h, au, av, nsv, dptr(S), dptr(res), C.byref(info), u0.h if u0 is not None else None, C.byref(o)))
+    return S, res, info.value
+
+
+def transient_growth_analysis_fixed_point(exptA: exptA_linop, nsv: int, kdim: int, tol: float = 0.0, outdir: str = ".",
+                                          seed: int = 0):
+    """reference: neklab_analysis.f90:107-156.  Returns (S, residuals, U (optimal responses), V (optimal
+    perturbations), info) and writes singular_spectrum.dat (:139-143)."""
+    mesh = exptA.mesh
+    U = [nek_dvector(mesh, 0, 3) for _ in range(nsv)]
+    V = [nek_dvector(mesh, 0, 3) for _ in range(nsv)]
+    S, residuals, info = svds(exptA, U, V, kdim=kdim, tol=tol, write_intermediate=True,
+                              logfile=os.path.join(outdir, "svds_output.txt"), seed=seed)
+    with open(os.path.join(outdir, "singular_spectrum.dat"), "w") as f:
+        f.write(" ".join("%.16e" % s for s in S) + "\n")
+    return S, residuals, U, V, info
+
+
 def save_eigenspectrum(eigvals, residuals, filename: str):
     """reference call site: neklab_analysis.f90:90 (LightKrylov save_eigenspectrum): (n,3) array
     [Re, Im, residual] in .npy format, the layout examples/*/plot_eigenvalues.py reads."""

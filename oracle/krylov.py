@@ -164,3 +164,46 @@ def eigs(matvec, x0, nev, kdim, tol=None, max_restarts=50, new_vector=None, log=
             vecs.append(comb(Y[:, j].real))
             j += 1
     return lam[:nev_out], vecs[:nev_out], res[:nev_out], nmv
+
+
+def svds(matvec, rmatvec, u0, nsv, kdim, tol=None):
+    """Leading singular triplets by Golub-Kahan-Lanczos bidiagonalisation with full re-orthogonalisation -- the
+    LightKrylov `svds` call of /root/reference/src/neklab_analysis.f90:136, restated (see csrc/krylov.hip nlg_svds).
+    Returns (S[nsv], U list, V list, residuals[nsv], number of operator applications)."""
+    if tol is None:
+        tol = np.sqrt(10.0 ** -15)
+    U = [None] * (kdim + 1)
+    V = [None] * kdim
+    alpha, beta = np.zeros(kdim), np.zeros(kdim + 1)
+    u = u0.copy()
+    u.scal(1.0 / u.norm())
+    U[0] = u
+    k = nmv = 0
+    sig = Q = res = None
+    while k < kdim:
+        v = rmatvec(U[k])
+        if k > 0:
+            cgs2_step(V[:k], v)
+        alpha[k] = v.norm()
+        v.scal(1.0 / alpha[k])
+        V[k] = v
+        w = matvec(V[k])
+        cgs2_step(U[: k + 1], w)
+        beta[k + 1] = w.norm()
+        w.scal(1.0 / beta[k + 1])
+        U[k + 1] = w
+        nmv += 2
+        k += 1
+        B = np.diag(alpha[:k]) + np.diag(beta[1:k], -1)
+        P, sig, Qt = np.linalg.svd(B)
+        Q = Qt.T
+        res = np.abs(beta[k] * Q[k - 1, :])
+        if int(np.sum(res < tol)) >= nsv:
+            break
+    nout = min(nsv, k)
+    Us, Vs = [], []
+    B = np.diag(alpha[:k]) + np.diag(beta[1:k], -1)
+    for i in range(nout):
+        Vs.append(lincomb(V, Q[:, i], k))
+        Us.append(lincomb(U, (B @ Q[:, i]) / sig[i], k))
+    return sig[:nout], Us, Vs, res[:nout], nmv
