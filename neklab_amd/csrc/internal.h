@@ -122,6 +122,11 @@ struct nlg_halo {
 struct nlg_pprec {
     bool ready = false;
     int na = 0;                                  // aggregates
+    int nvert = 0, ncorner = 0;                  // coarse dofs: element vertices (trilinear coarse space), 2^dim per element
+    int *d_vg = nullptr;                         // [E][ncorner] vertex id of every element corner
+    int *d_v2e_p = nullptr, *d_v2e_i = nullptr;  // vertex -> incident (element*ncorner + corner) entries, CSR
+    double *d_tq = nullptr;                      // [E][ncorner] element-local restriction
+    double hat1[16] = {};                        // (1 + z2)/2 at the GL points: the 1-D hat function of the upper corner
     double *d_S = nullptr, *d_invden = nullptr;  // FDM: [E][3][n2*n2] eigenvector matrices, [E][n2^dim] 1/(sum of eigenvalues)
     int *d_rp = nullptr, *d_ci = nullptr;        // A_c in CSR
     double *d_av = nullptr, *d_dinv = nullptr;

@@ -7,13 +7,21 @@
 // element-wise FDM 192, FDM + exact piecewise-constant coarse grid 81, FDM + the V-cycle below 110, all at
 // E = 512, independent of E for the two-level variants):
 //   M^-1 r = sum_e R_e^T Etilde_e^-1 R_e r                     (element-wise fast diagonalisation, additive)
-//          + R_0^T  V(A_c) R_0 r                               (piecewise-constant-per-element coarse space)
+//          + R_1   V(A_c) R_1^T r                              (trilinear coarse space on the element vertices)
 //   Etilde_e : E restricted to element e with the element replaced by a box of its mean edge lengths and the
 //              neighbours' mass lumped on shared faces: separable, inverted exactly by 1-D generalised
 //              eigen-decompositions (n2 x n2 per direction).
-//   A_c = R_0 E R_0^T : sparse E x E (27-point on structured meshes), assembled exactly on the host.
-//   V(A_c)  : one symmetric V-cycle: damped-Jacobi sweep, exact solve on greedy aggregates of elements (dense
-//             inverse), damped-Jacobi sweep.  When E is small the aggregates are the elements (exact solve).
+//   R_1     : columns = the trilinear (bilinear in 2-D) hat functions of the element vertices evaluated at the GL
+//             pressure points; continuous across elements although the pressure space is not.  Prototype
+//             (scripts/precond_proto2.py, precond_proto3.py, explicit sparse E): against the piecewise-constant
+//             space used first (R_0) the vertex space halves the iteration count (73 -> 37 at lx1 = 8 with exact
+//             element blocks; 30 at lx1 = 6), mesh-independent, and one V-cycle is as good as the exact solve.
+//   A_c = R_1^T E R_1 : Galerkin, sparse nvert x nvert (125-point on structured meshes).  Assembled by probing E on
+//             the device: elements are coloured so that no two of one colour share a neighbour, one E application
+//             per (colour, corner) gives the 2^dim x 2^dim blocks phi_c'^T E_{e',e} phi_c of every neighbouring pair.
+//   V(A_c)  : one symmetric V-cycle: damped-Jacobi sweep, exact solve on greedy aggregates of vertices (dense
+//             inverse), damped-Jacobi sweep.  When nvert is small the aggregates are the vertices (exact solve).
+//   With several ranks the coarse level is rank-local (E without the halo exchange): block-diagonal, still SPD.
 // M is a fixed symmetric positive (semi-)definite operator, so plain PCG stays valid.
 #include <algorithm>
 #include <cmath>
@@ -27,6 +35,10 @@ using namespace nlg;
 namespace {
 
 constexpr int NT = 256;
+
+struct Hat {
+    double h1[12];   // (1 + z)/2 at the GL points; the lower-corner hat is 1 - h1
+};
 
 template <int S0, int S1, int S2, int AX, int NOUT, bool TRANS>
 __device__ __forceinline__ void contract(const double *__restrict__ in, double *__restrict__ out,
@@ -85,8 +97,8 @@ __device__ __forceinline__ void fdm_stage(const double *__restrict__ in, double 
 template <int N2, int DIM>
 __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                             const double *__restrict__ invden, const double *__restrict__ r,
-                                            const double *__restrict__ xc, double *__restrict__ z,
-                                            double *__restrict__ part) {
+                                            const double *__restrict__ xc, const int *__restrict__ vg, Hat hat,
+                                            double *__restrict__ z, double *__restrict__ part) {
     constexpr int NP = DIM == 3 ? N2 * N2 * N2 : N2 * N2;
     __shared__ double sS[4][3][N2 * N2];
     __shared__ double sA[4][NP], sB[4][NP];
@@ -119,9 +131,21 @@ __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int
     __syncthreads();
     double srz = 0.0, sz = 0.0;
     if (act) {
-        const double c = xc ? xc[e] : 0.0;
+        // coarse correction prolonged on the fly: trilinear interpolation of the 2^DIM vertex values of the element
+        constexpr int NC = 1 << DIM;
+        double cv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cv[c] = xc ? xc[vg[e * NC + c]] : 0.0;
         for (int q = lane; q < NP; q += 64) {
-            const double zv = sA[wv][q] + c;
+            const double ha = hat.h1[q % N2], hb = hat.h1[(q / N2) % N2];
+            double c0 = (cv[0] + ha * (cv[1] - cv[0])), c1 = (cv[2] + ha * (cv[3] - cv[2]));
+            double cc = c0 + hb * (c1 - c0);
+            if constexpr (DIM == 3) {
+                const double hc = hat.h1[q / (N2 * N2)];
+                const double d0 = (cv[4] + ha * (cv[5] - cv[4])), d1 = (cv[6] + ha * (cv[7] - cv[6]));
+                cc += hc * ((d0 + hb * (d1 - d0)) - cc);
+            }
+            const double zv = sA[wv][q] + cc;
             z[e * NP + q] = zv;
             if (part) {
                 srz += r[e * NP + q] * zv;
@@ -148,22 +172,75 @@ __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int
     }
 }
 
-// rc[e] = sum of r over the pressure points of element e   (R_0 r)
-__global__ __launch_bounds__(NT) void k_restrict0(const double *__restrict__ flag, int64_t E, int np2,
-                                                  const double *__restrict__ r, double *__restrict__ rc,
-                                                  const double *__restrict__ dinv, double om, double *__restrict__ x) {
+// t[e][c] = sum_q phi_c(q) r_e(q): the element-local part of R_1^T r, one wave per element
+template <int DIM>
+__global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restrict__ flag, int64_t E, int n2, Hat hat,
+                                                          const double *__restrict__ r, double *__restrict__ t) {
     if (flag && flag[0] != 0.0) return;
+    constexpr int NC = 1 << DIM;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 4 + wid;
     if (e >= E) return;
-    double a = 0.0;
-    for (int q = lane; q < np2; q += 64) a += r[e * np2 + q];
+    const int np2 = DIM == 3 ? n2 * n2 * n2 : n2 * n2;
+    double a[NC];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    if (lane == 0) {
-        rc[e] = a;
-        x[e] = om * dinv[e] * a;   // first damped-Jacobi sweep from a zero guess
+    for (int c = 0; c < NC; ++c) a[c] = 0.0;
+    for (int q = lane; q < np2; q += 64) {
+        const double v = r[e * np2 + q];
+        const double ha = hat.h1[q % n2], hb = hat.h1[(q / n2) % n2];
+        const double hc = DIM == 3 ? hat.h1[q / (n2 * n2)] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double w = ((c & 1) ? ha : 1.0 - ha) * ((c & 2) ? hb : 1.0 - hb);
+            if (DIM == 3) w *= (c & 4) ? hc : 1.0 - hc;
+            a[c] += w * v;
+        }
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[c] += __shfl_down(a[c], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t[e * NC + c] = a[c];
+    }
+}
+
+// rc[v] = sum of t over the (element, corner) entries incident to vertex v (fixed order), and the first damped-Jacobi
+// sweep from a zero guess
+__global__ __launch_bounds__(NT) void k_q1_gather(const double *__restrict__ flag, int nvert, const int *__restrict__ vp,
+                                                  const int *__restrict__ vi, const double *__restrict__ t,
+                                                  double *__restrict__ rc, const double *__restrict__ dinv, double om,
+                                                  double *__restrict__ x) {
+    if (flag && flag[0] != 0.0) return;
+    const int v = blockIdx.x * NT + threadIdx.x;
+    if (v >= nvert) return;
+    double a = 0.0;
+    for (int q = vp[v]; q < vp[v + 1]; ++q) a += t[vi[q]];
+    rc[v] = a;
+    x[v] = om * dinv[v] * a;
+}
+
+// probing vector of the coarse-operator assembly: p = phi_c on the elements of colour `col`, 0 elsewhere
+template <int DIM>
+__global__ __launch_bounds__(NT) void k_q1_probe(int64_t E, int n2, Hat hat, const int *__restrict__ colour, int col, int c,
+                                                 double *__restrict__ p) {
+    const int np2 = DIM == 3 ? n2 * n2 * n2 : n2 * n2;
+    const int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x;
+    if (i >= E * np2) return;
+    const int64_t e = i / np2;
+    const int q = (int)(i % np2);
+    double w = 0.0;
+    if (colour[e] == col) {
+        const double ha = hat.h1[q % n2], hb = hat.h1[(q / n2) % n2];
+        w = ((c & 1) ? ha : 1.0 - ha) * ((c & 2) ? hb : 1.0 - hb);
+        if (DIM == 3) {
+            const double hc = hat.h1[q / (n2 * n2)];
+            w *= (c & 4) ? hc : 1.0 - hc;
+        }
+    }
+    p[i] = w;
 }
 
 // `xa`/`agg` (may be null): the aggregate-level correction, prolonged on the fly: x_eff = x + xa[agg].
@@ -435,109 +512,211 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     NLG_TRY(up(hS, &P.d_S));
     NLG_TRY(up(hden, &P.d_invden));
 
-    // ---- 2. coarse operator A_c = R_0 E R_0^T (exact), from the local vectors G_e = D_e^T 1
-    std::vector<std::vector<double>> G(dim, std::vector<double>((size_t)m->lvn));
+    // ---- 2. coarse space: element vertices, trilinear hats at the GL points
+    const int NC = 1 << dim;
+    P.ncorner = NC;
+    for (int k = 0; k < n2; ++k) P.hat1[k] = 0.5 * (1.0 + o.z2[k]);
+    Hat hat;
+    for (int k = 0; k < 12; ++k) hat.h1[k] = k < n2 ? P.hat1[k] : 0.0;
+    std::vector<int> vg((size_t)E * NC);
+    int nvert = 0;
     {
-        double *ones = sem_scratch2(m, 0);
-        double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), dim == 3 ? sem_scratch1(m, 2) : nullptr};
-        NLG_CHECK(ones && w[0] && w[1], "pprec_setup: scratch allocation failed");
-        std::vector<double> h1((size_t)m->lpn, 1.0);
-        NLG_HIP(hipMemcpyAsync(ones, h1.data(), sizeof(double) * (size_t)m->lpn, hipMemcpyHostToDevice, st));
-        NLG_TRY(sem_opgradt(m, ones, w));
-        for (int c = 0; c < dim; ++c)
-            NLG_HIP(hipMemcpyAsync(G[c].data(), w[c], sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, st));
-        NLG_HIP(hipStreamSynchronize(st));
-    }
-    std::vector<std::unordered_map<int, double>> rows((size_t)E);
-    {
-        // diagonal contributions of every local dof, cross terms through the groups of shared labels
-        for (int64_t q = 0; q < m->lvn; ++q) {
-            const int e = (int)(q / np1);
-            double s = 0.0;
-            for (int c = 0; c < dim; ++c) s += msk[c][q] * binv[q] * G[c][q] * G[c][q];
-            if (s != 0.0) rows[e][e] += s;
-        }
-        std::vector<int> order((size_t)m->lvn);
-        std::iota(order.begin(), order.end(), 0);
         const int64_t *glo = d->glo_num;
-        std::sort(order.begin(), order.end(), [glo](int a, int b) { return glo[a] < glo[b] || (glo[a] == glo[b] && a < b); });
-        int64_t b = 0;
-        while (b < m->lvn) {
-            int64_t e2 = b + 1;
-            while (e2 < m->lvn && glo[order[e2]] == glo[order[b]]) ++e2;
-            for (int64_t i = b; i < e2; ++i)
-                for (int64_t j = b; j < e2; ++j) {
-                    if (i == j) continue;
-                    const int qa = order[i], qb = order[j];
-                    double s = 0.0;
-                    for (int c = 0; c < dim; ++c) s += msk[c][qa] * binv[qa] * G[c][qa] * G[c][qb];
-                    if (s != 0.0) rows[qa / np1][qb / np1] += s;
-                }
-            b = e2;
+        std::vector<int64_t> lab((size_t)E * NC);
+        for (int64_t e = 0; e < E; ++e)
+            for (int c = 0; c < NC; ++c) {
+                const int i = (c & 1) ? n - 1 : 0, j = (c & 2) ? n - 1 : 0, k = (c & 4) ? n - 1 : 0;
+                lab[(size_t)e * NC + c] = glo[e * np1 + i + n * (j + n * k)];
+            }
+        std::vector<int64_t> u(lab);
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        nvert = (int)u.size();
+        for (size_t q = 0; q < lab.size(); ++q) vg[q] = (int)(std::lower_bound(u.begin(), u.end(), lab[q]) - u.begin());
+    }
+    P.nvert = nvert;
+    // vertex -> incident (element, corner) entries
+    std::vector<int> vp((size_t)nvert + 1, 0), vi((size_t)E * NC);
+    for (size_t q = 0; q < vg.size(); ++q) vp[vg[q] + 1]++;
+    for (int v = 0; v < nvert; ++v) vp[v + 1] += vp[v];
+    {
+        std::vector<int> pos(vp.begin(), vp.end() - 1);
+        for (size_t q = 0; q < vg.size(); ++q) vi[pos[vg[q]]++] = (int)q;
+    }
+    // element adjacency (conforming hexahedra that share any node share a vertex)
+    std::vector<std::vector<int>> adj((size_t)E);
+    for (int64_t e = 0; e < E; ++e) {
+        auto &a = adj[e];
+        for (int c = 0; c < NC; ++c) {
+            const int v = vg[(size_t)e * NC + c];
+            for (int q = vp[v]; q < vp[v + 1]; ++q) a.push_back(vi[q] / NC);
+        }
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    // greedy colouring: two elements of one colour have no common neighbour
+    std::vector<int> colour((size_t)E, -1);
+    int ncol = 0;
+    {
+        std::vector<int> mark;
+        for (int64_t e = 0; e < E; ++e) {
+            mark.assign((size_t)ncol + 1, 0);
+            for (int e1 : adj[e])
+                for (int e2 : adj[e1])
+                    if (colour[e2] >= 0) mark[colour[e2]] = 1;
+            int cidx = 0;
+            while (cidx < ncol && mark[cidx]) ++cidx;
+            colour[e] = cidx;
+            if (cidx == ncol) ++ncol;
         }
     }
-    std::vector<int> rp((size_t)E + 1, 0), ci;
-    std::vector<double> av, dinv((size_t)E, 0.0);
-    for (int64_t e = 0; e < E; ++e) {
-        std::vector<std::pair<int, double>> r(rows[e].begin(), rows[e].end());
+    // ---- 3. A_c = R_1^T E R_1 by probing E on the device (rank-local: without the halo exchange)
+    std::vector<std::unordered_map<int, double>> rows((size_t)nvert);
+    {
+        int *d_colour = nullptr;
+        double *d_t8 = nullptr;
+        NLG_TRY(up(colour, &d_colour));
+        NLG_HIP(hipMalloc(&d_t8, sizeof(double) * (size_t)E * NC));
+        double *pp = sem_scratch2(m, 0), *ep = sem_scratch2(m, 1);
+        NLG_CHECK(pp && ep, "pprec_setup: scratch allocation failed");
+        const bool halo_was = m->halo.active;
+        m->halo.active = false;
+        std::vector<double> t8((size_t)E * NC);
+        std::vector<int> owner((size_t)E);
+        const unsigned gp = (unsigned)((m->lpn + NT - 1) / NT), ge = (unsigned)((E + 3) / 4);
+        int rc = 0;
+        for (int col = 0; col < ncol && rc == 0; ++col) {
+            std::fill(owner.begin(), owner.end(), -1);
+            for (int64_t e = 0; e < E; ++e)
+                if (colour[e] == col)
+                    for (int e1 : adj[e]) owner[e1] = (int)e;
+            for (int c = 0; c < NC && rc == 0; ++c) {
+                if (dim == 3) {
+                    hipLaunchKernelGGL(k_q1_probe<3>, dim3(gp), dim3(NT), 0, st, E, n2, hat, d_colour, col, c, pp);
+                } else {
+                    hipLaunchKernelGGL(k_q1_probe<2>, dim3(gp), dim3(NT), 0, st, E, n2, hat, d_colour, col, c, pp);
+                }
+                rc = sem_cdabdtp(m, pp, ep);
+                if (rc) break;
+                if (dim == 3) {
+                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8);
+                } else {
+                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8);
+                }
+                if (hipMemcpyAsync(t8.data(), d_t8, sizeof(double) * t8.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) {
+                    set_error("pprec_setup: device error while probing the coarse operator");
+                    rc = 1;
+                    break;
+                }
+                for (int64_t e1 = 0; e1 < E; ++e1) {
+                    const int e0 = owner[e1];
+                    if (e0 < 0) continue;
+                    const int vcol = vg[(size_t)e0 * NC + c];
+                    for (int c1 = 0; c1 < NC; ++c1) {
+                        const double val = t8[(size_t)e1 * NC + c1];
+                        if (val != 0.0) rows[vg[(size_t)e1 * NC + c1]][vcol] += val;
+                    }
+                }
+            }
+        }
+        m->halo.active = halo_was;
+        hipFree(d_colour);
+        hipFree(d_t8);
+        if (rc) return rc;
+    }
+    // symmetrise (the probing is symmetric up to rounding) and build the CSR
+    for (int u = 0; u < nvert; ++u)
+        for (auto &kv : rows[u])
+            if (kv.first > u) {
+                auto it = rows[kv.first].find(u);
+                const double other = it == rows[kv.first].end() ? kv.second : it->second;
+                const double avg = 0.5 * (kv.second + other);
+                kv.second = avg;
+                rows[kv.first][u] = avg;
+            }
+    std::vector<int> rp((size_t)nvert + 1, 0), ci;
+    std::vector<double> av, dinv((size_t)nvert, 0.0);
+    for (int u = 0; u < nvert; ++u) {
+        std::vector<std::pair<int, double>> r(rows[u].begin(), rows[u].end());
         std::sort(r.begin(), r.end());
         for (auto &kv : r) {
             ci.push_back(kv.first);
             av.push_back(kv.second);
-            if (kv.first == e) dinv[e] = kv.second > 0 ? 1.0 / kv.second : 0.0;
+            if (kv.first == u) dinv[u] = kv.second > 0 ? 1.0 / kv.second : 0.0;
         }
-        rp[e + 1] = (int)ci.size();
+        rp[u + 1] = (int)ci.size();
     }
-    // ---- 3. aggregates and the dense inverse on them
-    std::vector<int> agg((size_t)E, -1);
+    // ---- 4. aggregates of vertices (greedy over the vertices that share an element) and the dense inverse on them
+    std::vector<int> agg((size_t)nvert, -1);
     int na = 0;
-    if (E <= 1024) {
-        for (int64_t e = 0; e < E; ++e) agg[e] = (int)e;
-        na = (int)E;
+    if (nvert <= 1024) {
+        for (int v = 0; v < nvert; ++v) agg[v] = v;
+        na = nvert;
     } else {
-        for (int64_t e = 0; e < E; ++e) {
-            if (agg[e] >= 0) continue;
+        auto near = [&](int v, std::vector<int> &out) {
+            out.clear();
+            for (int q = vp[v]; q < vp[v + 1]; ++q) {
+                const int e = vi[q] / NC;
+                for (int c = 0; c < NC; ++c) out.push_back(vg[(size_t)e * NC + c]);
+            }
+            std::sort(out.begin(), out.end());
+            out.erase(std::unique(out.begin(), out.end()), out.end());
+        };
+        std::vector<int> nb;
+        for (int v = 0; v < nvert; ++v) {
+            if (agg[v] >= 0) continue;
+            near(v, nb);
             bool free_all = true;
-            for (int q = rp[e]; q < rp[e + 1]; ++q)
-                if (agg[ci[q]] >= 0) free_all = false;
+            for (int w : nb)
+                if (agg[w] >= 0) free_all = false;
             if (!free_all) continue;
-            for (int q = rp[e]; q < rp[e + 1]; ++q) agg[ci[q]] = na;
+            for (int w : nb) agg[w] = na;
             ++na;
         }
-        for (int64_t e = 0; e < E; ++e) {
-            if (agg[e] >= 0) continue;
+        for (int v = 0; v < nvert; ++v) {
+            if (agg[v] >= 0) continue;
+            near(v, nb);
             int best = -1;
             double bv = -1.0;
-            for (int q = rp[e]; q < rp[e + 1]; ++q)
-                if (ci[q] != e && agg[ci[q]] >= 0 && std::fabs(av[q]) > bv) {
-                    bv = std::fabs(av[q]);
-                    best = agg[ci[q]];
+            for (int w : nb) {
+                if (w == v || agg[w] < 0) continue;
+                auto it = rows[v].find(w);
+                const double cv = it == rows[v].end() ? 0.0 : std::fabs(it->second);
+                if (cv > bv) {
+                    bv = cv;
+                    best = agg[w];
                 }
-            agg[e] = best >= 0 ? best : na++;
+            }
+            agg[v] = best >= 0 ? best : na++;
         }
     }
     std::vector<double> Acc((size_t)na * na, 0.0);
-    for (int64_t e = 0; e < E; ++e)
-        for (int q = rp[e]; q < rp[e + 1]; ++q) Acc[(size_t)agg[e] * na + agg[ci[q]]] += av[q];
+    for (int u = 0; u < nvert; ++u)
+        for (int q = rp[u]; q < rp[u + 1]; ++q) Acc[(size_t)agg[u] * na + agg[ci[q]]] += av[q];
     for (int i = 0; i < na; ++i)
         for (int j = i + 1; j < na; ++j) Acc[(size_t)i * na + j] = Acc[(size_t)j * na + i] = 0.5 * (Acc[(size_t)i * na + j] + Acc[(size_t)j * na + i]);
-    if (!m->has_outflow && !ctx->comm) {
-        // constant null space: shift it so that the inverse acts as the pseudo-inverse on mean-free data
+    if (!m->has_outflow) {
+        // constant null space (the hats sum to one): shift it so that the inverse acts as the pseudo-inverse on
+        // mean-free data.  With several ranks the rank-local operator has the same null vector.
         double tr = 0.0;
         for (int i = 0; i < na; ++i) tr += Acc[(size_t)i * na + i];
-        const double alpha = tr / na / na;   // the null vector of R_1 A_c R_1^T is the vector of ones
+        const double alpha = tr / na / na;   // the null vector of the aggregated operator is the vector of ones
         for (int i = 0; i < na; ++i)
             for (int j = 0; j < na; ++j) Acc[(size_t)i * na + j] += alpha;
     }
     NLG_CHECK(spd_inverse(na, Acc) == 0, "pprec_setup: aggregate operator is not positive definite");
-    std::vector<int> ap((size_t)na + 1, 0), am((size_t)E);
-    for (int64_t e = 0; e < E; ++e) ap[agg[e] + 1]++;
+    std::vector<int> ap((size_t)na + 1, 0), am((size_t)nvert);
+    for (int v = 0; v < nvert; ++v) ap[agg[v] + 1]++;
     for (int a = 0; a < na; ++a) ap[a + 1] += ap[a];
     {
         std::vector<int> pos(ap.begin(), ap.end() - 1);
-        for (int64_t e = 0; e < E; ++e) am[pos[agg[e]]++] = (int)e;
+        for (int v = 0; v < nvert; ++v) am[pos[agg[v]]++] = v;
     }
     P.na = na;
+    NLG_TRY(up(vg, &P.d_vg));
+    NLG_TRY(up(vp, &P.d_v2e_p));
+    NLG_TRY(up(vi, &P.d_v2e_i));
     NLG_TRY(up(rp, &P.d_rp));
     NLG_TRY(up(ci, &P.d_ci));
     NLG_TRY(up(av, &P.d_av));
@@ -546,42 +725,55 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     NLG_TRY(up(ap, &P.d_ap));
     NLG_TRY(up(am, &P.d_am));
     NLG_TRY(up(Acc, &P.d_Ainv));
-    for (double **v : {&P.d_rc, &P.d_x, &P.d_t}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)E));
+    NLG_HIP(hipMalloc(&P.d_tq, sizeof(double) * (size_t)E * NC));
+    for (double **v : {&P.d_rc, &P.d_x, &P.d_t}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(nvert, 1)));
     for (double **v : {&P.d_ra, &P.d_xa}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(na, 1)));
     P.ready = true;
     return 0;
 }
 
-// Coarse part of M^-1 r: xc[e] (one value per element) = V(A_c) R_0 r, launched on `st`.
+// Coarse part of M^-1 r: xc[v] (one value per element vertex) = V(A_c) R_1^T r, launched on `st`; pprec_fine
+// prolongs it.
 int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc) {
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
     const int64_t E = m->E;
+    const int nv = P.nvert;
     const double om = 0.7;
-    const int gE = (int)((E * 8 + 255) / 256);   // eight lanes per row
-    hipLaunchKernelGGL(k_restrict0, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->np2, r, P.d_rc, P.d_dinv, om, P.d_x);
-    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 0,
+    const int gV = (int)(((int64_t)nv * 8 + 255) / 256);   // eight lanes per row
+    Hat hat;
+    for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
+    if (m->dim == 3) {
+        hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq);
+    } else {
+        hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq);
+    }
+    hipLaunchKernelGGL(k_q1_gather, dim3((nv + NT - 1) / NT), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x);
+    hipLaunchKernelGGL(k_spmv, dim3(gV), dim3(256), 0, st, flag, (int64_t)nv, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 0,
                        (const double *)nullptr, (const int *)nullptr, P.d_t);
     hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_t, P.d_ra);
     hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_Ainv, P.d_ra, P.d_xa);
-    hipLaunchKernelGGL(k_spmv, dim3(gE), dim3(256), 0, st, flag, E, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 1,
+    hipLaunchKernelGGL(k_spmv, dim3(gV), dim3(256), 0, st, flag, (int64_t)nv, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 1,
                        (const double *)P.d_xa, (const int *)P.d_agg, P.d_t);
     NLG_HIP(hipGetLastError());
     *xc = P.d_t;
     return 0;
 }
 
-// Fine part: z = sum_e R_e^T Etilde_e^-1 R_e r (+ xc[e] when xc is given), launched on `st`.
+// Fine part: z = sum_e R_e^T Etilde_e^-1 R_e r (+ R_1 xc when xc is given), launched on `st`.
 int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
                double *rz_part) {
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
     const int64_t E = m->E;
+    Hat hat;
+    for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
+    const int *vg = P.d_vg;
 #define FDM_CASE(N_)                                                                                                  \
     if (m->dim == 3)                                                                                                  \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z, rz_part); \
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, vg, hat, z, rz_part); \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, z, rz_part);
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, vg, hat, z, rz_part);
     switch (m->n) {
         case 4: FDM_CASE(4); break;
         case 5: FDM_CASE(5); break;
@@ -600,10 +792,10 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
 
 void pprec_free(nlg_mesh *m) {
     nlg_pprec &P = m->pprec;
-    double *dp[] = {P.d_S, P.d_invden, P.d_av, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_t, P.d_ra, P.d_xa};
+    double *dp[] = {P.d_S, P.d_invden, P.d_av, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_t, P.d_ra, P.d_xa, P.d_tq};
     for (double *p : dp)
         if (p) hipFree(p);
-    int *ip[] = {P.d_rp, P.d_ci, P.d_agg, P.d_ap, P.d_am};
+    int *ip[] = {P.d_rp, P.d_ci, P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i};
     for (int *p : ip)
         if (p) hipFree(p);
     P = nlg_pprec();
