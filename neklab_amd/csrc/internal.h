@@ -128,11 +128,10 @@ struct nlg_pprec {
     double *d_tq = nullptr;                      // [E][ncorner] element-local restriction
     double hat1[16] = {};                        // (1 + z2)/2 at the GL points: the 1-D hat function of the upper corner
     double *d_S = nullptr, *d_invden = nullptr;  // FDM: [E][3][n2*n2] eigenvector matrices, [E][n2^dim] 1/(sum of eigenvalues)
-    int *d_rp = nullptr, *d_ci = nullptr;        // A_c in CSR
-    double *d_av = nullptr, *d_dinv = nullptr;
+    double *d_dinv = nullptr;                    // 1 / diag(A_c)
     int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;
     double *d_Ainv = nullptr;                    // dense inverse on the aggregates
-    double *d_rc = nullptr, *d_x = nullptr, *d_t = nullptr, *d_ra = nullptr, *d_xa = nullptr;
+    double *d_rc = nullptr, *d_x = nullptr, *d_ra = nullptr, *d_xa = nullptr;
 };
 
 struct nlg_mesh {

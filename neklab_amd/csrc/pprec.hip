@@ -19,8 +19,11 @@
 //   A_c = R_1^T E R_1 : Galerkin, sparse nvert x nvert (125-point on structured meshes).  Assembled by probing E on
 //             the device: elements are coloured so that no two of one colour share a neighbour, one E application
 //             per (colour, corner) gives the 2^dim x 2^dim blocks phi_c'^T E_{e',e} phi_c of every neighbouring pair.
-//   V(A_c)  : one symmetric V-cycle: damped-Jacobi sweep, exact solve on greedy aggregates of vertices (dense
-//             inverse), damped-Jacobi sweep.  When nvert is small the aggregates are the vertices (exact solve).
+//   V(A_c)  : additive two-grid approximation of A_c^-1: omega diag(A_c)^-1 + P (P^T A_c P)^-1 P^T with P the
+//             piecewise-constant prolongation from greedy aggregates of vertices (dense inverse on the aggregates).
+//             In the prototype it needs as few PCG iterations as the exact coarse solve or a multiplicative V-cycle
+//             (29-30), and it needs no product with A_c at run time.  When nvert is small the aggregates are the
+//             vertices (exact solve, no Jacobi term).
 //   With several ranks the coarse level is rank-local (E without the halo exchange): block-diagonal, still SPD.
 // M is a fixed symmetric positive (semi-)definite operator, so plain PCG stays valid.
 #include <algorithm>
@@ -97,7 +100,8 @@ __device__ __forceinline__ void fdm_stage(const double *__restrict__ in, double 
 template <int N2, int DIM>
 __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                             const double *__restrict__ invden, const double *__restrict__ r,
-                                            const double *__restrict__ xc, const int *__restrict__ vg, Hat hat,
+                                            const double *__restrict__ xc, const double *__restrict__ xa,
+                                            const int *__restrict__ agg, const int *__restrict__ vg, Hat hat,
                                             double *__restrict__ z, double *__restrict__ part) {
     constexpr int NP = DIM == 3 ? N2 * N2 * N2 : N2 * N2;
     __shared__ double sS[4][3][N2 * N2];
@@ -135,7 +139,10 @@ __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int
         constexpr int NC = 1 << DIM;
         double cv[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) cv[c] = xc ? xc[vg[e * NC + c]] : 0.0;
+        for (int c = 0; c < NC; ++c) {
+            const int v = xc ? vg[e * NC + c] : 0;
+            cv[c] = xc ? xc[v] + xa[agg[v]] : 0.0;   // Jacobi term + aggregate-level correction
+        }
         for (int q = lane; q < NP; q += 64) {
             const double ha = hat.h1[q % N2], hb = hat.h1[(q / N2) % N2];
             double c0 = (cv[0] + ha * (cv[1] - cv[0])), c1 = (cv[2] + ha * (cv[3] - cv[2]));
@@ -241,36 +248,6 @@ __global__ __launch_bounds__(NT) void k_q1_probe(int64_t E, int n2, Hat hat, con
         }
     }
     p[i] = w;
-}
-
-// `xa`/`agg` (may be null): the aggregate-level correction, prolonged on the fly: x_eff = x + xa[agg].
-// Eight lanes per row: the ~27 scattered reads of a row are issued together instead of one after another.
-__global__ __launch_bounds__(NT) void k_spmv(const double *flag, int64_t n, const int *__restrict__ rp,
-                                             const int *__restrict__ ci, const double *__restrict__ av,
-                                             const double *__restrict__ x, const double *__restrict__ b,
-                                             const double *__restrict__ dinv, double om, int mode,
-                                             const double *__restrict__ xa, const int *__restrict__ agg,
-                                             double *__restrict__ out) {
-    if (flag && flag[0] != 0.0) return;
-    const int sub = threadIdx.x & 7;
-    const int64_t i = (blockIdx.x * (int64_t)NT + threadIdx.x) >> 3;
-    double s = 0.0;
-    if (i < n) {
-        const int b0 = rp[i], e0 = rp[i + 1];
-        if (xa) {
-            for (int q = b0 + sub; q < e0; q += 8) s += av[q] * (x[ci[q]] + xa[agg[ci[q]]]);
-        } else {
-            for (int q = b0 + sub; q < e0; q += 8) s += av[q] * x[ci[q]];
-        }
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (i < n && sub == 0) {
-        const double res = b[i] - s;
-        const double xi = xa ? x[i] + xa[agg[i]] : x[i];
-        out[i] = mode == 0 ? res : xi + om * dinv[i] * res;
-    }
 }
 
 // ra[a] = sum of rr over the members of aggregate a, one wave per aggregate
@@ -717,30 +694,26 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     NLG_TRY(up(vg, &P.d_vg));
     NLG_TRY(up(vp, &P.d_v2e_p));
     NLG_TRY(up(vi, &P.d_v2e_i));
-    NLG_TRY(up(rp, &P.d_rp));
-    NLG_TRY(up(ci, &P.d_ci));
-    NLG_TRY(up(av, &P.d_av));
     NLG_TRY(up(dinv, &P.d_dinv));
     NLG_TRY(up(agg, &P.d_agg));
     NLG_TRY(up(ap, &P.d_ap));
     NLG_TRY(up(am, &P.d_am));
     NLG_TRY(up(Acc, &P.d_Ainv));
     NLG_HIP(hipMalloc(&P.d_tq, sizeof(double) * (size_t)E * NC));
-    for (double **v : {&P.d_rc, &P.d_x, &P.d_t}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(nvert, 1)));
+    for (double **v : {&P.d_rc, &P.d_x}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(nvert, 1)));
     for (double **v : {&P.d_ra, &P.d_xa}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(na, 1)));
     P.ready = true;
     return 0;
 }
 
-// Coarse part of M^-1 r: xc[v] (one value per element vertex) = V(A_c) R_1^T r, launched on `st`; pprec_fine
-// prolongs it.
+// Coarse part of M^-1 r on `st`: xc[v] = omega dinv[v] (R_1^T r)[v] and P.d_xa = aggregate-level solve; pprec_fine
+// adds the two while prolonging.
 int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc) {
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
     const int64_t E = m->E;
     const int nv = P.nvert;
-    const double om = 0.7;
-    const int gV = (int)(((int64_t)nv * 8 + 255) / 256);   // eight lanes per row
+    const double om = P.na == nv ? 0.0 : 0.7;   // exact coarse solve when every vertex is its own aggregate
     Hat hat;
     for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
     if (m->dim == 3) {
@@ -749,14 +722,10 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
         hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq);
     }
     hipLaunchKernelGGL(k_q1_gather, dim3((nv + NT - 1) / NT), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x);
-    hipLaunchKernelGGL(k_spmv, dim3(gV), dim3(256), 0, st, flag, (int64_t)nv, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 0,
-                       (const double *)nullptr, (const int *)nullptr, P.d_t);
-    hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_t, P.d_ra);
+    hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
     hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_Ainv, P.d_ra, P.d_xa);
-    hipLaunchKernelGGL(k_spmv, dim3(gV), dim3(256), 0, st, flag, (int64_t)nv, P.d_rp, P.d_ci, P.d_av, P.d_x, P.d_rc, P.d_dinv, om, 1,
-                       (const double *)P.d_xa, (const int *)P.d_agg, P.d_t);
     NLG_HIP(hipGetLastError());
-    *xc = P.d_t;
+    *xc = P.d_x;   // the Jacobi term; pprec_fine adds xa[agg[v]] while prolonging
     return 0;
 }
 
@@ -771,9 +740,9 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
     const int *vg = P.d_vg;
 #define FDM_CASE(N_)                                                                                                  \
     if (m->dim == 3)                                                                                                  \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, vg, hat, z, rz_part); \
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, vg, hat, z, rz_part);
+        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part);
     switch (m->n) {
         case 4: FDM_CASE(4); break;
         case 5: FDM_CASE(5); break;
@@ -792,10 +761,10 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
 
 void pprec_free(nlg_mesh *m) {
     nlg_pprec &P = m->pprec;
-    double *dp[] = {P.d_S, P.d_invden, P.d_av, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_t, P.d_ra, P.d_xa, P.d_tq};
+    double *dp[] = {P.d_S, P.d_invden, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_ra, P.d_xa, P.d_tq};
     for (double *p : dp)
         if (p) hipFree(p);
-    int *ip[] = {P.d_rp, P.d_ci, P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i};
+    int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i};
     for (int *p : ip)
         if (p) hipFree(p);
     P = nlg_pprec();

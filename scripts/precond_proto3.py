@@ -66,9 +66,14 @@ def run(nel, n, deform):
             for _ in range(nu): x = x + om * dinv * (bc - Ac @ x)
             return x
         x, it = pcg(A, b, lambda r: bj(r) + R @ vcycle(R.T @ r), 1e-7); res[(nu, om)] = it
+    for om in (0.5, 0.7, 1.0):
+        def addc(bc): return om * dinv * bc + R1.T @ (Accp @ (R1 @ bc))
+        x, it = pcg(A, b, lambda r: bj(r) + R @ addc(R.T @ r), 1e-7); res[('add', om)] = it
+    def post(bc):       # coarse first, then one Jacobi sweep on the residual, symmetrised by a mirrored pre-sweep is the V-cycle; this is the half-cost variant
+        x = R1.T @ (Accp @ (R1 @ bc)); return x + 0.7 * dinv * (bc - Ac @ x)
+    x, it = pcg(A, b, lambda r: bj(r) + R @ post(R.T @ r), 1e-7); res['post-only(nonsym)'] = it
     print(nel, n, 'E=%d nvert=%d na=%d nnz/row=%.0f' % (E_, nvert, na, np.count_nonzero(np.abs(Ac) > 1e-14) / nvert), res, 'time %.0f' % (time.time() - t0), flush=True)
 
 if __name__ == '__main__':
-    run((6, 6, 6), 6, 0.05)
     run((8, 8, 8), 6, 0.05)
-    run((12, 8, 8), 6, 0.05)
+    run((16, 8, 8), 6, 0.05)
