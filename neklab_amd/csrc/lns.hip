@@ -143,11 +143,13 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             x.p[c][i] += alpha * p.p[c][i];
-            const double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
+            double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
+            const double pcv = pc.p[c] ? pc.p[c][i] : 1.0;
+            if (pcv == 0.0) rv = 0.0;   // Dirichlet dof (the Helmholtz preconditioner carries the mask): w is not masked
             r.p[c][i] = rv;
             b += rv * rv * wn;
             if (pc.p[c]) {
-                const double zv = pc.p[c][i] * rv;
+                const double zv = pcv * rv;
                 z.p[c][i] = zv;
                 a += rv * zv * wi;
                 c3 += zv;
@@ -420,6 +422,7 @@ struct CGProblem {
     // first-stage sums produced by the operator / preconditioner kernels themselves (null = separate kernels)
     const double *pw_part = nullptr;   // [2][pw_n]: sum p.w , sum w   (written by `apply`)
     int pw_n = 0;
+    bool pw_sum = true;                // false: the sum of w is not provided (and not needed: inv_n == 0)
     const double *rz_part = nullptr;   // [2][rz_n]: sum r.z , sum z   (written by `precond`)
     int rz_n = 0;
 };
@@ -469,7 +472,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         rd_pw.p[0] = P.pw_part;
         rd_pw.n[0] = P.pw_n;
         rd_pw.p[1] = P.pw_part + P.pw_n;
-        rd_pw.n[1] = P.pw_n;
+        rd_pw.n[1] = P.pw_sum ? P.pw_n : 0;
     }
     NLG_TRY(reduce_post(rd_rz, 3, 0, 0));
     launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
@@ -533,14 +536,18 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     P.inv_n = 0.0;
     P.chunk = std::max(4, std::min(op->last_viters + 1, 32));
     const double nu = 1.0 / c.re;
-    auto apply = [&](double *s) -> int {
-        // w = mask * QQ^T (nu A + h2 B) p
-        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2));
+    // w = QQ^T (nu A + h2 B) p.  The Dirichlet mask is not applied to w: p is masked (z = pc r with pc = mask/diag), so
+    // (p, w) does not see the masked entries, and k_cg_update zeroes the residual where pc == 0.
+    // 3-D: (p, w) = sum over the local dofs of p . w_local (p is continuous), summed inside the operator kernel.
+    double *pw_part = dim == 3 ? op->d_part : nullptr;
+    if (pw_part) {
+        P.pw_part = pw_part;
+        P.pw_n = sem_axhelm_blocks(m, dim);
+        P.pw_sum = false;
+    }
+    auto apply = [&](double *) -> int {
+        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part));
         NLG_TRY(sem_gs(m, op->w, dim));
-        F3 fw = f3(op->w, dim);
-        CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
-        launch_nf(dim, k_colmul_gated<1>, k_colmul_gated<2>, k_colmul_gated<3>, dim3(grid_for(m->lvn)), m->ctx->stream,
-                  (const double *)s, fw, mk, m->lvn);
         return 0;
     };
     int iters = 0;

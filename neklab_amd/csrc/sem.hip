@@ -395,9 +395,11 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
                                                 const double *__restrict__ G0, const double *__restrict__ G1,
                                                 const double *__restrict__ G2, const double *__restrict__ G3,
                                                 const double *__restrict__ G4, const double *__restrict__ G5,
-                                                const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2) {
+                                                const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
+                                                double *__restrict__ pw_part) {
     constexpr int NP = N * N * N, NS = N * N;
     extern __shared__ double smem[];
+    __shared__ double sred[8];
     double *sD = smem;                   // N*N
     const int tid = threadIdx.x;
     const int slot = tid / NS;           // (element, field) slot inside the block
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
         sT[ij + k * NS] = h1 * (g2 * ur + g4 * us + g5 * ut);
     }
     __syncthreads();
+    double pw = 0.0;
 #pragma unroll 1
     for (int k = 0; k < N; ++k) {
         const int64_t q = base + ij + k * NS;
@@ -447,7 +450,23 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
 #pragma unroll
         for (int l = 0; l < N; ++l)
             a += dti[l] * sR[l + N * j + k * NS] + dtj[l] * sS[i + N * l + k * NS] + sD[l * N + k] * sT[ij + l * NS];
-        if (act) wc[q] = a;
+        if (act) {
+            wc[q] = a;
+            pw += a * sU[ij + k * NS];
+        }
+    }
+    if (pw_part) {
+        // first-stage sum of u . w_local of the surrounding PCG: for a continuous u this is (u, QQ^T w_local) with
+        // the inverse-multiplicity weight, so the solver needs no separate pass over p and w
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+        if ((tid & 63) == 0) sred[tid >> 6] = pw;
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0;
+            for (int q = 0; q < (int)((blockDim.x + 63) >> 6); ++q) a += sred[q];
+            pw_part[blockIdx.x] = a;
+        }
     }
 }
 
@@ -1120,25 +1139,37 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
     return halo_exchange(m, fields, nf);   // no-op on a single rank
 }
 
-int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2) {
+// (element, field) slots per block of k_axhelm3: bounded by 512 threads and by 64 KB of dynamic LDS
+static int axhelm3_nslot(int N) {
+    int nslot = 512 / (N * N);
+    const int lds_cap = (int)((64 * 1024 / 8 - N * N) / (4 * N * N * N));
+    if (nslot > lds_cap) nslot = lds_cap;
+    if (nslot > 6) nslot = 6;
+    if (nslot < 1) nslot = 1;
+    return nslot;
+}
+
+int sem_axhelm_blocks(nlg_mesh *m, int nf) {
+    const int nslot = axhelm3_nslot(m->n);
+    return (int)((m->E * nf + nslot - 1) / nslot);
+}
+
+int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
     ProfScope ps(m->ctx, P_AXHELM);
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
     F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
     hipStream_t s = m->ctx->stream;
+    NLG_CHECK(!pw_part || m->dim == 3, "sem_axhelm: the fused u.w sums exist in the 3-D kernel only");
     if (m->dim == 3) {
 #define AX3(N_)                                                                                                       \
     {                                                                                                                 \
-        int nslot = 512 / (N_ * N_);                                                                                  \
-        const int lds_cap = (int)((64 * 1024 / 8 - N_ * N_) / (4 * N_ * N_ * N_));                                    \
-        if (nslot > lds_cap) nslot = lds_cap;                                                                         \
-        if (nslot > 6) nslot = 6;                                                                                     \
-        if (nslot < 1) nslot = 1;                                                                                     \
+        const int nslot = axhelm3_nslot(N_);                                                                          \
         const int64_t tot = m->E * nf;                                                                                \
         const int grid = (int)((tot + nslot - 1) / nslot);                                                            \
         const size_t lds = sizeof(double) * (size_t)(N_ * N_ + nslot * 4 * N_ * N_ * N_);                             \
         hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2); \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part); \
     }
         NLG_FOR_N(AX3)
 #undef AX3
