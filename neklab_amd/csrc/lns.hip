@@ -253,19 +253,48 @@ __global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int max
     cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
 }
 
-// single rank: second-stage reduction and scalar logic in one launch (no all-reduce in between)
-__global__ __launch_bounds__(NT) void k_cg_final_post(double *s, Red rd, int nsums, int gate, int mode, double tol2,
-                                                      int use_tol, int maxit, double inv_n) {
-    __shared__ double sm[8];
+// single rank: second-stage reduction and scalar logic in one launch (no all-reduce in between).  One block of
+// 1024 threads; the (up to three) sums are accumulated together so that their loads overlap, and the per-thread
+// loop is unrolled four-fold for the same reason: the kernel is pure load latency.
+constexpr int NTF = 1024;
+__global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int nsums, int gate, int mode, double tol2,
+                                                       int use_tol, int maxit, double inv_n) {
+    __shared__ double sm[3][NTF / 64];
     if (gate && s[S_DONE] != 0.0) return;
-    for (int q = 0; q < nsums; ++q) {
-        double a = 0.0, b = 0.0;
-        for (int i = threadIdx.x; i < rd.n[q]; i += NT) a += rd.p[q][i];
-        block_sum2(a, b, sm);
-        if (threadIdx.x == 0) s[S_T0 + q] = a;
-        __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (q >= nsums) break;
+        const double *__restrict__ p = rd.p[q];
+        const int n = rd.n[q];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = threadIdx.x;
+        for (; i + 3 * NTF < n; i += 4 * NTF) {
+            a0 += p[i];
+            a1 += p[i + NTF];
+            a2 += p[i + 2 * NTF];
+            a3 += p[i + 3 * NTF];
+        }
+        for (; i < n; i += NTF) a0 += p[i];
+        acc[q] = (a0 + a1) + (a2 + a3);
     }
-    if (threadIdx.x == 0) cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double a = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0) sm[q][wid] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < nsums; ++q) {
+            double a = 0.0;
+            for (int w = 0; w < NTF / 64; ++w) a += sm[q][w];
+            s[S_T0 + q] = a;
+        }
+        cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
+    }
 }
 
 // generic pointwise helpers
@@ -444,7 +473,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     const Red rd_std = {{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
     auto reduce_post = [&](const Red &rd, int nsums, int gate, int mode) -> int {
         if (!ctx->comm) {
-            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NT), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
+            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
                                P.inv_n);
         } else {
             hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, (const double *)s, rd, nsums, s + S_T0, gate);

@@ -979,6 +979,234 @@ __global__ void k_conv_combine(int dim, int64_t n, CF3 Ur, CF3 du, CF3 uf, CF3 G
     }
 }
 
+// Fused weak linearised convective term, 3-D, one block per element (replaces 3 + 9 + 3 tensor launches and three
+// combine launches that round-tripped ~20 fine-mesh fields through HBM):
+//   out_i = J^T [ sgn * sum_j Ur_j (du_i/dr_j)_fine + sum_m uf_m Gsel_m ]      Gsel_m = GU[i][m] (direct), GU[m][i] (adjoint)
+// The only fine-mesh HBM traffic left is the twelve precomputed base-flow fields (Ur, GU), read once.
+// Phase A interpolates the three components to the fine mesh; each of the ND*ND threads that own a fine-mesh column
+// (a, b, :) keeps its 3 x ND values in registers.  Phase B, per component: x/y stages through LDS, the z stage
+// produces value and the three derivatives of the thread's column in registers, combines them with the base flow
+// (coalesced HBM reads: consecutive threads = consecutive (a, b)) and immediately applies J_z^T; the y and x
+// back-projections go through LDS again.
+// Work split of the LDS stages: lanes over the input columns, waves over the output index, so that every matrix
+// entry a wave needs has a wave-uniform address -> scalar loads straight into FMA operands (two 96-entry matrices
+// do not fit the scalar register file as kernel arguments: 366 spilled SGPRs and 2 ms per launch at E = 10k).
+// LDS leading dimensions are padded to odd values where a thread walks a row.
+template <int N, int ND>
+__global__ __launch_bounds__(NT, 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
+                                                 CF3 Ur, CF9 GU, CF3 u, F3 out, int adjoint) {
+    constexpr int NP = N * N * N, NPD = ND * ND * ND;
+    constexpr int NQ = N | 1, NDQ = ND | 1;          // padded (odd) leading dimensions
+    constexpr int SU = NQ * N * N;                   // u:  (i | j, k), row stride NQ
+    constexpr int SX = NDQ * N * N;                  // after the x stage: (a | j, k), row stride NDQ
+    constexpr int SY = ND * ND * N;                  // after the y stage: (a, b, k)
+    constexpr int NCOLZ = ND * ND;                   // fine columns along z
+    constexpr int NW = NT / 64;
+    static_assert(NCOLZ <= NT, "one thread per fine-mesh column");
+    __shared__ double sU[3][SU];
+    __shared__ double sW[2 * SX + 3 * SY];
+    double *sA = sW, *sB = sW + SX, *sAA = sW + 2 * SX, *sAD = sAA + SY, *sBA = sAD + SY;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t e = blockIdx.x;
+    if (e >= E) return;
+    for (int t = tid; t < 3 * NP; t += NT) {
+        const int c = t / NP, q = t % NP;
+        sU[c][(q % N) + NQ * (q / N)] = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]))[e * NP + q];
+    }
+    double ufr[3][ND];
+    constexpr int OD = (ND + NW - 1) / NW;   // fine-index outputs per wave
+    constexpr int ON = (N + NW - 1) / NW;    // coarse-index outputs per wave
+    __syncthreads();
+    // ---- phase A: uf_m on the fine mesh, columns in registers
+#pragma unroll
+    for (int mcomp = 0; mcomp < 3; ++mcomp) {   // unrolled: ufr must be indexed statically to stay in registers
+        for (int col = lane; col < N * N; col += 64) {
+            double v[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = sU[mcomp][i + NQ * col];
+#pragma unroll
+            for (int o = 0; o < OD; ++o) {
+                const int a = wave + NW * o;
+                if (a < ND) {
+                    const double *__restrict__ row = Jg + a * N;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc += row[i] * v[i];
+                    sA[a + NDQ * col] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        for (int col = lane; col < ND * N; col += 64) {
+            const int a = col % ND, k = col / ND;
+            double v[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = sA[a + NDQ * (j + N * k)];
+#pragma unroll
+            for (int o = 0; o < OD; ++o) {
+                const int b = wave + NW * o;
+                if (b < ND) {
+                    const double *__restrict__ row = Jg + b * N;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc += row[j] * v[j];
+                    sAA[a + ND * (b + ND * k)] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < NCOLZ) {
+            double v[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = sAA[tid + NCOLZ * k];
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) acc += Jg[c * N + k] * v[k];
+                ufr[mcomp][c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase B: one output component at a time
+    const double sgn = adjoint ? -1.0 : 1.0;
+#pragma unroll 1
+    for (int ic = 0; ic < 3; ++ic) {
+        // x stage: A = J_x u_i, B = DJ_x u_i
+        for (int col = lane; col < N * N; col += 64) {
+            double v[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = sU[ic][i + NQ * col];
+#pragma unroll
+            for (int o = 0; o < OD; ++o) {
+                const int a = wave + NW * o;
+                if (a < ND) {
+                    const double *__restrict__ r0 = Jg + a * N, *__restrict__ r1 = DJg + a * N;
+                    double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        x0 += r0[i] * v[i];
+                        x1 += r1[i] * v[i];
+                    }
+                    sA[a + NDQ * col] = x0;
+                    sB[a + NDQ * col] = x1;
+                }
+            }
+        }
+        __syncthreads();
+        // y stage: AA = J_y A, AD = DJ_y A, BA = J_y B
+        for (int col = lane; col < ND * N; col += 64) {
+            const int a = col % ND, k = col / ND;
+            double va[N], vb[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                va[j] = sA[a + NDQ * (j + N * k)];
+                vb[j] = sB[a + NDQ * (j + N * k)];
+            }
+#pragma unroll
+            for (int o = 0; o < OD; ++o) {
+                const int b = wave + NW * o;
+                if (b < ND) {
+                    const double *__restrict__ r0 = Jg + b * N, *__restrict__ r1 = DJg + b * N;
+                    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        y0 += r0[j] * va[j];
+                        y1 += r1[j] * va[j];
+                        y2 += r0[j] * vb[j];
+                    }
+                    sAA[a + ND * (b + ND * k)] = y0;
+                    sAD[a + ND * (b + ND * k)] = y1;
+                    sBA[a + ND * (b + ND * k)] = y2;
+                }
+            }
+        }
+        __syncthreads();
+        // z stage + combination with the base flow + J_z^T, per fine column
+        double T[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) T[k] = 0.0;
+        if (tid < NCOLZ) {
+            double v0[N], v1[N], v2[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                v0[k] = sAA[tid + NCOLZ * k];
+                v1[k] = sAD[tid + NCOLZ * k];
+                v2[k] = sBA[tid + NCOLZ * k];
+            }
+            const int64_t qb = e * NPD + tid;
+            const double *g0 = adjoint ? GU.p[0 * 3 + ic] : GU.p[ic * 3 + 0];
+            const double *g1 = adjoint ? GU.p[1 * 3 + ic] : GU.p[ic * 3 + 1];
+            const double *g2 = adjoint ? GU.p[2 * 3 + ic] : GU.p[ic * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                const int64_t q = qb + (int64_t)NCOLZ * c;
+                const double b0 = Ur.p[0][q], b1 = Ur.p[1][q], b2 = Ur.p[2][q];
+                const double h0 = g0[q], h1 = g1[q], h2 = g2[q];
+                double ut = 0.0, us = 0.0, ur = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    ut += DJg[c * N + k] * v0[k];
+                    us += Jg[c * N + k] * v1[k];
+                    ur += Jg[c * N + k] * v2[k];
+                }
+                const double acc = sgn * (b0 * ur + b1 * us + b2 * ut) + (ufr[0][c] * h0 + ufr[1][c] * h1 + ufr[2][c] * h2);
+#pragma unroll
+                for (int k = 0; k < N; ++k) T[k] += Jg[c * N + k] * acc;
+            }
+        }
+        __syncthreads();   // every thread is done with sAA/sAD/sBA and sA/sB
+        // T -> LDS as (a, b, kz), reusing sAA
+        if (tid < NCOLZ) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) sAA[tid + NCOLZ * k] = T[k];
+        }
+        __syncthreads();
+        // back y stage: S(a, j, kz) = sum_b J[b][j] T(a, b, kz), into sA
+        for (int col = lane; col < ND * N; col += 64) {
+            const int a = col % ND, k = col / ND;
+            double v[ND];
+#pragma unroll
+            for (int b = 0; b < ND; ++b) v[b] = sAA[a + ND * (b + ND * k)];
+#pragma unroll
+            for (int o = 0; o < ON; ++o) {
+                const int j = wave + NW * o;
+                if (j < N) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int b = 0; b < ND; ++b) acc += Jg[b * N + j] * v[b];
+                    sA[a + NDQ * (j + N * k)] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        // back x stage: out(i, j, kz) = sum_a J[a][i] S(a, j, kz) -> LDS (reusing sB) -> coalesced store
+        for (int col = lane; col < N * N; col += 64) {
+            double v[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) v[a] = sA[a + NDQ * col];
+#pragma unroll
+            for (int o = 0; o < ON; ++o) {
+                const int i = wave + NW * o;
+                if (i < N) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < ND; ++a) acc += Jg[a * N + i] * v[a];
+                    sB[i + NQ * col] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            double *op = (ic == 0 ? out.p[0] : (ic == 1 ? out.p[1] : out.p[2])) + e * NP;
+            for (int q = tid; q < NP; q += NT) op[q] = sB[(q % N) + NQ * (q / N)];
+        }
+        __syncthreads();
+    }
+}
+
 // CFL (Nek compute_cfl): max over points of dt * sum_j |u_rj| * rdr
 __global__ __launch_bounds__(NT) void k_cfl(int dim, int n, int64_t E, CF9 rst, const double *jac, const double *rdr,
                                             CF3 U, double dt, double *partial) {
@@ -1401,6 +1629,26 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
     ProfScope ps(m->ctx, P_CONV);
     const int dim = m->dim;
+    if (dim == 3 && m->n <= 8 && m->nd == (3 * m->n) / 2) {
+        // fused kernel (LDS budget: lx1 <= 8 with the standard 3/2 dealiasing mesh)
+        CF3 cur = {{Ur[0], Ur[1], Ur[2]}}, cu = {{u[0], u[1], u[2]}};
+        CF9 cg;
+        for (int q = 0; q < 9; ++q) cg.p[q] = GU[q];
+        F3 co = {{out[0], out[1], out[2]}};
+#define CV3(N_)                                                                                                       \
+    hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E,           \
+                       (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, adjoint);
+        switch (m->n) {
+            case 4: CV3(4); break;
+            case 5: CV3(5); break;
+            case 6: CV3(6); break;
+            case 7: CV3(7); break;
+            default: CV3(8); break;
+        }
+#undef CV3
+        NLG_HIP(hipGetLastError());
+        return 0;
+    }
     double *uf[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
     double *du[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), dim == 3 ? sem_scratchd(m, 5) : nullptr};
     double *acc = sem_scratchd(m, 6);
