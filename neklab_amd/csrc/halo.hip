@@ -193,25 +193,37 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     NLG_TRY(up(rpos, &h.d_rpos));
     NLG_TRY(up(coff, &h.d_coff));
     NLG_TRY(up(cidx, &h.d_cidx));
+    if (!m->h_slot.empty()) {
+        // the same lists for fields kept in the face-grouped element layout (3-D pressure operator)
+        auto to_fg = [&](std::vector<int> v) {
+            for (int &i : v) i = (i / np1) * np1 + m->h_slot[i % np1];
+            return v;
+        };
+        NLG_TRY(up(to_fg(send_idx), &h.d_send_idx_fg));
+        NLG_TRY(up(to_fg(cidx), &h.d_cidx_fg));
+    }
     NLG_HIP(hipMalloc(&h.d_send, sizeof(double) * (size_t)tot * 3));
     NLG_HIP(hipMalloc(&h.d_recv, sizeof(double) * (size_t)tot * 3));
     h.active = true;
     return 0;
 }
 
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf) {
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped) {
     nlg_halo &h = m->halo;
     if (!h.active) return 0;
+    NLG_CHECK(!face_grouped || h.d_send_idx_fg, "halo_exchange: no face-grouped index lists");
+    const int *send_idx = face_grouped ? h.d_send_idx_fg : h.d_send_idx;
+    const int *cidx = face_grouped ? h.d_cidx_fg : h.d_cidx;
     nlg_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
     const int g1 = (int)((h.ntot + NT - 1) / NT);
     if (nf == 1)
-        hipLaunchKernelGGL(k_halo_pack<1>, dim3(g1), dim3(NT), 0, st, h.d_send_idx, h.ntot, f, h.d_send);
+        hipLaunchKernelGGL(k_halo_pack<1>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
     else if (nf == 2)
-        hipLaunchKernelGGL(k_halo_pack<2>, dim3(g1), dim3(NT), 0, st, h.d_send_idx, h.ntot, f, h.d_send);
+        hipLaunchKernelGGL(k_halo_pack<2>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
     else
-        hipLaunchKernelGGL(k_halo_pack<3>, dim3(g1), dim3(NT), 0, st, h.d_send_idx, h.ntot, f, h.d_send);
+        hipLaunchKernelGGL(k_halo_pack<3>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
     NLG_NCCL(ncclGroupStart());
     for (size_t q = 0; q < h.neigh.size(); ++q)
         for (int c = 0; c < nf; ++c) {
@@ -221,18 +233,18 @@ int halo_exchange(nlg_mesh *m, double *const *fields, int nf) {
     NLG_NCCL(ncclGroupEnd());
     const int g2 = (int)((h.nlab + NT - 1) / NT);
     if (nf == 1)
-        hipLaunchKernelGGL(k_halo_unpack<1>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.ntot, h.d_recv, f);
+        hipLaunchKernelGGL(k_halo_unpack<1>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
     else if (nf == 2)
-        hipLaunchKernelGGL(k_halo_unpack<2>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.ntot, h.d_recv, f);
+        hipLaunchKernelGGL(k_halo_unpack<2>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
     else
-        hipLaunchKernelGGL(k_halo_unpack<3>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.ntot, h.d_recv, f);
+        hipLaunchKernelGGL(k_halo_unpack<3>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
     NLG_HIP(hipGetLastError());
     return 0;
 }
 
 void halo_free(nlg_mesh *m) {
     nlg_halo &h = m->halo;
-    int *ip[] = {h.d_send_idx, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx};
+    int *ip[] = {h.d_send_idx, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.d_send_idx_fg, h.d_cidx_fg};
     for (int *p : ip)
         if (p) hipFree(p);
     if (h.d_send) hipFree(h.d_send);

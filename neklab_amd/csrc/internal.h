@@ -115,6 +115,7 @@ struct nlg_halo {
     int *d_send_idx = nullptr;       // [ntot] representative local dof per (neighbour, label)
     int *d_roff = nullptr, *d_rpos = nullptr;   // per distinct shared label: positions in the recv buffer
     int *d_coff = nullptr, *d_cidx = nullptr;   // per distinct shared label: all local copies
+    int *d_send_idx_fg = nullptr, *d_cidx_fg = nullptr;   // d_send_idx / d_cidx for the face-grouped element layout
     double *d_send = nullptr, *d_recv = nullptr;
 };
 
@@ -236,7 +237,7 @@ void pprec_free(nlg_mesh *m);
 
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf);
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped = false);
 void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----

@@ -207,19 +207,6 @@ struct Red {
     int n[3];
 };
 
-// second stage: out[q] = sum_b rd.p[q][b], q < nsums  (one block, fixed order)
-__global__ __launch_bounds__(NT) void k_cg_final(const double *s, Red rd, int nsums, double *out, int gate) {
-    __shared__ double sm[8];
-    if (gate && s[S_DONE] != 0.0) return;
-    for (int q = 0; q < nsums; ++q) {
-        double a = 0.0, b = 0.0;
-        for (int i = threadIdx.x; i < rd.n[q]; i += NT) a += rd.p[q][i];
-        block_sum2(a, b, sm);
-        if (threadIdx.x == 0) out[q] = a;
-        __syncthreads();
-    }
-}
-
 // scalar logic, one thread. mode 0: after init (T0 = rz, T1 = rn2, T2 = sum z) ; 1: after pw (T0 = pw, T1 = sum w) ;
 // 2: after update (T0 = rz, T1 = rn2, T2 = sum z).  inv_n = 1/n for the projected solve, 0 otherwise.
 __device__ __forceinline__ void cg_post_logic(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n) {
@@ -253,12 +240,12 @@ __global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int max
     cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
 }
 
-// single rank: second-stage reduction and scalar logic in one launch (no all-reduce in between).  One block of
+// Second-stage reduction and (single rank: no all-reduce in between) the scalar logic in one launch.  One block of
 // 1024 threads; the (up to three) sums are accumulated together so that their loads overlap, and the per-thread
 // loop is unrolled four-fold for the same reason: the kernel is pure load latency.
 constexpr int NTF = 1024;
 __global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int nsums, int gate, int mode, double tol2,
-                                                       int use_tol, int maxit, double inv_n) {
+                                                       int use_tol, int maxit, double inv_n, int post) {
     __shared__ double sm[3][NTF / 64];
     if (gate && s[S_DONE] != 0.0) return;
     double acc[3] = {0.0, 0.0, 0.0};
@@ -293,7 +280,7 @@ __global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int ns
             for (int w = 0; w < NTF / 64; ++w) a += sm[q][w];
             s[S_T0 + q] = a;
         }
-        cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
+        if (post) cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);   // several ranks: the all-reduce comes first
     }
 }
 
@@ -474,9 +461,10 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     auto reduce_post = [&](const Red &rd, int nsums, int gate, int mode) -> int {
         if (!ctx->comm) {
             hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
-                               P.inv_n);
+                               P.inv_n, 1);
         } else {
-            hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(NT), 0, st, (const double *)s, rd, nsums, s + S_T0, gate);
+            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
+                               P.inv_n, 0);
             NLG_TRY(allreduce_sum(ctx, s + S_T0, nsums));
             hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n);
         }
@@ -610,7 +598,7 @@ int pres_solve(nlg_linop *op, double scale) {
     if (c.pprecond == 0) {   // two-level FDM + coarse V-cycle (pprec.hip); 1 = Jacobi on diag(E), as in the oracle
         P.pc = nopc;
         P.npe = m->np2;
-        double *rzp = (m->dim == 3 && !m->ctx->comm) ? op->d_part + 2 * m->E : nullptr;
+        double *rzp = m->dim == 3 ? op->d_part + 2 * m->E : nullptr;
         P.precond = [m, rzp](const double *flag, const double *rr, double *zz, const double **xc) -> int {
             // one stream: a fork/join through events costs more than it hides (measured: 98 vs 84 us per apply)
             nlg_ctx *c = m->ctx;
@@ -623,7 +611,7 @@ int pres_solve(nlg_linop *op, double scale) {
         };
     }
     P.chunk = std::max(8, std::min(op->last_piters / 4 + 1, 64));
-    const bool fuse = (m->dim == 3) && !m->ctx->comm;   // the fused first-stage sums are rank-local only in layout, fine either way
+    const bool fuse = m->dim == 3;   // the fused first-stage sums are rank-local; the all-reduce follows the second stage
     double *pw_part = nullptr;
     if (fuse) {
         pw_part = op->d_part;

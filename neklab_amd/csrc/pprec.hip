@@ -673,9 +673,9 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         for (int q = rp[u]; q < rp[u + 1]; ++q) Acc[(size_t)agg[u] * na + agg[ci[q]]] += av[q];
     for (int i = 0; i < na; ++i)
         for (int j = i + 1; j < na; ++j) Acc[(size_t)i * na + j] = Acc[(size_t)j * na + i] = 0.5 * (Acc[(size_t)i * na + j] + Acc[(size_t)j * na + i]);
-    if (!m->has_outflow) {
+    if (!m->has_outflow && ctx->nranks <= 1) {
         // constant null space (the hats sum to one): shift it so that the inverse acts as the pseudo-inverse on
-        // mean-free data.  With several ranks the rank-local operator has the same null vector.
+        // mean-free data.  With several ranks the rank-local operator (no halo) is positive definite as it is.
         double tr = 0.0;
         for (int i = 0; i < na; ++i) tr += Acc[(size_t)i * na + i];
         const double alpha = tr / na / na;   // the null vector of the aggregated operator is the vector of ones

@@ -1538,9 +1538,9 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part) {
     double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
     NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
-    if (m->dim == 3 && !m->halo.active && m->gs.d_indices_fg) {
-        // single rank, 3-D: the intermediate velocity-mesh fields use the face-grouped element layout, in which
-        // the copies of a shared face are contiguous runs -> coalesced gather-scatter
+    if (m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg)) {
+        // 3-D: the intermediate velocity-mesh fields use the face-grouped element layout, in which the copies of a
+        // shared face are contiguous runs -> coalesced gather-scatter; the rank halo uses index lists in that layout
         NLG_TRY(sem_opgradt(m, p, w, true));
         if (m->gs.ngroups > 0) {
             ProfScope ps(m->ctx, P_GS);
@@ -1548,6 +1548,10 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part) {
             const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
             hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, f);
             NLG_HIP(hipGetLastError());
+        }
+        if (m->halo.active) {
+            ProfScope ps(m->ctx, P_GS);
+            NLG_TRY(halo_exchange(m, w, 3, true));
         }
         NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part));
         return 0;
