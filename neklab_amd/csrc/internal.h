@@ -98,6 +98,7 @@ struct nlg_gs {
     // groups of local dofs that share a global label (only groups of size >= 2 are stored)
     int64_t ngroups = 0;
     int64_t nshared = 0;
+    int64_t npairs = 0;         // the first npairs groups have exactly two copies (same count in both layouts)
     int *d_offsets = nullptr;   // [ngroups + 1]
     int *d_indices = nullptr;   // [nshared] local dof index
     // the same groups in the face-grouped element layout used for the intermediate fields of the consistent

@@ -350,11 +350,24 @@ __global__ void k_mul(double *y, const double *a, const double *b, int64_t n) {
 // =================================================================================================
 // gather-scatter: one thread per group of local copies of a shared global dof
 // =================================================================================================
+// The groups are stored pairs first (a shared face interior: two copies, ~3/4 of all groups in 3-D): a thread of the
+// pair range reads its two indices as one int2 and needs neither the offset array nor a loop; the remaining groups
+// (edges, corners, irregular valences) go through the general CSR path.  Sums run over ascending local index.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const int *__restrict__ idx, int64_t ngroups,
-                                           F3 f) {
+                                           int64_t npairs, F3 f) {
     const int64_t g = blockIdx.x * (int64_t)NT + threadIdx.x;
     if (g >= ngroups) return;
+    if (g < npairs) {
+        const int2 ab = reinterpret_cast<const int2 *>(idx)[g];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double s = f.p[c][ab.x] + f.p[c][ab.y];
+            f.p[c][ab.x] = s;
+            f.p[c][ab.y] = s;
+        }
+        return;
+    }
     const int b = off[g], e = off[g + 1];
     double s[NF];
 #pragma unroll
@@ -580,19 +593,33 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
 // arguments, i.e. in the scalar kernarg segment, so the matrix operand of every FMA is an SGPR pair and costs no
 // LDS or vector-memory traffic.  NC = velocity components processed per pass (3 when the LDS image of all three
 // fits, else 1).
-// Face-grouped slot of point (a, j, k) inside an element: x- face, x+ face, y- (without x faces), y+, z-, z+,
-// then the interior.  FG = false gives the natural ix-fastest index.
+// Face-grouped slot of point (a, j, k) inside an element: the 8 corners, the 12 edges (interior points of an edge
+// contiguous), the 6 face interiors (contiguous (N-2)^2 blocks), then the element interior.  The copies of a shared
+// face or edge are then contiguous runs in every element that shares it, so the gather-scatter moves whole runs
+// instead of one 8-byte word per 64-byte line.  FG = false gives the natural ix-fastest index.
+__host__ __device__ __forceinline__ int fg_slot(int N, int a, int j, int k) {
+    const int M = N - 2;
+    const int ba = (a == 0 || a == N - 1), bj = (j == 0 || j == N - 1), bk = (k == 0 || k == N - 1);
+    const int sa = a == N - 1, sj = j == N - 1, sk = k == N - 1;
+    const int nb = ba + bj + bk;
+    if (nb == 3) return sa + 2 * sj + 4 * sk;
+    if (nb == 2) {
+        if (!ba) return 8 + (0 + sj + 2 * sk) * M + (a - 1);
+        if (!bj) return 8 + (4 + sa + 2 * sk) * M + (j - 1);
+        return 8 + (8 + sa + 2 * sj) * M + (k - 1);
+    }
+    const int fbase = 8 + 12 * M;
+    if (nb == 1) {
+        if (ba) return fbase + (0 + sa) * M * M + (j - 1) + M * (k - 1);
+        if (bj) return fbase + (2 + sj) * M * M + (a - 1) + M * (k - 1);
+        return fbase + (4 + sk) * M * M + (a - 1) + M * (j - 1);
+    }
+    return fbase + 6 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
+}
 template <int N, bool FG>
 __device__ __forceinline__ int elem_slot(int a, int j, int k) {
     if (!FG) return a + N * (j + N * k);
-    constexpr int M = N - 2, F = N * N;
-    if (a == 0) return j + N * k;
-    if (a == N - 1) return F + j + N * k;
-    if (j == 0) return 2 * F + (a - 1) + M * k;
-    if (j == N - 1) return 2 * F + M * N + (a - 1) + M * k;
-    if (k == 0) return 2 * F + 2 * M * N + (a - 1) + M * (j - 1);
-    if (k == N - 1) return 2 * F + 2 * M * N + M * M + (a - 1) + M * (j - 1);
-    return 2 * F + 2 * M * N + 2 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
+    return fg_slot(N, a, j, k);
 }
 
 template <int N>
@@ -1357,11 +1384,11 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
         F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
         const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
         if (nf == 1)
-            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, f);
         else if (nf == 2)
-            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, f);
         else
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, f);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, f);
         NLG_HIP(hipGetLastError());
     }
     return halo_exchange(m, fields, nf);   // no-op on a single rank
@@ -1546,7 +1573,7 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part) {
             ProfScope ps(m->ctx, P_GS);
             F3 f = {{w[0], w[1], w[2]}};
             const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, f);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, f);
             NLG_HIP(hipGetLastError());
         }
         if (m->halo.active) {
@@ -1860,7 +1887,13 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
             if (e - b >= 2) groups.push_back({order[b], {(int)b, (int)e}});
             b = e;
         }
-        std::sort(groups.begin(), groups.end());
+        // pairs first, each class ordered by its first (smallest) local index
+        auto is_pair = [](const std::pair<int, std::pair<int, int>> &g) { return g.second.second - g.second.first == 2; };
+        std::sort(groups.begin(), groups.end(), [&](const auto &a, const auto &b) {
+            const bool pa = is_pair(a), pb = is_pair(b);
+            return pa != pb ? pa : a < b;
+        });
+        m->gs.npairs = (int64_t)std::count_if(groups.begin(), groups.end(), is_pair);
         for (auto &g : groups) {
             for (int q = g.second.first; q < g.second.second; ++q) idx.push_back(order[q]);
             off.push_back((int)idx.size());
@@ -1869,27 +1902,18 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         m->gs.nshared = (int64_t)idx.size();
         if (dim == 3 && !groups.empty()) {
             // the same groups in face-grouped numbering, re-sorted by their first index
-            const int M2 = n - 2, F = n * n;
             std::vector<int> slot((size_t)m->np1);
-            for (int p = 0; p < m->np1; ++p) {
-                const int a = p % n, j = (p / n) % n, k = p / (n * n);
-                int sl;
-                if (a == 0) sl = j + n * k;
-                else if (a == n - 1) sl = F + j + n * k;
-                else if (j == 0) sl = 2 * F + (a - 1) + M2 * k;
-                else if (j == n - 1) sl = 2 * F + M2 * n + (a - 1) + M2 * k;
-                else if (k == 0) sl = 2 * F + 2 * M2 * n + (a - 1) + M2 * (j - 1);
-                else if (k == n - 1) sl = 2 * F + 2 * M2 * n + M2 * M2 + (a - 1) + M2 * (j - 1);
-                else sl = 2 * F + 2 * M2 * n + 2 * M2 * M2 + (a - 1) + M2 * ((j - 1) + M2 * (k - 1));
-                slot[p] = sl;
-            }
+            for (int p = 0; p < m->np1; ++p) slot[p] = fg_slot(n, p % n, (p / n) % n, p / (n * n));
             m->h_slot = slot;
             std::vector<std::vector<int>> gl(groups.size());
             for (size_t gi = 0; gi + 1 < off.size(); ++gi) {
                 for (int q = off[gi]; q < off[gi + 1]; ++q) gl[gi].push_back((idx[q] / m->np1) * m->np1 + slot[idx[q] % m->np1]);
                 std::sort(gl[gi].begin(), gl[gi].end());
             }
-            std::sort(gl.begin(), gl.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a[0] < b[0]; });
+            std::sort(gl.begin(), gl.end(), [](const std::vector<int> &a, const std::vector<int> &b) {
+                const bool pa = a.size() == 2, pb = b.size() == 2;
+                return pa != pb ? pa : a[0] < b[0];
+            });
             std::vector<int> off2{0}, idx2;
             for (auto &v : gl) {
                 idx2.insert(idx2.end(), v.begin(), v.end());
