@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--nsteps", type=int, default=2, help="time steps per matvec before the torder-1 history steps")
     ap.add_argument("--re", type=float, default=100.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--pprecond", type=int, default=0, help="pressure preconditioner (0 default, 2 = no overlap, 1 = Jacobi)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -120,7 +121,8 @@ def main():
     host.check(lib.nlg_op_cfl(gm.h, bf.h, 1.0, C.byref(cfl1)))
     dt0 = 0.5 / cfl1.value
     tau = dt0 * (args.nsteps - 0.5)
-    A = host.exptA_linop(tau, bf, re=args.re, torder=3, vtol=1e-9, ptol=1e-7, maxit_v=200, maxit_p=4000)
+    A = host.exptA_linop(tau, bf, re=args.re, torder=3, vtol=1e-9, ptol=1e-7, maxit_v=200, maxit_p=4000,
+                         pprecond=args.pprecond)
     A.init()
     info = A.info()
     assert info["nsteps"] == args.nsteps, info

@@ -169,7 +169,8 @@ typedef struct nlg_exptA_config {
     int maxit_p;
     int fixed_iters_v; /* > 0: run exactly this many PCG iterations (parity / benchmarking mode)      */
     int fixed_iters_p;
-    int pprecond;      /* pressure preconditioner: 0 = two-level (element FDM + coarse V-cycle), 1 = Jacobi   */
+    int pprecond;      /* pressure preconditioner: 0 = two-level Schwarz (element FDM with one layer of face overlap
+                          in 3-D for lx1 <= 8 + vertex coarse space), 1 = Jacobi, 2 = two-level without overlap    */
 } nlg_exptA_config;
 
 int nlg_exptA_config_default(nlg_exptA_config *cfg);
@@ -203,6 +204,10 @@ int nlg_linop_get_stats(const nlg_linop *op, int64_t *steps, int64_t *v_iters, i
 int nlg_op_helmholtz(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out, double h1, double h2, int assemble);
 int nlg_op_dssum(nlg_mesh *mesh, nlg_vec *v);
 int nlg_op_cdabdtp(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out);
+/* out%pr = M^-1 in%pr, the two-level Schwarz preconditioner the pressure solve uses for E (Nek5000's role:
+   `preconditioner = semg_xxt`, examples/cylinder/stability/direct/1cyl.par:21).  overlap != 0: local solves with one
+   layer of face overlap (3-D, lx1 <= 8); with_coarse == 0: local solves only.  M is symmetric positive semi-definite. */
+int nlg_op_pprec(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out, int overlap, int with_coarse);
 int nlg_op_opdiv(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out);
 int nlg_op_opgradt(nlg_mesh *mesh, const nlg_vec *in, nlg_vec *out);
 int nlg_op_conv(nlg_mesh *mesh, const nlg_vec *base, const nlg_vec *in, nlg_vec *out, int adjoint);

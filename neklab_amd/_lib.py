@@ -102,6 +102,7 @@ SIGNATURES = {
     "nlg_op_helmholtz": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int]),
     "nlg_op_dssum": (C.c_int, [vp, vp]),
     "nlg_op_cdabdtp": (C.c_int, [vp, vp, vp]),
+    "nlg_op_pprec": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
     "nlg_op_opdiv": (C.c_int, [vp, vp, vp]),
     "nlg_op_opgradt": (C.c_int, [vp, vp, vp]),
     "nlg_op_conv": (C.c_int, [vp, vp, vp, vp, C.c_int]),

@@ -94,6 +94,30 @@ struct nlg_ops1d {
     std::vector<double> rdr;   // n  inverse reference spacing (CFL)
 };
 
+// Face-grouped slot of point (a, j, k) inside an element: the 8 corners, the 12 edges (interior points of an edge
+// contiguous), the 6 face interiors (contiguous (N-2)^2 blocks), then the element interior.  The copies of a shared
+// face or edge are then contiguous runs in every element that shares it, so the gather-scatter moves whole runs
+// instead of one 8-byte word per 64-byte line.  FG = false gives the natural ix-fastest index.
+__host__ __device__ inline int fg_slot(int N, int a, int j, int k) {
+    const int M = N - 2;
+    const int ba = (a == 0 || a == N - 1), bj = (j == 0 || j == N - 1), bk = (k == 0 || k == N - 1);
+    const int sa = a == N - 1, sj = j == N - 1, sk = k == N - 1;
+    const int nb = ba + bj + bk;
+    if (nb == 3) return sa + 2 * sj + 4 * sk;
+    if (nb == 2) {
+        if (!ba) return 8 + (0 + sj + 2 * sk) * M + (a - 1);
+        if (!bj) return 8 + (4 + sa + 2 * sk) * M + (j - 1);
+        return 8 + (8 + sa + 2 * sj) * M + (k - 1);
+    }
+    const int fbase = 8 + 12 * M;
+    if (nb == 1) {
+        if (ba) return fbase + (0 + sa) * M * M + (j - 1) + M * (k - 1);
+        if (bj) return fbase + (2 + sj) * M * M + (a - 1) + M * (k - 1);
+        return fbase + (4 + sk) * M * M + (a - 1) + M * (j - 1);
+    }
+    return fbase + 6 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
+}
+
 struct nlg_gs {
     // groups of local dofs that share a global label (only groups of size >= 2 are stored)
     int64_t ngroups = 0;
@@ -131,6 +155,11 @@ struct nlg_pprec {
     double hat1[16] = {};                        // (1 + z2)/2 at the GL points: the 1-D hat function of the upper corner
     double *d_S = nullptr, *d_invden = nullptr;  // FDM: [E][3][n2*n2] eigenvector matrices, [E][n2^dim] 1/(sum of eigenvalues)
     double *d_dinv = nullptr;                    // 1 / diag(A_c)
+    // overlapping variant (3-D, lx1 <= 8): extended 1-D eigen-decompositions [E][3][n*n], eigenvalues [E][3][n], the
+    // velocity-shaped exchange array (face-grouped layout) and the zero-denominator threshold
+    bool overlap = false;
+    double *d_Sx = nullptr, *d_lamx = nullptr, *d_W = nullptr, *d_wq = nullptr;   // d_wq: count^-1/2 weights [E][n2^3]
+    double thrx = 0.0;
     int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;
     double *d_Ainv = nullptr;                    // dense inverse on the aggregates
     double *d_rc = nullptr, *d_x = nullptr, *d_ra = nullptr, *d_xa = nullptr;
@@ -231,9 +260,9 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
 
 // ---- pprec.hip ----
 int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d);
-int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc);
+int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap = false);
 int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
-               double *rz_part = nullptr);
+               double *rz_part = nullptr, bool overlap = false);
 void pprec_free(nlg_mesh *m);
 
 // ---- halo.hip ----
@@ -243,6 +272,7 @@ void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
 int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place QQ^T
+int sem_gs_pairs_fg(nlg_mesh *m, double *w);   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr);
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)

@@ -595,17 +595,18 @@ int pres_solve(nlg_linop *op, double scale) {
     P.s = op->d_s + S_N;
     P.inv_n = m->has_outflow ? 0.0 : 1.0 / (double)m->lpn_global;
     double *nopc[1] = {nullptr};
-    if (c.pprecond == 0) {   // two-level FDM + coarse V-cycle (pprec.hip); 1 = Jacobi on diag(E), as in the oracle
+    if (c.pprecond == 0 || c.pprecond == 2) {   // two-level Schwarz (pprec.hip): 0 = with overlap where available, 2 = without; 1 = Jacobi on diag(E), as in the oracle
+        const bool overlap = c.pprecond == 0 && m->pprec.overlap;
         P.pc = nopc;
         P.npe = m->np2;
         double *rzp = m->dim == 3 ? op->d_part + 2 * m->E : nullptr;
-        P.precond = [m, rzp](const double *flag, const double *rr, double *zz, const double **xc) -> int {
+        P.precond = [m, rzp, overlap](const double *flag, const double *rr, double *zz, const double **xc) -> int {
             // one stream: a fork/join through events costs more than it hides (measured: 98 vs 84 us per apply)
             nlg_ctx *c = m->ctx;
             ProfScope ps(c, P_PPREC);
             const double *coarse = nullptr;
-            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse));
-            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz, rzp));   // z = FDM(r) + coarse[e]
+            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse, overlap));
+            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz, rzp, overlap));   // z = local solves + prolonged coarse part
             *xc = nullptr;
             return 0;
         };

@@ -593,29 +593,7 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
 // arguments, i.e. in the scalar kernarg segment, so the matrix operand of every FMA is an SGPR pair and costs no
 // LDS or vector-memory traffic.  NC = velocity components processed per pass (3 when the LDS image of all three
 // fits, else 1).
-// Face-grouped slot of point (a, j, k) inside an element: the 8 corners, the 12 edges (interior points of an edge
-// contiguous), the 6 face interiors (contiguous (N-2)^2 blocks), then the element interior.  The copies of a shared
-// face or edge are then contiguous runs in every element that shares it, so the gather-scatter moves whole runs
-// instead of one 8-byte word per 64-byte line.  FG = false gives the natural ix-fastest index.
-__host__ __device__ __forceinline__ int fg_slot(int N, int a, int j, int k) {
-    const int M = N - 2;
-    const int ba = (a == 0 || a == N - 1), bj = (j == 0 || j == N - 1), bk = (k == 0 || k == N - 1);
-    const int sa = a == N - 1, sj = j == N - 1, sk = k == N - 1;
-    const int nb = ba + bj + bk;
-    if (nb == 3) return sa + 2 * sj + 4 * sk;
-    if (nb == 2) {
-        if (!ba) return 8 + (0 + sj + 2 * sk) * M + (a - 1);
-        if (!bj) return 8 + (4 + sa + 2 * sk) * M + (j - 1);
-        return 8 + (8 + sa + 2 * sj) * M + (k - 1);
-    }
-    const int fbase = 8 + 12 * M;
-    if (nb == 1) {
-        if (ba) return fbase + (0 + sa) * M * M + (j - 1) + M * (k - 1);
-        if (bj) return fbase + (2 + sj) * M * M + (a - 1) + M * (k - 1);
-        return fbase + (4 + sk) * M * M + (a - 1) + M * (j - 1);
-    }
-    return fbase + 6 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
-}
+// elem_slot: natural ix-fastest index (FG = false) or the corner/edge/face-grouped slot fg_slot of internal.h.
 template <int N, bool FG>
 __device__ __forceinline__ int elem_slot(int a, int j, int k) {
     if (!FG) return a + N * (j + N * k);
@@ -1404,6 +1382,17 @@ static int axhelm3_nslot(int N) {
     return nslot;
 }
 
+int sem_gs_pairs_fg(nlg_mesh *m, double *w) {
+    NLG_CHECK(m->gs.d_indices_fg, "sem_gs_pairs_fg: no face-grouped tables (3-D only)");
+    if (m->gs.npairs == 0) return 0;
+    F3 f = {{w, nullptr, nullptr}};
+    const int grid = (int)((m->gs.npairs + NT - 1) / NT);
+    hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.npairs,
+                       m->gs.npairs, f);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 int sem_axhelm_blocks(nlg_mesh *m, int nf) {
     const int nslot = axhelm3_nslot(m->n);
     return (int)((m->E * nf + nslot - 1) / nslot);
@@ -2186,6 +2175,15 @@ int nlg_op_dssum(nlg_mesh *m, nlg_vec *v) {
 int nlg_op_cdabdtp(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {
     NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m, "nlg_op_cdabdtp: bad arguments");
     return sem_cdabdtp(m, in->pr(), out->pr());
+}
+
+int nlg_op_pprec(nlg_mesh *m, const nlg_vec *in, nlg_vec *out, int overlap, int with_coarse) {
+    NLG_CHECK(m && in && out && in->mesh == m && out->mesh == m && in != out, "nlg_op_pprec: bad arguments");
+    const double *xc = nullptr;
+    // the coarse call also packs the overlap layers, so it always runs; its result is dropped when not wanted
+    NLG_TRY(pprec_coarse(m, m->ctx->stream, nullptr, in->pr(), &xc, overlap != 0));
+    NLG_TRY(pprec_fine(m, m->ctx->stream, nullptr, in->pr(), with_coarse ? xc : nullptr, out->pr(), nullptr, overlap != 0));
+    return 0;
 }
 
 int nlg_op_opdiv(nlg_mesh *m, const nlg_vec *in, nlg_vec *out) {

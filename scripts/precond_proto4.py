@@ -21,7 +21,8 @@ def lengths(sem):
         L[:, d] = np.linalg.norm(face(1) - face(0), axis=1)
     return L
 
-def run(nel, n, deform):
+FAR_LUMP = False
+def run(nel, n, deform, only_build=False):
     t0 = time.time(); hm = box_mesh(nel, n, deform=deform); sem = SEM(hm)
     E_, n2, dim = sem.E, sem.n2, sem.dim; npr = n2 ** dim; m = n2 + 2
     A = build_E(sem); rng = np.random.default_rng(0)
@@ -67,7 +68,10 @@ def run(nel, n, deform):
             first = 0 if eL >= 0 else n - 1
             last = nvl - 1 if eR >= 0 else 2 * (n - 1)
             for (end, ee, s) in ((first, eL if eL >= 0 else e, -1), (last, eR if eR >= 0 else e, 1)):
-                binv[end] = 0.0 if nbr(ee, d, s) < 0 else binv[end] / 2
+                if FAR_LUMP and ee != e:
+                    binv[end] = binv[end] / 2          # far end of a neighbour: always treated as interior
+                else:
+                    binv[end] = 0.0 if nbr(ee, d, s) < 0 else binv[end] / 2
             Af = Dl @ (binv[:, None] * Dl.T); Bf = Il @ (binv[:, None] * Il.T)
             idx = np.arange(n2 - 1, 2 * n2 + 1)
             Ae = Af[np.ix_(idx, idx)]; Be = Bf[np.ix_(idx, idx)]
@@ -81,7 +85,19 @@ def run(nel, n, deform):
         t = np.where(den > 1e-12 * den.max(), t / np.where(den > 0, den, 1), 0.0)
         return np.einsum('eza,eyb,exc,eabc->ezyx', S[:, 2], S[:, 1], S[:, 0], t, optimize=True)
     def local0(r): return fdm(S0, lam0, r.reshape(sem.shape2)).ravel()
-    def local1(r):
+    def local1(r): return local1_core(r)
+    def local_count():
+        c = np.ones(sem.shape2)
+        for e in range(E_):
+            for d in range(dim):
+                ax = dim - 1 - d
+                for s_ in (-1, 1):
+                    q = nbr(e, d, s_)
+                    if q < 0: continue
+                    dst = [slice(None)] * dim; dst[ax] = (n2 - 1) if s_ == -1 else 0
+                    c[(q,) + tuple(dst)] += 1
+        return c
+    def local1_core(r, wt=None):
         r = r.reshape(sem.shape2)
         ext = np.zeros((E_, m, m, m)); ext[:, 1:-1, 1:-1, 1:-1] = r
         for e in range(E_):
@@ -105,6 +121,12 @@ def run(nel, n, deform):
                     dst = [slice(None)] * dim; dst[ax] = (n2 - 1) if s == -1 else 0
                     out[(q,) + tuple(dst)] += z[(e,) + tuple(src)]
         return out.ravel()
+    cnt = local_count()
+    sq = 1.0 / np.sqrt(cnt)
+    def local1w(r):
+        return sq.ravel() * local1_core(sq.ravel() * r, wt=sq)
+    if only_build:
+        return dict(sem=sem, local0=local0, local1=local1, local1w=local1w)
     res = {}
     for name, pr in (('fdm+Q1', lambda r: local0(r) + coarse(r)), ('fdm_ext+Q1', lambda r: local1(r) + coarse(r))):
         x, it = pcg(A, b, pr, 1e-7); res[name] = it
@@ -114,6 +136,7 @@ def run(nel, n, deform):
     print(nel, n, 'E=%d' % E_, res, 'time %.0f' % (time.time() - t0), flush=True)
 
 if __name__ == '__main__':
-    run((4, 4, 4), 6, 0.05)
-    run((6, 6, 6), 6, 0.05)
-    run((4, 4, 4), 8, 0.05)
+    for FAR_LUMP in (False, True):
+        print('FAR_LUMP', FAR_LUMP)
+        run((4, 4, 4), 6, 0.05)
+        run((3, 3, 3), 8, 0.05)
