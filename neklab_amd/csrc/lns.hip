@@ -439,6 +439,7 @@ struct CGProblem {
     const double *pw_part = nullptr;   // [2][pw_n]: sum p.w , sum w   (written by `apply`)
     int pw_n = 0;
     bool pw_sum = true;                // false: the sum of w is not provided (and not needed: inv_n == 0)
+    bool fused_pupdate = false;        // `apply` itself performs p <- z + beta p (gated by the done flag) before w = A p
     const double *rz_part = nullptr;   // [2][rz_n]: sum r.z , sum z   (written by `precond`)
     int rz_n = 0;
 };
@@ -492,7 +493,8 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         rd_pw.n[1] = P.pw_sum ? P.pw_n : 0;
     }
     NLG_TRY(reduce_post(rd_rz, 3, 0, 0));
-    launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
+    if (!P.fused_pupdate)
+        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
     hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
     int launched = 0;
     int iters = 0;
@@ -514,7 +516,8 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
                     launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
             }
             NLG_TRY(reduce_post(rd_rz, 3, 1, 2));
-            launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
+            if (!P.fused_pupdate)
+                launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
         }
         launched += todo;
         NLG_HIP(hipGetLastError());
@@ -561,9 +564,13 @@ int helm_solve(nlg_linop *op, int order, double h2) {
         P.pw_part = pw_part;
         P.pw_n = sem_axhelm_blocks(m, dim);
         P.pw_sum = false;
+        P.fused_pupdate = true;   // 3-D: p <- z + beta p happens while the operator kernel loads p
     }
     auto apply = [&](double *) -> int {
-        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part));
+        if (pw_part)
+            NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE));
+        else
+            NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part));
         NLG_TRY(sem_gs(m, op->w, dim));
         return 0;
     };

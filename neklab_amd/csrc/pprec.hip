@@ -195,18 +195,20 @@ __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int
 // i.e. z = sum_e R_e^T Atilde_e^-1 R_e r with overlapping index sets R_e: symmetric, additive.
 __device__ __forceinline__ int ext_slot(int N, int a, int b, int c) { return fg_slot(N, a, b, c); }
 
-template <int N>
-__global__ __launch_bounds__(NT) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
+// WPB waves (= elements) per block.  WPB = 1 makes every __syncthreads a single-wave barrier: the stages of one element
+// never wait for another element's.
+template <int N, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                 const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                 const double *__restrict__ wq, double *__restrict__ W,
                                                 double *__restrict__ z) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
-    __shared__ double sS[4][3][N * N];
-    __shared__ double sL[4][3][N];
-    __shared__ double sA[4][NP], sB[4][NP];
+    __shared__ double sS[WPB][3][N * N];
+    __shared__ double sL[WPB][3][N];
+    __shared__ double sA[WPB][NP], sB[WPB][NP];
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t e = (int64_t)blockIdx.x * WPB + wv;
     const bool act = e < E;
     const int64_t ee = act ? e : 0;
     for (int q = lane; q < 3 * N * N; q += 64) sS[wv][q / (N * N)][q % (N * N)] = S[ee * (3 * N * N) + q];
@@ -1072,7 +1074,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         NLG_TRY(sem_gs_pairs_fg(m, P.d_W));
 #define FX_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_fdm_ext<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
+        hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
         break;
         switch (m->n) {
             FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8)

@@ -409,7 +409,8 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
                                                 const double *__restrict__ G2, const double *__restrict__ G3,
                                                 const double *__restrict__ G4, const double *__restrict__ G5,
                                                 const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
-                                                double *__restrict__ pw_part) {
+                                                double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
+                                                const double *__restrict__ done_p) {
     constexpr int NP = N * N * N, NS = N * N;
     extern __shared__ double smem[];
     __shared__ double sred[8];
@@ -428,8 +429,20 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
     const int64_t base = (act ? e : 0) * NP;
     const double *uc = c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]);
     double *wc = c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2]);
+    // fused direction update of the surrounding PCG (beta_p != null): u <- z + beta u before the operator is applied,
+    // unless the solver has converged (the separate update kernel is gated the same way)
+    const bool upd = beta_p != nullptr && done_p[0] == 0.0;
+    const double beta = upd ? beta_p[0] : 0.0;
+    const double *zc = c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2]);
 #pragma unroll 1
-    for (int k = 0; k < N; ++k) sU[ij + k * NS] = act ? uc[base + ij + k * NS] : 0.0;
+    for (int k = 0; k < N; ++k) {
+        double v = act ? uc[base + ij + k * NS] : 0.0;
+        if (upd && act) {
+            v = zc[base + ij + k * NS] + beta * v;
+            const_cast<double *>(uc)[base + ij + k * NS] = v;
+        }
+        sU[ij + k * NS] = v;
+    }
     __syncthreads();
     double di[N], dj[N], dti[N], dtj[N];
 #pragma unroll
@@ -478,6 +491,138 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
         if (tid == 0) {
             double a = 0.0;
             for (int q = 0; q < (int)((blockDim.x + 63) >> 6); ++q) a += sred[q];
+            pw_part[blockIdx.x] = a;
+        }
+    }
+}
+
+// LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in order, so no s_barrier is needed;
+// the fence keeps the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of `v` held by lane `srclane` (wave-uniform result in scalar registers)
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Register-column variant for N <= 8: one wave (N*N active lanes) per (element, field).  Lane (i, j) keeps its k-column of
+// u and of w in registers; per k-slab the r/s contractions go through three N x N LDS slabs (rows padded to N+1), the
+// t contraction stays in registers.  A wave only ever touches its own slabs and LDS operations of one wave execute in
+// order, so the kernel needs no barrier at all; ~2.5 KB of LDS per wave, occupancy set by registers alone.
+template <int N, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const double *__restrict__ Dg,
+                                                       const double *__restrict__ G0, const double *__restrict__ G1,
+                                                       const double *__restrict__ G2, const double *__restrict__ G3,
+                                                       const double *__restrict__ G4, const double *__restrict__ G5,
+                                                       const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
+                                                       double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
+                                                       const double *__restrict__ done_p) {
+    static_assert(N * N <= 64, "one lane per (i, j)");
+    constexpr int NP = N * N * N, NS = N * N, NQ = N + 1;
+    __shared__ double sD[N * N];
+    __shared__ double sU[WPB][N * NQ], sR[WPB][N * NQ], sS[WPB][N * NQ];
+    __shared__ double sred[WPB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int p = tid; p < NS; p += 64 * WPB) sD[p] = Dg[p];
+    __syncthreads();   // the only block-wide barrier: the derivative matrix
+    const int64_t gslot = (int64_t)blockIdx.x * WPB + wv;
+    const int64_t e = gslot / nf;
+    const int c = (int)(gslot % nf);
+    const bool act = e < E && lane < NS;
+    const int ij = lane < NS ? lane : 0;
+    const int i = ij % N, j = ij / N;
+    const int64_t base = (e < E ? e : 0) * NP + ij;
+    const double *uc = c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]);
+    double *wc = c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2]);
+    const double *zc = c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2]);
+    const bool upd = beta_p != nullptr && done_p[0] == 0.0;
+    const double beta = upd ? beta_p[0] : 0.0;
+    double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double v = act ? uc[base + k * NS] : 0.0;
+        if (upd && act) {
+            v = zc[base + k * NS] + beta * v;
+            const_cast<double *>(uc)[base + k * NS] = v;
+        }
+        uk[k] = v;
+        wk[k] = 0.0;
+    }
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        di[l] = sD[i * N + l];
+        dj[l] = sD[j * N + l];
+        dti[l] = sD[l * N + i];
+        dtj[l] = sD[l * N + j];
+    }
+    double *mU = sU[wv], *mR = sR[wv], *mS = sS[wv];
+    double pw = 0.0;
+    // metric factors of slab k+1 are requested while slab k is computed; the compiler barrier at the end of every slab
+    // keeps it from hoisting ALL slabs' loads to the top (which costs 400 registers and the occupancy)
+    double gn[7];
+    gn[0] = G0[base], gn[1] = G1[base], gn[2] = G2[base], gn[3] = G3[base], gn[4] = G4[base], gn[5] = G5[base], gn[6] = bm1[base];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3], g4 = gn[4], g5 = gn[5], bm = gn[6];
+        if (k + 1 < N) {
+            const int64_t q = base + (k + 1) * NS;
+            gn[0] = G0[q], gn[1] = G1[q], gn[2] = G2[q], gn[3] = G3[q], gn[4] = G4[q], gn[5] = G5[q], gn[6] = bm1[q];
+        }
+        if (lane < NS) mU[i + NQ * j] = uk[k];
+        wave_lds_sync();
+        // row k of D, wave-uniform: lane k (i = k, j = 0) holds it in di[] -> scalar registers, no LDS, no vector registers
+        double dk[N];
+#pragma unroll
+        for (int l = 0; l < N; ++l) dk[l] = readlane_f64(di[l], k);
+        double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            ur += di[l] * mU[l + NQ * j];
+            us += dj[l] * mU[i + NQ * l];
+            ut += dk[l] * uk[l];
+        }
+        const double gr = h1 * (g0 * ur + g1 * us + g2 * ut);
+        const double gs = h1 * (g1 * ur + g3 * us + g4 * ut);
+        const double gt = h1 * (g2 * ur + g4 * us + g5 * ut);
+        if (lane < NS) {
+            mR[i + NQ * j] = gr;
+            mS[i + NQ * j] = gs;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int l = 0; l < N; ++l) wk[l] += dk[l] * gt;
+        double a = h2 * bm * uk[k];
+#pragma unroll
+        for (int l = 0; l < N; ++l) a += dti[l] * mR[l + NQ * j] + dtj[l] * mS[i + NQ * l];
+        wk[k] += a;
+        // pin the accumulators here: otherwise the compiler sinks these sums into the guarded store at the end and keeps
+        // every slab's LDS operands alive until then (400 registers, one wave per SIMD)
+#pragma unroll
+        for (int l = 0; l < N; ++l) asm volatile("" : "+v"(wk[l]));
+        asm volatile("" ::: "memory");
+    }
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            wc[base + k * NS] = wk[k];
+            pw += wk[k] * uk[k];
+        }
+    }
+    if (pw_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+        if (lane == 0) sred[wv] = pw;
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0;
+            for (int q = 0; q < WPB; ++q) a += sred[q];
             pw_part[blockIdx.x] = a;
         }
     }
@@ -1374,6 +1519,7 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
 
 // (element, field) slots per block of k_axhelm3: bounded by 512 threads and by 64 KB of dynamic LDS
 static int axhelm3_nslot(int N) {
+    if (N <= 8) return 4;   // k_axhelm3r: four waves = four (element, field) slots per block
     int nslot = 512 / (N * N);
     const int lds_cap = (int)((64 * 1024 / 8 - N * N) / (4 * N * N * N));
     if (nslot > lds_cap) nslot = lds_cap;
@@ -1398,13 +1544,16 @@ int sem_axhelm_blocks(nlg_mesh *m, int nf) {
     return (int)((m->E * nf + nslot - 1) / nslot);
 }
 
-int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part) {
+int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part,
+               double *const *zf, const double *beta_p, const double *done_p) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
     ProfScope ps(m->ctx, P_AXHELM);
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
     F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
     hipStream_t s = m->ctx->stream;
     NLG_CHECK(!pw_part || m->dim == 3, "sem_axhelm: the fused u.w sums exist in the 3-D kernel only");
+    NLG_CHECK(!beta_p || (m->dim == 3 && zf && done_p), "sem_axhelm: the fused direction update exists in the 3-D kernel only");
+    CF3 cz = {{zf ? zf[0] : nullptr, (zf && nf > 1) ? zf[1] : nullptr, (zf && nf > 2) ? zf[2] : nullptr}};
     if (m->dim == 3) {
 #define AX3(N_)                                                                                                       \
     {                                                                                                                 \
@@ -1412,8 +1561,12 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         const int64_t tot = m->E * nf;                                                                                \
         const int grid = (int)((tot + nslot - 1) / nslot);                                                            \
         const size_t lds = sizeof(double) * (size_t)(N_ * N_ + nslot * 4 * N_ * N_ * N_);                             \
+        if constexpr (N_ <= 8)                                                                                        \
+            hipLaunchKernelGGL((k_axhelm3r<N_, 4>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+        else                                                                                                          \
         hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part); \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
     }
         NLG_FOR_N(AX3)
 #undef AX3
