@@ -48,7 +48,7 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len):
+def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lorder=3):
     """Algorithmic HBM bytes of ONE launch of a kernel class, fp64."""
     n2 = n - 2
     np1, np2 = n ** dim, n2 ** dim
@@ -56,15 +56,15 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len):
         return 8.0 * E * (np2 * (1 + dim * dim) + dim * np1)
     if cls == "opdiv":        # dim fields + dim fused weights in, dim^2 metric terms, p out
         return 8.0 * E * (2 * dim * np1 + np2 * (dim * dim + 1))
-    if cls == "axhelm":       # NF = dim fields in/out, 6 (3) metric factors + mass
-        ng = 6 if dim == 3 else 3
-        return 8.0 * E * np1 * (2 * dim + ng + 1)
+    if cls == "axhelm":       # NF = dim fields in/out, 6 (3) metric factors + mass; 3-D: the fused PCG direction
+        ng = 6 if dim == 3 else 3   # update p <- z + beta p adds z in and p out
+        return 8.0 * E * np1 * ((4 if dim == 3 else 2) * dim + ng + 1)
     if cls == "gs":           # value in + out per shared local dof and field, 4-byte index once
         return nshared * (16.0 * dim + 4.0)
     if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
         return 8.0 * (k * ncomp + ncomp + 1) * lvs
-    if cls == "block_axpy":   # k basis vectors + w in/out over all main fields
-        return 8.0 * (k + 2) * main_len
+    if cls == "block_axpy":   # k basis vectors + w in/out over all main fields and (consistent restart history,
+        return 8.0 * (k + 2) * main_len * lorder   # DESIGN.md 3.1) the lorder-1 history blocks of every vector
     return None
 
 
