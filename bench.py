@@ -210,6 +210,29 @@ def main():
     p_iters = (st2["p_iters"] - st1["p_iters"]) / max(st2["steps"] - st1["steps"], 1)
     v_iters = (st2["v_iters"] - st1["v_iters"]) / max(st2["steps"] - st1["steps"], 1)
 
+    # ---- the two roofline-accountable units of SURVEY.md 8(d), timed outside the timed region (collective, all ranks):
+    # U1+U2 = element-local Helmholtz operator + gather-scatter per scalar field; U3 = CGS2 + norm + scale at k = m
+    va, vb = host.nek_dvector(gm), host.nek_dvector(gm)
+    va.rand(False, seed=7)
+    nrep = 20
+    host.check(lib.nlg_op_helmholtz(gm.h, va.h, vb.h, 1.0 / args.re, 1.0, 1))
+    ctx.sync()
+    t_u = time.perf_counter()
+    for _ in range(nrep):
+        host.check(lib.nlg_op_helmholtz(gm.h, va.h, vb.h, 1.0 / args.re, 1.0, 1))
+    ctx.sync()
+    u12_per_s = dim * nrep / (time.perf_counter() - t_u)
+    wv = B[m]
+    wv.rand(False, seed=8)
+    ctx.sync()
+    t_u = time.perf_counter()
+    nrep3 = 3
+    for _ in range(nrep3):
+        B.cgs2(m, wv)
+    ctx.sync()
+    u3_ms = 1e3 * (time.perf_counter() - t_u) / nrep3
+    del va, vb
+
     # ---- CPU baseline (rank 0, N = 1 only): oracle restatement on a bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -237,6 +260,8 @@ def main():
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
                        "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
                        "global_elements": E * world,
+                       "operator_applies_per_s_per_field_per_gpu": round(u12_per_s, 1),
+                       "arnoldi_orthogonalisation_ms_at_k=m": round(u3_ms, 3),
                        "parallelism": "1 process per GPU, contiguous element blocks, RCCL all-reduce for every reduction, "
                                       "RCCL send/recv halo for the gather-scatter"},
             "roofline": roofline,

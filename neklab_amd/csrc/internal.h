@@ -123,6 +123,7 @@ struct nlg_gs {
     int64_t ngroups = 0;
     int64_t nshared = 0;
     int64_t npairs = 0;         // the first npairs groups have exactly two copies (same count in both layouts)
+    int64_t nquads = 0;         // the next nquads groups have exactly four
     int *d_offsets = nullptr;   // [ngroups + 1]
     int *d_indices = nullptr;   // [nshared] local dof index
     // the same groups in the face-grouped element layout used for the intermediate fields of the consistent

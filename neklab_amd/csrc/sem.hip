@@ -350,12 +350,13 @@ __global__ void k_mul(double *y, const double *a, const double *b, int64_t n) {
 // =================================================================================================
 // gather-scatter: one thread per group of local copies of a shared global dof
 // =================================================================================================
-// The groups are stored pairs first (a shared face interior: two copies, ~3/4 of all groups in 3-D): a thread of the
-// pair range reads its two indices as one int2 and needs neither the offset array nor a loop; the remaining groups
-// (edges, corners, irregular valences) go through the general CSR path.  Sums run over ascending local index.
+// The groups are stored pairs first (a shared face interior: two copies, ~3/4 of all groups in 3-D), then quads (a
+// shared edge: four copies), then the rest: a thread of the pair / quad range reads its indices as one int2 / int4 and
+// needs neither the offset array nor a loop with dependent loads; the remaining groups (corners, irregular valences)
+// go through the general CSR path.  Sums run over ascending local index in every class.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const int *__restrict__ idx, int64_t ngroups,
-                                           int64_t npairs, F3 f) {
+                                           int64_t npairs, int64_t nquads, F3 f) {
     const int64_t g = blockIdx.x * (int64_t)NT + threadIdx.x;
     if (g >= ngroups) return;
     if (g < npairs) {
@@ -365,6 +366,20 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
             const double s = f.p[c][ab.x] + f.p[c][ab.y];
             f.p[c][ab.x] = s;
             f.p[c][ab.y] = s;
+        }
+        return;
+    }
+    if (g < npairs + nquads) {
+        // 2 * npairs is even, so the quad block starts 8-byte aligned; read it as two int2
+        const int2 *q2 = reinterpret_cast<const int2 *>(idx + 2 * npairs) + 2 * (g - npairs);
+        const int2 ab = q2[0], cd = q2[1];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double s = ((f.p[c][ab.x] + f.p[c][ab.y]) + f.p[c][cd.x]) + f.p[c][cd.y];
+            f.p[c][ab.x] = s;
+            f.p[c][ab.y] = s;
+            f.p[c][cd.x] = s;
+            f.p[c][cd.y] = s;
         }
         return;
     }
@@ -1507,11 +1522,11 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
         F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
         const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
         if (nf == 1)
-            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, f);
+            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
         else if (nf == 2)
-            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, f);
+            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
         else
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, f);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
         NLG_HIP(hipGetLastError());
     }
     return halo_exchange(m, fields, nf);   // no-op on a single rank
@@ -1534,7 +1549,7 @@ int sem_gs_pairs_fg(nlg_mesh *m, double *w) {
     F3 f = {{w, nullptr, nullptr}};
     const int grid = (int)((m->gs.npairs + NT - 1) / NT);
     hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.npairs,
-                       m->gs.npairs, f);
+                       m->gs.npairs, (int64_t)0, f);
     NLG_HIP(hipGetLastError());
     return 0;
 }
@@ -1715,7 +1730,7 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part) {
             ProfScope ps(m->ctx, P_GS);
             F3 f = {{w[0], w[1], w[2]}};
             const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, f);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
             NLG_HIP(hipGetLastError());
         }
         if (m->halo.active) {
@@ -2030,12 +2045,14 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
             b = e;
         }
         // pairs first, each class ordered by its first (smallest) local index
-        auto is_pair = [](const std::pair<int, std::pair<int, int>> &g) { return g.second.second - g.second.first == 2; };
+        auto cls = [](int sz) { return sz == 2 ? 0 : (sz == 4 ? 1 : 2); };
+        auto gsz = [](const std::pair<int, std::pair<int, int>> &g) { return g.second.second - g.second.first; };
         std::sort(groups.begin(), groups.end(), [&](const auto &a, const auto &b) {
-            const bool pa = is_pair(a), pb = is_pair(b);
-            return pa != pb ? pa : a < b;
+            const int ca = cls(gsz(a)), cb = cls(gsz(b));
+            return ca != cb ? ca < cb : a < b;
         });
-        m->gs.npairs = (int64_t)std::count_if(groups.begin(), groups.end(), is_pair);
+        m->gs.npairs = (int64_t)std::count_if(groups.begin(), groups.end(), [&](const auto &g) { return gsz(g) == 2; });
+        m->gs.nquads = (int64_t)std::count_if(groups.begin(), groups.end(), [&](const auto &g) { return gsz(g) == 4; });
         for (auto &g : groups) {
             for (int q = g.second.first; q < g.second.second; ++q) idx.push_back(order[q]);
             off.push_back((int)idx.size());
@@ -2053,8 +2070,8 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
                 std::sort(gl[gi].begin(), gl[gi].end());
             }
             std::sort(gl.begin(), gl.end(), [](const std::vector<int> &a, const std::vector<int> &b) {
-                const bool pa = a.size() == 2, pb = b.size() == 2;
-                return pa != pb ? pa : a[0] < b[0];
+                const int ca = a.size() == 2 ? 0 : (a.size() == 4 ? 1 : 2), cb = b.size() == 2 ? 0 : (b.size() == 4 ? 1 : 2);
+                return ca != cb ? ca < cb : a[0] < b[0];
             });
             std::vector<int> off2{0}, idx2;
             for (auto &v : gl) {

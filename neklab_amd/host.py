@@ -380,7 +380,7 @@ def svds(exptA: exptA_linop, U: list, V: list, kdim: int = 0, tol: float = 0.0, 
 
 
 def transient_growth_analysis_fixed_point(exptA: exptA_linop, nsv: int, kdim: int, tol: float = 0.0, outdir: str = ".",
-                                          seed: int = 0):
+                                          seed: int = 0, outpost: bool = False, session: str = "neklab"):
     """reference: neklab_analysis.f90:107-156.  Returns (S, residuals, U (optimal responses), V (optimal
     perturbations), info) and writes singular_spectrum.dat (:139-143)."""
     mesh = exptA.mesh
@@ -390,7 +390,63 @@ def transient_growth_analysis_fixed_point(exptA: exptA_linop, nsv: int, kdim: in
                               logfile=os.path.join(outdir, "svds_output.txt"), seed=seed)
     with open(os.path.join(outdir, "singular_spectrum.dat"), "w") as f:
         f.write(" ".join("%.16e" % s for s in S) + "\n")
+    if outpost:                                                      # :146-147
+        outpost_dnek(V, "prt", session, outdir)
+        outpost_dnek(U, "rsp", session, outdir)
     return S, residuals, U, V, info
+
+
+def _gl_to_gll_matrix(n: int) -> np.ndarray:
+    """(n x n-2) Lagrange interpolation from the Gauss-Legendre pressure points to the GLL velocity points."""
+    from .mesh import gll_points
+    z1 = gll_points(n)
+    z2 = np.polynomial.legendre.leggauss(n - 2)[0]
+    M = np.ones((n, n - 2))
+    for k in range(n - 2):
+        for l in range(n - 2):
+            if l != k:
+                M[:, k] *= (z1 - z2[l]) / (z2[k] - z2[l])
+    return M
+
+
+def pressure_to_mesh1(vec: nek_dvector) -> np.ndarray:
+    """Pressure of `vec` on the velocity mesh, as Nek5000's outpost writes it for a Pn-Pn-2 run (`mappr`: tensor
+    interpolation GL -> GLL inside every element, then the direct-stiffness average across elements)."""
+    mesh = vec.mesh
+    n, dim, E = mesh.host.n, mesh.host.dim, mesh.host.E
+    M = _gl_to_gll_matrix(n)
+    p = vec.get_field(PR).reshape((E,) + (n - 2,) * dim)
+    for ax in range(1, dim + 1):
+        p = np.moveaxis(np.tensordot(M, p, axes=([1], [ax])), 0, ax)
+    tmp = nek_dvector(mesh)
+    tmp.set_field(VX, p.reshape(-1))
+    check(mesh.lib.nlg_op_dssum(mesh.h, tmp.h))
+    return tmp.get_field(VX) * mesh.get("vmult")
+
+
+def outpost_dnek(vecs, prefix: str, session: str = "neklab", outdir: str = ".", first_index: int = 1, time: float = 0.0):
+    """reference: outpost_dnek (src/neklab_utils.f90:305-333, called at neklab_analysis.f90:93,146,147): every vector
+    becomes one Nek5000 field file `<prefix><session>0.f%05d` with the GLL coordinates in the first file only (Nek5000's
+    default `ifxyo` behaviour), velocity and the pressure mapped to the velocity mesh.  Single-rank writer."""
+    from . import nekio
+    if isinstance(vecs, nek_dvector):
+        vecs = [vecs]
+    if len(prefix) != 3:
+        raise ValueError("outpost_dnek: the prefix has three characters in Nek5000 (got %r)" % prefix)
+    paths = []
+    for i, v in enumerate(vecs):
+        hm = v.mesh.host
+        n, dim, E = hm.n, hm.dim, hm.E
+        coords = None
+        if i == 0:
+            coords = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
+            coords = [np.asarray(c).reshape(E, -1) for c in coords]
+        vel = [v.get_field(c).reshape(E, -1) for c in range(dim)]
+        path = os.path.join(outdir, "%s%s0.f%05d" % (prefix, session, first_index + i))
+        nekio.write_fld(path, n, dim, coords=coords, vel=vel, p=pressure_to_mesh1(v).reshape(E, -1), time=time,
+                        istep=first_index + i)
+        paths.append(path)
+    return paths
 
 
 def save_eigenspectrum(eigvals, residuals, filename: str):
@@ -402,7 +458,7 @@ def save_eigenspectrum(eigvals, residuals, filename: str):
 
 def linear_stability_analysis_fixed_point(exptA: exptA_linop, kdim: int, nev: int, adjoint: bool = False,
                                           X0: nek_dvector | None = None, tol: float = 0.0, outdir: str = ".",
-                                          seed: int = 0):
+                                          seed: int = 0, outpost: bool = False, session: str = "neklab"):
     """reference: neklab_analysis.f90:38-105.  Returns (eigvals continuous-time, residuals, eigvecs)."""
     mesh = exptA.mesh
     eigvecs = [nek_dvector(mesh, 0, 3) for _ in range(nev)]   # lorder = 3 as in every reference SIZE file
@@ -413,4 +469,6 @@ def linear_stability_analysis_fixed_point(exptA: exptA_linop, kdim: int, nev: in
                                logfile=os.path.join(outdir, "eigs_output.txt"), tol=tol, seed=seed)
     eigvals = np.log(mu.astype(complex)) / exptA.info()["tau"]       # :84
     save_eigenspectrum(eigvals, residuals, os.path.join(outdir, prefix + "_eigenspectrum.npy"))   # :90
+    if outpost:
+        outpost_dnek(eigvecs, prefix, session, outdir)               # :93
     return eigvals, residuals, eigvecs, mu, info

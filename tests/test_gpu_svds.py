@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from neklab_amd import host
+from neklab_amd.mesh import box_mesh
 from oracle.krylov import svds as o_svds
 from test_gpu_linop import load_pair, setup_case
 
@@ -49,3 +50,33 @@ def test_transient_growth_driver_outputs(gpu_ctx, tmp_path):
     assert S[0] >= S[1] > 0 and info % 2 == 0
     vals = [float(x) for x in open(tmp_path / "singular_spectrum.dat").read().split()]
     assert np.allclose(vals, S)
+
+
+def test_outpost_dnek_round_trip(gpu_ctx, tmp_path):
+    """outpost_dnek (neklab_utils.f90:305-333): field files readable by the reader; pressure on mesh 1 equals the
+    oracle's interpolation + direct-stiffness average; coordinates only in the first file."""
+    from neklab_amd import nekio
+    from oracle.sem import SEM, interp_matrix
+    hm = box_mesh((3, 2, 2), 6, deform=0.03)
+    sem = SEM(hm)
+    gm = host.Mesh(gpu_ctx, hm)
+    rng = np.random.default_rng(2)
+    vecs = []
+    for _ in range(2):
+        v = host.nek_dvector(gm)
+        for c in range(3):
+            v.set_field(c, rng.standard_normal(gm.lvn))
+        v.set_field(host.PR, rng.standard_normal(gm.lpn))
+        vecs.append(v)
+    paths = host.outpost_dnek(vecs, "dir", session="case", outdir=str(tmp_path))
+    assert [p.split("/")[-1] for p in paths] == ["dircase0.f00001", "dircase0.f00002"]
+    d0, d1 = nekio.read_fld(paths[0]), nekio.read_fld(paths[1])
+    assert "x" in d0 and "x" not in d1
+    assert np.array_equal(d0["x"].ravel(), hm.x.ravel())
+    assert np.array_equal(d1["uy"].ravel(), vecs[1].get_field(1))
+    I21 = interp_matrix(sem.z2, sem.z1)
+    p = vecs[0].get_field(host.PR).reshape(sem.shape2)
+    for ax in (1, 2, 3):
+        p = np.moveaxis(np.tensordot(I21, p, axes=([1], [ax])), 0, ax)
+    ref = sem.dsavg(p)
+    assert np.max(np.abs(d0["p"].ravel() - ref.ravel())) < 1e-12 * np.abs(ref).max()
