@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--re", type=float, default=100.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--pprecond", type=int, default=0, help="pressure preconditioner (0 default, 2 = no overlap, 1 = Jacobi)")
+    ap.add_argument("--pproj", type=int, default=1, help="pressure residual projection (1 default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -122,7 +123,7 @@ def main():
     dt0 = 0.5 / cfl1.value
     tau = dt0 * (args.nsteps - 0.5)
     A = host.exptA_linop(tau, bf, re=args.re, torder=3, vtol=1e-9, ptol=1e-7, maxit_v=200, maxit_p=4000,
-                         pprecond=args.pprecond)
+                         pprecond=args.pprecond, pproj=args.pproj)
     A.init()
     info = A.info()
     assert info["nsteps"] == args.nsteps, info

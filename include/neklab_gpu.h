@@ -171,6 +171,8 @@ typedef struct nlg_exptA_config {
     int fixed_iters_p;
     int pprecond;      /* pressure preconditioner: 0 = two-level Schwarz (element FDM with one layer of face overlap
                           in 3-D for lx1 <= 8 + vertex coarse space), 1 = Jacobi, 2 = two-level without overlap    */
+    int pproj;         /* pressure residual projection onto the previous increments of the matvec (Nek5000
+                          `residualProj = yes`, examples/cylinder/stability/direct/1cyl.par:23): 0 = off, 1 = on    */
 } nlg_exptA_config;
 
 int nlg_exptA_config_default(nlg_exptA_config *cfg);

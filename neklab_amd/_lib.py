@@ -35,7 +35,7 @@ class ExptAConfig(C.Structure):
         ("tau", C.c_double), ("re", C.c_double), ("cfl_limit", C.c_double), ("vtol", C.c_double),
         ("ptol", C.c_double), ("dt", C.c_double),
         ("torder", C.c_int), ("maxit_v", C.c_int), ("maxit_p", C.c_int),
-        ("fixed_iters_v", C.c_int), ("fixed_iters_p", C.c_int), ("pprecond", C.c_int),
+        ("fixed_iters_v", C.c_int), ("fixed_iters_p", C.c_int), ("pprecond", C.c_int), ("pproj", C.c_int),
     ]
 
 

@@ -284,6 +284,80 @@ __global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int ns
     }
 }
 
+// ---- residual projection of the pressure solve (Fischer 1998; Nek5000 `residualProj = yes`, 1cyl.par:23) ----
+// X = up to PROJ_L previous solution increments, A-orthonormal (A = P E P), B = A X.  All on the device, no host sync.
+constexpr int PROJ_L = 8;
+// partial[v * NB + blk] = sum over the block's share of X_v . y   (v < nvec <= PROJ_L)
+__global__ __launch_bounds__(NT) void k_proj_dots(int64_t n, const double *__restrict__ X, int64_t stride, int nvec,
+                                                  const double *__restrict__ y, double *__restrict__ partial) {
+    __shared__ double sm[PROJ_L][NT / 64];
+    double a[PROJ_L];
+#pragma unroll
+    for (int v = 0; v < PROJ_L; ++v) a[v] = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double yv = y[i];
+#pragma unroll
+        for (int v = 0; v < PROJ_L; ++v)
+            if (v < nvec) a[v] += X[v * stride + i] * yv;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < PROJ_L; ++v) {
+        double t = a[v];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if (lane == 0) sm[v][wid] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < PROJ_L) {
+        double t = 0.0;
+        for (int w = 0; w < NT / 64; ++w) t += sm[threadIdx.x][w];
+        partial[threadIdx.x * NB + blockIdx.x] = t;
+    }
+}
+// out[v] = sum_blk partial[v * NB + blk]
+__global__ __launch_bounds__(NT) void k_proj_reduce(const double *__restrict__ partial, int nblk, int nvec, double *__restrict__ out) {
+    __shared__ double sm[NT / 64];
+    for (int v = 0; v < nvec; ++v) {
+        double t = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += NT) t += partial[v * NB + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0;
+            for (int w = 0; w < NT / 64; ++w) a += sm[w];
+            out[v] = a;
+        }
+        __syncthreads();
+    }
+}
+// y += sgn * sum_v c[v] M_v
+__global__ __launch_bounds__(NT) void k_proj_comb(int64_t n, double *__restrict__ y, const double *__restrict__ M, int64_t stride,
+                                                  int nvec, const double *__restrict__ c, double sgn) {
+    double cv[PROJ_L];
+#pragma unroll
+    for (int v = 0; v < PROJ_L; ++v) cv[v] = v < nvec ? sgn * c[v] : 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        double a = y[i];
+#pragma unroll
+        for (int v = 0; v < PROJ_L; ++v)
+            if (v < nvec) a += cv[v] * M[v * stride + i];
+        y[i] = a;
+    }
+}
+// new basis pair: X_new = v / sqrt(nrm2), B_new = w / sqrt(nrm2); a non-positive nrm2 stores zeros (a harmless member)
+__global__ __launch_bounds__(NT) void k_proj_store(int64_t n, const double *__restrict__ v, const double *__restrict__ w,
+                                                   const double *__restrict__ nrm2, double *__restrict__ Xn, double *__restrict__ Bn) {
+    const double q = nrm2[0];
+    const double sc = q > 0.0 ? 1.0 / sqrt(q) : 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        Xn[i] = sc * v[i];
+        Bn[i] = sc * w[i];
+    }
+}
+
 // generic pointwise helpers
 template <int NF>
 __global__ __launch_bounds__(NT) void k_colmul_gated(const double *s, F3 w, CF3 wt, int64_t n) {
@@ -384,6 +458,8 @@ struct nlg_linop {
     double *pr_r = nullptr, *pr_x = nullptr, *pr_z = nullptr, *pr_p = nullptr, *pr_w = nullptr;
     double *pcv[4][3] = {};    // mask_i / diag(H) per BDF order
     double *pce = nullptr;     // 1 / diag(E)
+    double *prX = nullptr, *prB = nullptr, *d_pc = nullptr;   // pressure residual projection: PROJ_L solution / image pairs, coefficients
+    int nproj = 0;
     double *nwv = nullptr;     // binvm1 * vmult / volvm1
     double *nwp = nullptr;     // bm2inv / volvm2
     double *d_s = nullptr;     // solver scalars (two blocks of S_N)
@@ -631,10 +707,52 @@ int pres_solve(nlg_linop *op, double scale) {
         }
     }
     auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w, pw_part); };
+    // ---- residual projection (c.pproj): start from the A-orthogonal projection of the solution onto the span of the
+    // previous increments of this matvec; the PCG then solves for the remainder
+    hipStream_t st = m->ctx->stream;
+    // (not in the fixed-iteration parity mode: there the iteration is the oracle's, run on the full right-hand side)
+    const bool proj = c.pproj != 0 && op->prX != nullptr && c.fixed_iters_p <= 0;
+    double *alpha = op->d_pc, *beta = op->d_pc + PROJ_L, *nrm2 = op->d_pc + 2 * PROJ_L, *ppart = op->d_pc + 4 * PROJ_L;
+    const int gp = red_grid(m->lpn);
+    const int nold = op->nproj;
+    auto dots = [&](const double *y, int nvec, const double *M, double *out) -> int {
+        hipLaunchKernelGGL(k_proj_dots, dim3(gp), dim3(NT), 0, st, m->lpn, M, m->lps, nvec, y, ppart);
+        hipLaunchKernelGGL(k_proj_reduce, dim3(1), dim3(NT), 0, st, (const double *)ppart, gp, nvec, out);
+        return allreduce_sum(m->ctx, out, nvec);
+    };
+    if (proj && nold > 0) {
+        ProfScope ps(m->ctx, P_VECOPS);
+        NLG_TRY(dots(op->pr_r, nold, op->prX, alpha));                       // alpha = X^T b
+        hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_r, (const double *)op->prB, m->lps,
+                           nold, (const double *)alpha, -1.0);               // b <- b - B alpha
+    }
     int iters = 0;
     NLG_TRY(run_pcg(op, P, apply, &iters));
     op->st_piters += iters;
     op->last_piters = iters;
+    if (proj) {
+        // new member from the increment d = pr_x: w = A d, A-orthogonalised against the old members, normalised
+        NLG_TRY(sem_cdabdtp(m, op->pr_x, op->pr_w));
+        if (!m->has_outflow) NLG_TRY(sem_ortho(m, op->pr_w));                // A = P E P
+        ProfScope ps(m->ctx, P_VECOPS);
+        NLG_HIP(hipMemcpyAsync(op->pr_z, op->pr_x, sizeof(double) * (size_t)m->lpn, hipMemcpyDeviceToDevice, st));   // v = d
+        if (nold > 0) {
+            NLG_TRY(dots(op->pr_w, nold, op->prX, beta));                    // beta = X^T A d
+            hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_z, (const double *)op->prX, m->lps,
+                               nold, (const double *)beta, -1.0);
+            hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_w, (const double *)op->prB, m->lps,
+                               nold, (const double *)beta, -1.0);
+            // total solution: x = d + X alpha
+            hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_x, (const double *)op->prX, m->lps,
+                               nold, (const double *)alpha, 1.0);
+        }
+        NLG_TRY(dots(op->pr_w, 1, op->pr_z, nrm2));                          // v^T A v
+        const int slot = nold < PROJ_L ? nold : 0;                           // full: start over with the newest member
+        hipLaunchKernelGGL(k_proj_store, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, (const double *)op->pr_z, (const double *)op->pr_w,
+                           (const double *)nrm2, op->prX + (size_t)slot * m->lps, op->prB + (size_t)slot * m->lps);
+        op->nproj = nold < PROJ_L ? nold + 1 : 1;
+        NLG_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -758,6 +876,7 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
         }
     op->istep = 0;
     op->adjoint = adjoint;
+    op->nproj = 0;   // the projection space belongs to one matvec: the result must not depend on earlier calls
     NLG_TRY(load_state(op, vin, 0));
     for (int istep = 1; istep <= op->nsteps; ++istep) {
         NLG_TRY(advance(op));
@@ -791,6 +910,7 @@ int nlg_exptA_config_default(nlg_exptA_config *c) {
     c->torder = 3;
     c->maxit_v = 200;
     c->maxit_p = 2000;
+    c->pproj = 1;   // residualProj = yes for the pressure, as in the reference's cylinder case (1cyl.par:23)
     return 0;
 }
 
@@ -835,6 +955,9 @@ int nlg_linop_destroy(nlg_linop *op) {
     fr(op->pr_p);
     fr(op->pr_w);
     fr(op->pce);
+    fr(op->prX);
+    fr(op->prB);
+    fr(op->d_pc);
     fr(op->nwv);
     fr(op->nwp);
     fr(op->d_s);
@@ -875,6 +998,11 @@ int nlg_linop_init(nlg_linop *op) {
         NLG_TRY(lalloc(op, &op->pr_p, m->lps));
         NLG_TRY(lalloc(op, &op->pr_w, m->lps));
         NLG_TRY(lalloc(op, &op->pce, m->lps));
+        if (op->cfg.pproj) {
+            NLG_TRY(lalloc(op, &op->prX, (int64_t)PROJ_L * m->lps));
+            NLG_TRY(lalloc(op, &op->prB, (int64_t)PROJ_L * m->lps));
+            NLG_TRY(lalloc(op, &op->d_pc, 4 * PROJ_L + PROJ_L * NB));
+        }
         NLG_TRY(lalloc(op, &op->nwv, m->lvs));
         NLG_TRY(lalloc(op, &op->nwp, m->lps));
         NLG_TRY(lalloc(op, &op->d_s, 4 * S_N));

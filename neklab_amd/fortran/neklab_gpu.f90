@@ -35,7 +35,7 @@ module neklab_gpu
 
    type, bind(C), public :: nlg_exptA_config
       real(c_double) :: tau, re, cfl_limit, vtol, ptol, dt
-      integer(c_int) :: torder, maxit_v, maxit_p, fixed_iters_v, fixed_iters_p, pprecond
+      integer(c_int) :: torder, maxit_v, maxit_p, fixed_iters_v, fixed_iters_p, pprecond, pproj
    end type
 
    interface

@@ -13,7 +13,7 @@ from oracle.vectors import NekDVector
 pytestmark = pytest.mark.gpu
 
 
-def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.04, pprecond=0):
+def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.04, pprecond=0, pproj=1):
     if dim == 2:
         hm = box_mesh((4, 3), n, lengths=(4.0, 2.0), periodic=(True, False), deform=deform)
     else:
@@ -34,7 +34,7 @@ def setup_case(ctx, dim, n=6, torder=3, fixed=True, tau=0.05, re=50.0, deform=0.
         kw.update(fixed_iters_v=30, fixed_iters_p=600)   # converged: unconverged CG amplifies rounding differences
     ocfg = LNSConfig(**kw)
     oA = ExptA(sem, ob.v, ocfg)
-    gA = host.exptA_linop(tau, gb, pprecond=pprecond, **{k: v for k, v in kw.items() if k != "tau"})
+    gA = host.exptA_linop(tau, gb, pprecond=pprecond, pproj=pproj, **{k: v for k, v in kw.items() if k != "tau"})
     gA.init()
     return hm, sem, gm, oA, gA, rng
 
@@ -227,3 +227,21 @@ def test_eigs_against_oracle(gpu_ctx):
     rows = [ln.split() for ln in open(log) if not ln.startswith("#")]
     assert len(rows) >= nev and all(len(r) == 6 and r[5] in ("T", "F") for r in rows)
     assert abs(float(rows[0][3]) - abs(mu[0])) < 1e-12
+
+
+def test_pressure_residual_projection(gpu_ctx):
+    """residualProj (1cyl.par:23): the projection onto the previous increments changes the starting guess of the
+    pressure solve, not the answer; it saves iterations once the matvec has several time steps."""
+    outs, iters = [], []
+    for pproj in (0, 1):
+        hm, sem, gm, oA, gA, rng = setup_case(gpu_ctx, 3, fixed=False, tau=0.3, pproj=pproj)
+        ov, gv = load_pair(sem, gm, rng)
+        out = host.nek_dvector(gm)
+        gA.matvec(gv, out)
+        outs.append([out.get_field(i) for i in range(3)])
+        iters.append(gA.stats()["p_iters"])
+        assert gA.stats()["steps"] >= 8
+    sc = max(np.abs(a).max() for a in outs[0])
+    for a, b in zip(*outs):
+        assert np.max(np.abs(a - b)) < 1e-9 * sc
+    assert iters[1] < iters[0]
