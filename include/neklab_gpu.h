@@ -186,6 +186,16 @@ int nlg_linop_init(nlg_linop *op);
 int nlg_linop_matvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
 /* exptA_rmatvec exponential_propagator.f90:62-107  (interface neklab_linops.f90:58-62) */
 int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
+/* Newton-Krylov base-flow solver.
+ * nonlinear_map  src/systems/fixed_point.f90:4-38 : vec_out = Phi_tau(vec_in) - vec_in with the nonlinear integrator,
+ *   time step from the CFL number of vec_in (cfg.cfl_limit; the reference uses 0.4), tolerances cfg.vtol / cfg.ptol.
+ *   Afterwards the operator's base-flow dependent set-up belongs to vec_in.
+ * set_baseflow   the `self%X` of jac_exptA_matvec (fixed_point.f90:52): replaces the frozen base flow of the linearised
+ *   operator and redoes init (dt / nsteps from its CFL number); the Jacobian of the map is then matvec - identity.
+ * set_tolerances the tolerance schedulers nek_constant_tol / nek_dynamic_tol (src/systems/neklab_systems.f90:229-335). */
+int nlg_linop_nonlinear_map(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
+int nlg_linop_set_baseflow(nlg_linop *op, const nlg_vec *baseflow);
+int nlg_linop_set_tolerances(nlg_linop *op, double vtol, double ptol);
 /* %tau read/written by the driver (src/neklab_analysis.f90:84; apply_exptA neklab_linops.f90:252) */
 int nlg_linop_set_tau(nlg_linop *op, double tau);
 int nlg_linop_get_info(const nlg_linop *op, double *tau, double *dt, int *nsteps, double *cfl);

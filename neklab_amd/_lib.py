@@ -94,6 +94,9 @@ SIGNATURES = {
     "nlg_linop_create": (C.c_int, [vp, C.POINTER(ExptAConfig), vp, C.POINTER(vp)]),
     "nlg_linop_destroy": (C.c_int, [vp]),
     "nlg_linop_init": (C.c_int, [vp]),
+    "nlg_linop_nonlinear_map": (C.c_int, [vp, vp, vp]),
+    "nlg_linop_set_baseflow": (C.c_int, [vp, vp]),
+    "nlg_linop_set_tolerances": (C.c_int, [vp, C.c_double, C.c_double]),
     "nlg_linop_matvec": (C.c_int, [vp, vp, vp]),
     "nlg_linop_rmatvec": (C.c_int, [vp, vp, vp]),
     "nlg_linop_set_tau": (C.c_int, [vp, C.c_double]),

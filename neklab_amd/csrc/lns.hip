@@ -466,6 +466,7 @@ struct nlg_linop {
     double *d_part = nullptr;  // first-stage sums written by opdiv ([2][E]) and by the FDM kernel ([2][E/4])
     double *h_s = nullptr;     // pinned
     int istep = 0, adjoint = 0;
+    int nonlinear = 0;         // 1: full Navier-Stokes step, N(u) = (u.grad)u = half of the linearised term about U = u
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
 };
@@ -769,7 +770,8 @@ int advance(nlg_linop *op) {
     const double b0 = BDF_B0[k];
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
-    NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->adjoint));
+    if (op->nonlinear) NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));   // the "base flow" is the current state
+    NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
     {
         double *t0 = op->fbuf[2][0], *t1 = op->fbuf[2][1], *t2 = op->fbuf[2][2];
         for (int c = 0; c < 3; ++c) {
@@ -783,7 +785,7 @@ int advance(nlg_linop *op) {
     Hist h;
     h.k = k;
     for (int j = 0; j < 3; ++j) {
-        h.ab[j] = -EXT_C[k][j];   // F = -N
+        h.ab[j] = -(op->nonlinear ? 0.5 : 1.0) * EXT_C[k][j];   // F = -N ; nonlinear: (u.grad)u = 1/2 [(U.grad)u + (u.grad)U] at U = u
         h.bd[j] = BDF_C[k][j];
         for (int c = 0; c < 3; ++c) {
             h.f[j][c] = op->fbuf[j][c];
@@ -891,6 +893,38 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
         vout->nrst = std::max(vout->nrst, irst);
     }
     op->st_matvecs += 1;
+    return 0;
+}
+
+// vec_out = Phi_tau(vec_in) - vec_in with the NONLINEAR integrator (reference: nonlinear_map, src/systems/fixed_point.f90:4-38):
+// dt from the CFL number of vec_in itself, no restart-history replay, no history in the result
+int do_nonlinear_map(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout) {
+    NLG_CHECK(op && vin && vout, "nonlinear_map: NULL argument");
+    nlg_mesh *m = op->mesh;
+    NLG_CHECK(vin->mesh == m && vout->mesh == m, "nonlinear_map: vector on a different mesh (reference: type_error, fixed_point.f90:31-36)");
+    NLG_CHECK(vin->nscal == 0 && vout->nscal == 0, "nonlinear_map: scalar (temperature) coupling is not built yet");
+    NLG_CHECK(vin != vout, "nonlinear_map: vec_in and vec_out must be distinct");
+    hipStream_t st = m->ctx->stream;
+    // "setup_nonlinear_solver(recompute_dt = .true.)": the time step follows the state that is integrated
+    NLG_TRY(nlg_vec_copy(op->baseflow, vin));
+    NLG_TRY(nlg_linop_init(op));
+    for (int s = 0; s < 3; ++s)
+        for (int c = 0; c < m->dim; ++c) {
+            NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
+            NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
+        }
+    op->istep = 0;
+    op->adjoint = 0;
+    op->nproj = 0;
+    op->nonlinear = 1;
+    int rc = load_state(op, vin, 0);
+    for (int istep = 1; istep <= op->nsteps && rc == 0; ++istep) rc = advance(op);
+    op->nonlinear = 0;
+    if (rc) return rc;
+    NLG_TRY(nlg_vec_zero(vout));
+    NLG_TRY(store_state(op, vout, 0));
+    NLG_TRY(nlg_vec_axpby(-1.0, vin, 1.0, vout));   // vec_out%sub(vec_in), fixed_point.f90:29
+    // the base-flow dependent set-up now belongs to vec_in: a later linear matvec needs nlg_linop_set_baseflow
     return 0;
 }
 
@@ -1057,6 +1091,21 @@ int nlg_linop_init(nlg_linop *op) {
 
 int nlg_linop_matvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out) { return do_matvec(op, vec_in, vec_out, 0); }
 int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out) { return do_matvec(op, vec_in, vec_out, 1); }
+
+int nlg_linop_nonlinear_map(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out) { return do_nonlinear_map(op, vec_in, vec_out); }
+
+int nlg_linop_set_baseflow(nlg_linop *op, const nlg_vec *baseflow) {
+    NLG_CHECK(op && baseflow && baseflow->mesh == op->mesh, "nlg_linop_set_baseflow: bad argument");
+    NLG_TRY(nlg_vec_copy(op->baseflow, baseflow));
+    return nlg_linop_init(op);
+}
+
+int nlg_linop_set_tolerances(nlg_linop *op, double vtol, double ptol) {
+    NLG_CHECK(op && vtol > 0.0 && ptol > 0.0, "nlg_linop_set_tolerances: bad argument");
+    op->cfg.vtol = vtol;
+    op->cfg.ptol = ptol;
+    return 0;
+}
 
 int nlg_linop_set_tau(nlg_linop *op, double tau) {
     NLG_CHECK(op && tau > 0.0, "nlg_linop_set_tau: bad argument");

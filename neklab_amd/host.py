@@ -332,6 +332,164 @@ class exptA_linop:
             self.h = None
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Newton-Krylov fixed-point solver.  Reference: nek_system / nek_jacobian
+# (src/systems/neklab_systems.f90, fixed_point.f90:4-96) driven by LightKrylov's `newton` + `gmres_rdp`
+# (src/neklab_analysis.f90:158-205).  LightKrylov is absent from the reference tree, so Newton and GMRES are restated
+# from the published algorithms (Saad & Schultz 1986: restarted GMRES with Givens rotations; inexact Newton with the
+# reference's own tolerance schedulers) -- parity at LightKrylov's internals is unpinned, as for `eigs`.
+class nek_system:
+    """`eval` = nonlinear_map: F(X) = Phi_tau(X) - X (fixed_point.f90:4-38); `jacobian` = exp(tau J(X)) - I about the
+    frozen state X (fixed_point.f90:40-96).  Two operator objects, as the reference switches Nek5000 between its
+    nonlinear (CFL limit 0.4) and linearised (0.5) set-ups."""
+
+    def __init__(self, tau: float, X0: nek_dvector, re: float, torder: int = 3, **cfg):
+        self.mesh, self.lib, self.tau = X0.mesh, X0.lib, float(tau)
+        self.nl = exptA_linop(tau, X0, re=re, torder=torder, cfl_limit=0.4, **cfg)
+        self.jac = exptA_linop(tau, X0, re=re, torder=torder, cfl_limit=0.5, **cfg)
+        self.nl.init()
+        self.jac.init()
+        self.n_eval = 0
+
+    def set_tolerance(self, tol: float):
+        """nek_constant_tol / nek_dynamic_tol set param(21) = param(22) = tol; nonlinear_map then solves to tol * 0.1
+        (fixed_point.f90:16-17), the Jacobian to tol * 0.5 (:58-59)."""
+        check(self.lib.nlg_linop_set_tolerances(self.nl.h, 0.1 * tol, 0.1 * tol))
+        check(self.lib.nlg_linop_set_tolerances(self.jac.h, 0.5 * tol, 0.5 * tol))
+
+    def eval(self, X: nek_dvector, out: nek_dvector):
+        check(self.lib.nlg_linop_nonlinear_map(self.nl.h, X.h, out.h))
+        self.n_eval += 1
+
+    def set_jacobian_state(self, X: nek_dvector):
+        check(self.lib.nlg_linop_set_baseflow(self.jac.h, X.h))
+
+
+def nek_dynamic_tol(tol_old: float, target: float, rnorm: float):
+    """neklab_systems.f90:273-335: tol = max(0.1 rnorm, target), snapped to the target when within a decade of it,
+    capped at 1e-4; the target itself is clipped to [10 atol_dp, 1e-4]."""
+    maxtol, mintol = 1.0e-4, 10.0 * 10.0 ** -12
+    target = min(max(target, mintol), maxtol)
+    tol = max(0.1 * rnorm, target)
+    if tol < 10.0 * target:
+        tol = target
+    return min(tol, maxtol)
+
+
+def nek_constant_tol(tol_old: float, target: float, rnorm: float):
+    """neklab_systems.f90:229-261."""
+    return max(target, 10.0 * 10.0 ** -12)
+
+
+def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim: int = 30, maxiter: int = 10,
+          shift: float = -1.0, basis: "KrylovBasis | None" = None, replay_history: bool = False):
+    """Restarted GMRES(kdim) for (A + shift I) x = b, zero initial guess, stop at |residual| <= atol.  The Krylov space of
+    A + shift I is that of A, so the Arnoldi relation comes from the device Arnoldi step of A (`nlg_arnoldi_step`:
+    matvec + block CGS2) with `shift` added to the diagonal of H.  Returns (residual norm, number of matvecs).
+
+    replay_history = False strips the restart history from every new Krylov vector, so that each matvec starts
+    impulsively like the nonlinear map whose Jacobian it stands for.  The reference's jac_exptA_matvec replays the
+    history (fixed_point.f90:73); measured on a lid-driven cavity (scripts/newton_cavity_oracle.py, tau = 0.4): Newton
+    needs 17 iterations with the replay (the Krylov operator is then the start-up-free continuation map, not the
+    derivative of the map being solved) and 3 without.  The converged fixed point is the same."""
+    mesh = b.mesh
+    B = basis if basis is not None else KrylovBasis(mesh, kdim + 1)
+    x.zero()
+    r = b.copy()
+    nmv = 0
+    res = r.norm()
+    for _ in range(maxiter):
+        beta = res
+        if beta <= atol:
+            break
+        v0 = B[0]
+        v0.assign(r)
+        v0.scal(1.0 / beta)
+        H = np.zeros((kdim + 2, kdim + 1), order="F")
+        R = np.zeros((kdim + 1, kdim))
+        cs, sn = np.zeros(kdim), np.zeros(kdim)
+        g = np.zeros(kdim + 1)
+        g[0] = beta
+        k = 0
+        while k < kdim:
+            arnoldi_step(exptA, B, k, H)
+            nmv += 1
+            if not replay_history:
+                B[k + 1].clear_rst_fields()
+            h = H[: k + 2, k].copy()
+            h[k] += shift
+            for i in range(k):                                   # previous rotations
+                t = cs[i] * h[i] + sn[i] * h[i + 1]
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]
+                h[i] = t
+            d = np.hypot(h[k], h[k + 1])
+            cs[k], sn[k] = (1.0, 0.0) if d == 0.0 else (h[k] / d, h[k + 1] / d)
+            h[k], h[k + 1] = d, 0.0
+            R[: k + 1, k] = h[: k + 1]
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            k += 1
+            res = abs(g[k])
+            if res <= atol:
+                break
+        y = np.linalg.solve(np.triu(R[:k, :k]), g[:k])
+        dx = nek_dvector(mesh, b.nscal, b.lorder)
+        B.combine(k, y, dx)
+        x.axpby(1.0, dx, 1.0)
+        if res <= atol:
+            break
+        # true residual for the restart: r = b - (A + shift I) x
+        Ax = nek_dvector(mesh, b.nscal, b.lorder)
+        exptA.matvec(x, Ax)
+        nmv += 1
+        r.assign(b)
+        r.axpby(-1.0, Ax, 1.0)
+        r.axpby(-shift, x, 1.0)
+        res = r.norm()
+    return res, nmv
+
+
+def newton_fixed_point_iteration(sys: nek_system, bf: nek_dvector, tol: float, tol_mode: int = 1, maxiter: int = 40,
+                                 kdim: int = 30, outdir: str | None = None, session: str = "neklab", log=None,
+                                 replay_history: bool = False):
+    """reference: newton_fixed_point_iteration (src/neklab_analysis.f90:158-205): Newton on F(X) = Phi_tau(X) - X with
+    GMRES on the Jacobian exp(tau J) - I, tolerance scheduler nek_constant_tol (tol_mode 1) or nek_dynamic_tol, 40
+    iterations at most, no bisection; on convergence the fixed point is written as `nwt<session>0.f00001`.
+    `bf` is updated in place.  Returns dict(converged, iterations, residuals, gmres_matvecs, evals)."""
+    sched = nek_constant_tol if tol_mode == 1 else nek_dynamic_tol
+    mesh = bf.mesh
+    r = nek_dvector(mesh, bf.nscal, bf.lorder)
+    dx = nek_dvector(mesh, bf.nscal, bf.lorder)
+    B = KrylovBasis(mesh, kdim + 1)
+    final = sched(0.0, tol, 0.0)               # the tightest level the scheduler will ever set
+    cur, rnorm = 0.0, 1.0
+    residuals, nmv_total, converged = [], 0, False
+    for it in range(maxiter + 1):
+        new = sched(cur, tol, rnorm)           # scheduler first, as LightKrylov's newton calls it at the top of an iteration
+        if new != cur:
+            cur = new
+            sys.set_tolerance(cur)
+        sys.eval(bf, r)
+        rnorm = r.norm()
+        residuals.append(rnorm)
+        if log is not None:
+            log("newton %2d  |F(X)| = %.6e  solver tol %.3e" % (it, rnorm, cur))
+        if rnorm < tol and cur <= final:       # a residual below the target only counts when computed at the final level
+            converged = True
+            break
+        if it == maxiter:
+            break
+        sys.set_jacobian_state(bf)
+        r.scal(-1.0)
+        res, nmv = gmres(sys.jac, r, dx, atol=sched(cur, tol, rnorm), kdim=kdim, basis=B, replay_history=replay_history)
+        nmv_total += nmv
+        bf.axpby(1.0, dx, 1.0)
+    if converged and outdir is not None:
+        outpost_dnek(bf, "nwt", session, outdir)
+    return {"converged": converged, "iterations": len(residuals) - 1, "residuals": residuals, "gmres_matvecs": nmv_total,
+            "evals": sys.n_eval}
+
+
 def arnoldi_step(exptA: exptA_linop, basis: KrylovBasis, k: int, H: np.ndarray, transpose: bool = False):
     """H is Fortran-ordered (kdim+1, kdim)."""
     assert H.flags.f_contiguous

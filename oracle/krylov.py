@@ -207,3 +207,107 @@ def svds(matvec, rmatvec, u0, nsv, kdim, tol=None):
         Vs.append(lincomb(V, Q[:, i], k))
         Us.append(lincomb(U, (B @ Q[:, i]) / sig[i], k))
     return sig[:nout], Us, Vs, res[:nout], nmv
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Newton-Krylov fixed-point solver: twin of neklab_amd/host.py gmres / newton_fixed_point_iteration.
+# LightKrylov's `newton` and `gmres_rdp` (call site /root/reference/src/neklab_analysis.f90:186-194) are absent from the
+# reference tree: restated from the published algorithms, PARITY UNPINNED at their internals; the tolerance schedulers
+# follow /root/reference/src/systems/neklab_systems.f90:229-335.
+def nek_dynamic_tol(tol_old, target, rnorm):
+    maxtol, mintol = 1.0e-4, 10.0 * 10.0 ** -12
+    target = min(max(target, mintol), maxtol)
+    tol = max(0.1 * rnorm, target)
+    if tol < 10.0 * target:
+        tol = target
+    return min(tol, maxtol)
+
+
+def nek_constant_tol(tol_old, target, rnorm):
+    return max(target, 10.0 * 10.0 ** -12)
+
+
+def gmres(matvec, b, atol, kdim=30, maxiter=10, shift=-1.0, replay_history=False):
+    """Restarted GMRES(kdim) for (A + shift I) x = b from a zero guess; Arnoldi on A (same Krylov space).
+    replay_history=False: new Krylov vectors lose their restart history (see neklab_amd/host.py gmres)."""
+    x = b.copy()
+    x.zero()
+    r = b.copy()
+    nmv = 0
+    res = r.norm()
+    for _ in range(maxiter):
+        beta = res
+        if beta <= atol:
+            break
+        V = [None] * (kdim + 1)
+        v0 = r.copy()
+        v0.scal(1.0 / beta)
+        V[0] = v0
+        H = np.zeros((kdim + 1, kdim))
+        R = np.zeros((kdim + 1, kdim))
+        cs, sn = np.zeros(kdim), np.zeros(kdim)
+        g = np.zeros(kdim + 1)
+        g[0] = beta
+        k = 0
+        while k < kdim:
+            arnoldi_step(matvec, V, H, k)
+            nmv += 1
+            if not replay_history:
+                V[k + 1].clear_rst_fields()
+            h = H[: k + 2, k].copy()
+            h[k] += shift
+            for i in range(k):
+                t = cs[i] * h[i] + sn[i] * h[i + 1]
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]
+                h[i] = t
+            d = np.hypot(h[k], h[k + 1])
+            cs[k], sn[k] = (1.0, 0.0) if d == 0.0 else (h[k] / d, h[k + 1] / d)
+            h[k], h[k + 1] = d, 0.0
+            R[: k + 1, k] = h[: k + 1]
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            k += 1
+            res = abs(g[k])
+            if res <= atol:
+                break
+        y = np.linalg.solve(np.triu(R[:k, :k]), g[:k])
+        x.axpby(1.0, lincomb(V, y, k), 1.0)
+        if res <= atol:
+            break
+        Ax = matvec(x)
+        nmv += 1
+        r = b.copy()
+        r.axpby(-1.0, Ax, 1.0)
+        r.axpby(-shift, x, 1.0)
+        res = r.norm()
+    return x, res, nmv
+
+
+def newton(nonlinear_map, jacobian_for, set_tolerance, X, tol, tol_mode=1, maxiter=40, kdim=30, log=None,
+           replay_history=False):
+    """X updated in place.  nonlinear_map(X) -> F(X); jacobian_for(X) -> matvec of exp(tau J(X)); set_tolerance(tol)."""
+    sched = nek_constant_tol if tol_mode == 1 else nek_dynamic_tol
+    final = sched(0.0, tol, 0.0)
+    cur, rnorm = 0.0, 1.0
+    residuals, nmv_total, converged = [], 0, False
+    for it in range(maxiter + 1):
+        new = sched(cur, tol, rnorm)
+        if new != cur:
+            cur = new
+            set_tolerance(cur)
+        r = nonlinear_map(X)
+        rnorm = r.norm()
+        residuals.append(rnorm)
+        if log is not None:
+            log("newton %2d  |F(X)| = %.6e  solver tol %.3e" % (it, rnorm, cur))
+        if rnorm < tol and cur <= final:
+            converged = True
+            break
+        if it == maxiter:
+            break
+        mv = jacobian_for(X)
+        r.scal(-1.0)
+        dx, res, nmv = gmres(mv, r, atol=sched(cur, tol, rnorm), kdim=kdim, replay_history=replay_history)
+        nmv_total += nmv
+        X.axpby(1.0, dx, 1.0)
+    return {"converged": converged, "iterations": len(residuals) - 1, "residuals": residuals, "gmres_matvecs": nmv_total}

@@ -187,7 +187,12 @@ class ExptA:
         k = min(self.istep, cfg.torder)
         b0, bd = BDF[k]
         ab = EXT[k]
-        N = s.lns_conv_weak(self.U, self.u, adjoint=self.adjoint)
+        if getattr(self, "nonlinear", False):
+            # full Navier-Stokes step (nonlinear_map, /root/reference/src/systems/fixed_point.f90:4-38):
+            # (u.grad)u = 1/2 [(U.grad)u + (u.grad)U] at U = u
+            N = [0.5 * a for a in s.lns_conv_weak(self.u, self.u, adjoint=False)]
+        else:
+            N = s.lns_conv_weak(self.U, self.u, adjoint=self.adjoint)
         F = [-a for a in N]
         hist_f = [F] + self.flag
         hist_u = [self.u] + self.ulag
@@ -245,3 +250,30 @@ class ExptA:
 
     def rmatvec(self, vec_in):
         return self.matvec(vec_in, adjoint=True)
+
+    # ---------------- reference: src/systems/fixed_point.f90:4-38 ----------------
+    def set_baseflow(self, baseflow):
+        """`self%X` of jac_exptA_matvec (fixed_point.f90:52): new frozen base flow, dt / nsteps from its CFL number."""
+        self.U = [self.sem.f1(a).copy() for a in baseflow]
+        if self.cfg.dt > 0:
+            self.nsteps = int(math.ceil(self.cfg.tau / self.cfg.dt - 1e-12))
+            self.dt = self.cfg.tau / self.nsteps
+        else:
+            c1 = self.sem.compute_cfl(self.U, 1.0)
+            self.dt, self.nsteps = dt_rule(self.cfg.tau, c1, self.cfg.cfl_limit)
+        self._hdiag = {}
+
+    def nonlinear_map(self, vec_in: NekDVector) -> NekDVector:
+        """F(X) = Phi_tau(X) - X with the nonlinear integrator; the time step follows the CFL number of X."""
+        self.set_baseflow(vec_in.v)
+        vec_out = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)
+        self._reset_state(vec_in, False)
+        self.nonlinear = True
+        try:
+            for _ in range(self.nsteps):
+                self.advance()
+        finally:
+            self.nonlinear = False
+        self._store(vec_out)
+        vec_out.axpby(-1.0, vec_in, 1.0)
+        return vec_out
