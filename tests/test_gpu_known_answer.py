@@ -40,3 +40,35 @@ def test_cylinder_re50_leading_eigenvalue(gpu_ctx, tmp_path):
     assert abs(float(conv[0][3]) - abs(mu[0])) < 1e-12                    # get_converged_eigs_data()['lambda_1']['modulus']
     spec = np.load(tmp_path / "dir_eigenspectrum.npy")
     assert spec.shape == (2, 3)
+
+
+def test_cylinder_base_flow_is_fixed_point_and_newton_returns_to_it(gpu_ctx):
+    """Newton-Krylov row pinned on reference data: the reference's own Re = 50 base flow
+    (BF_1cyl0.f00001, an UNSTABLE steady state -- time stepping leaves it, which is why the reference computes it by
+    Newton) is a fixed point of the restated nonlinear map, and Newton + GMRES returns to it from a perturbed state.
+    Measured (profiles/r01_cylinder_newton.log): |F(BF)| = 1.56e-5 at |BF| = 46.2 (tau = 1, 125 steps); from a wake
+    perturbation of norm 8.9e-2 Newton ends 2.7e-5 from the reference field."""
+    hm, ux, uy, p, re, lxd, _ = load_cylinder(with_bcs=True)
+    gm = host.Mesh(gpu_ctx, hm, lxd=lxd)
+    bf = host.nek_dvector(gm)
+    bf.set_field(host.VX, ux)
+    bf.set_field(host.VY, uy)
+    sysm = host.nek_system(1.0, bf, re=re, maxit_v=400, maxit_p=4000)
+    F = host.nek_dvector(gm)
+    sysm.set_tolerance(1e-8)
+    sysm.eval(bf, F)
+    assert sysm.nl.info()["nsteps"] == 125                     # CFL limit 0.4 of the nonlinear set-up (fixed_point.f90:15)
+    assert F.norm() < 3e-5 and F.norm() < 1e-6 * bf.norm()
+    X = bf.copy()
+    x, y = hm.x.ravel(), hm.y.ravel()
+    X.set_field(host.VX, ux.ravel() + 0.02 * np.exp(-((x - 3.0) ** 2 + y ** 2) / 2.0) * hm.mask[0].ravel())
+    d0 = X.copy()
+    d0.sub(bf)
+    out = host.newton_fixed_point_iteration(sysm, X, 1e-6, tol_mode=2, kdim=60)
+    assert out["converged"] and out["iterations"] <= 6, out
+    d1 = X.copy()
+    d1.sub(bf)
+    assert d0.norm() > 3e-2 and d1.norm() < 1e-4, (d0.norm(), d1.norm())
+    sysm.set_tolerance(1e-8)                                    # the claim is checked with tighter solves than Newton used
+    sysm.eval(X, F)
+    assert F.norm() < 1e-5
