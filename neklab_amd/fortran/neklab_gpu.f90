@@ -202,6 +202,22 @@ module neklab_gpu
          type(c_ptr), value :: op, vin, vout
          integer(c_int) :: rc
       end function
+      function c_linop_nonlinear_map(op, vin, vout) bind(C, name="nlg_linop_nonlinear_map") result(rc)
+         import c_int, c_ptr
+         type(c_ptr), value :: op, vin, vout
+         integer(c_int) :: rc
+      end function
+      function c_linop_set_baseflow(op, bf) bind(C, name="nlg_linop_set_baseflow") result(rc)
+         import c_int, c_ptr
+         type(c_ptr), value :: op, bf
+         integer(c_int) :: rc
+      end function
+      function c_linop_set_tolerances(op, vtol, ptol) bind(C, name="nlg_linop_set_tolerances") result(rc)
+         import c_int, c_ptr, c_double
+         type(c_ptr), value :: op
+         real(c_double), value :: vtol, ptol
+         integer(c_int) :: rc
+      end function
       function c_strlen(s) bind(C, name="strlen") result(n)
          import c_ptr, c_size_t
          type(c_ptr), value :: s
@@ -244,6 +260,11 @@ module neklab_gpu
       procedure, pass(self), public :: init => init_exptA
       procedure, pass(self), public :: matvec => exptA_matvec
       procedure, pass(self), public :: rmatvec => exptA_rmatvec
+      ! Newton-Krylov row: what nek_system%eval (nonlinear_map) and nek_jacobian (self%X) forward to
+      ! (src/systems/fixed_point.f90:4-96); the tolerance schedulers of neklab_systems.f90:229-335 call set_tolerances
+      procedure, pass(self), public :: nonlinear_map => exptA_nonlinear_map
+      procedure, pass(self), public :: set_baseflow => exptA_set_baseflow
+      procedure, pass(self), public :: set_tolerances => exptA_set_tolerances
       final :: finalize_exptA
    end type exptA_linop
 
@@ -493,6 +514,41 @@ contains
       class default
          write (*, '(A)') "type_error: 'vec_in' must be nek_dvector in exptA_matvec"; error stop 1
       end select
+   end subroutine
+
+   subroutine exptA_nonlinear_map(self, vec_in, vec_out)
+      class(exptA_linop), intent(inout) :: self
+      class(abstract_vector_rdp), intent(in) :: vec_in
+      class(abstract_vector_rdp), intent(out) :: vec_out
+      select type (vec_in)
+      type is (nek_dvector)
+         select type (vec_out)
+         type is (nek_dvector)
+            call ensure(vec_out)
+            call nlg_check(c_linop_nonlinear_map(self%h, vec_in%h, vec_out%h), 'nonlinear_map')
+         class default
+            write (*, '(A)') "type_error: 'vec_out' must be nek_dvector in nonlinear_map"; error stop 1
+         end select
+      class default
+         write (*, '(A)') "type_error: 'vec_in' must be nek_dvector in nonlinear_map"; error stop 1
+      end select
+   end subroutine
+
+   subroutine exptA_set_baseflow(self, X)
+      class(exptA_linop), intent(inout) :: self
+      class(abstract_vector_rdp), intent(in) :: X
+      select type (X)
+      type is (nek_dvector)
+         call nlg_check(c_linop_set_baseflow(self%h, X%h), 'set_baseflow')
+      class default
+         write (*, '(A)') "type_error: 'X' must be nek_dvector in set_baseflow"; error stop 1
+      end select
+   end subroutine
+
+   subroutine exptA_set_tolerances(self, vtol, ptol)
+      class(exptA_linop), intent(inout) :: self
+      real(dp), intent(in) :: vtol, ptol
+      call nlg_check(c_linop_set_tolerances(self%h, vtol, ptol), 'set_tolerances')
    end subroutine
 
    subroutine exptA_rmatvec(self, vec_in, vec_out)

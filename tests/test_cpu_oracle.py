@@ -214,3 +214,45 @@ def test_krylov_on_known_spectrum():
     lam, vecs, res, nmv = eigs(lambda v: V(d * v.a), V(np.ones(60)), nev=2, kdim=12, tol=1e-10, max_restarts=30)
     assert np.allclose(np.sort(np.abs(lam))[::-1], [1.5, 1.2], atol=1e-9) and np.all(res < 1e-10)
     assert abs(abs(vecs[0].a[0]) - 1.0) < 1e-8
+
+
+def test_oracle_gmres_and_nonlinear_map():
+    """Oracle twins of the Newton-Krylov row: GMRES on exp(tau L) - I reproduces its own Arnoldi residual estimate with
+    history-free Krylov vectors; the nonlinear map reduces to the linearised one for small amplitudes."""
+    from oracle import krylov as K
+    from oracle.lns import ExptA, LNSConfig
+    hm = box_mesh((3, 2), 5, lengths=(1.0, 1.0), deform=0.02)
+    sem = SEM(hm)
+    rng = np.random.default_rng(0)
+    U = [sem.mask[i] * sem.dsavg(np.sin(2 * sem.X[0] + i) * np.cos(sem.X[1])) for i in range(2)]
+    cfg = LNSConfig(re=20.0, torder=2, tau=0.05, dt=0.01, vtol=1e-13, ptol=1e-13, maxit_v=300, maxit_p=3000)
+    A = ExptA(sem, U, cfg)
+    b = NekDVector(sem)
+    for i in range(2):
+        b.v[i][...] = sem.mask[i] * sem.dsavg(rng.standard_normal(sem.shape1))
+
+    def mv(v):                      # the operator GMRES sees: impulsive start, no history replay
+        w = v.copy()
+        w.clear_rst_fields()
+        return A.matvec(w)
+
+    x, res, nmv = K.gmres(mv, b, atol=1e-9, kdim=25)
+    r = mv(x)
+    r.axpby(-1.0, x, 1.0)
+    r.axpby(-1.0, b, 1.0)
+    assert res <= 1e-9 and r.norm() < 1e-7 * b.norm(), (res, r.norm())
+    # about the state of rest (a fixed point, so the frozen-base-flow Jacobian is the exact derivative):
+    # F(eps v) / eps -> (exp(tau L(0)) - I) v, the nonlinear term being O(eps)
+    zero = [np.zeros(sem.shape1) for _ in range(2)]
+    An = ExptA(sem, zero, cfg)
+    eps = 1e-4
+    Xp = b.copy()
+    Xp.scal(eps)
+    F1 = An.nonlinear_map(Xp)
+    F1.scal(1.0 / eps)
+    A.set_baseflow(zero)
+    Jb = mv(b)
+    Jb.axpby(-1.0, b, 1.0)
+    d = F1.copy()
+    d.axpby(-1.0, Jb, 1.0)
+    assert d.norm() < 1e-3 * Jb.norm(), (d.norm(), Jb.norm())
