@@ -232,6 +232,16 @@ def main():
         B.cgs2(m, wv)
     ctx.sync()
     u3_ms = 1e3 * (time.perf_counter() - t_u) / nrep3
+    u3_vs_k = {}
+    for kk in sorted({1, 2, 4, 8, 16, 32, 48, m}):
+        if kk > m:
+            continue
+        wv.rand(False, seed=9)
+        ctx.sync()
+        t_u = time.perf_counter()
+        B.cgs2(kk, wv)
+        ctx.sync()
+        u3_vs_k[str(kk)] = round(1e3 * (time.perf_counter() - t_u), 3)
     del va, vb
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle restatement on a bounded sample
@@ -263,6 +273,7 @@ def main():
                        "global_elements": E * world,
                        "operator_applies_per_s_per_field_per_gpu": round(u12_per_s, 1),
                        "arnoldi_orthogonalisation_ms_at_k=m": round(u3_ms, 3),
+                       "arnoldi_orthogonalisation_ms_vs_k": u3_vs_k,
                        "parallelism": "1 process per GPU, contiguous element blocks, RCCL all-reduce for every reduction, "
                                       "RCCL send/recv halo for the gather-scatter"},
             "roofline": roofline,
