@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--re", type=float, default=100.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--pprecond", type=int, default=0, help="pressure preconditioner (0 default, 2 = no overlap, 1 = Jacobi)")
+    ap.add_argument("--no-units", action="store_true", help="skip the U1+U2 / U3 unit timings after the timed region (profiling runs)")
     ap.add_argument("--pproj", type=int, default=1, help="pressure residual projection (1 default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -213,36 +214,39 @@ def main():
 
     # ---- the two roofline-accountable units of SURVEY.md 8(d), timed outside the timed region (collective, all ranks):
     # U1+U2 = element-local Helmholtz operator + gather-scatter per scalar field; U3 = CGS2 + norm + scale at k = m
-    va, vb = host.nek_dvector(gm), host.nek_dvector(gm)
-    va.rand(False, seed=7)
-    nrep = 20
-    host.check(lib.nlg_op_helmholtz(gm.h, va.h, vb.h, 1.0 / args.re, 1.0, 1))
-    ctx.sync()
-    t_u = time.perf_counter()
-    for _ in range(nrep):
+    u12_per_s, u3_ms, u3_vs_k = None, None, None
+    if not args.no_units:
+        va, vb = host.nek_dvector(gm), host.nek_dvector(gm)
+        va.rand(False, seed=7)
+        nrep = 20
         host.check(lib.nlg_op_helmholtz(gm.h, va.h, vb.h, 1.0 / args.re, 1.0, 1))
-    ctx.sync()
-    u12_per_s = dim * nrep / (time.perf_counter() - t_u)
-    wv = B[m]
-    wv.rand(False, seed=8)
-    ctx.sync()
-    t_u = time.perf_counter()
-    nrep3 = 3
-    for _ in range(nrep3):
-        B.cgs2(m, wv)
-    ctx.sync()
-    u3_ms = 1e3 * (time.perf_counter() - t_u) / nrep3
-    u3_vs_k = {}
-    for kk in sorted({1, 2, 4, 8, 16, 32, 48, m}):
-        if kk > m:
-            continue
-        wv.rand(False, seed=9)
         ctx.sync()
         t_u = time.perf_counter()
-        B.cgs2(kk, wv)
+        for _ in range(nrep):
+            host.check(lib.nlg_op_helmholtz(gm.h, va.h, vb.h, 1.0 / args.re, 1.0, 1))
         ctx.sync()
-        u3_vs_k[str(kk)] = round(1e3 * (time.perf_counter() - t_u), 3)
-    del va, vb
+        u12_per_s = dim * nrep / (time.perf_counter() - t_u)
+        wv = B[m]
+        wv.rand(False, seed=8)
+        ctx.sync()
+        t_u = time.perf_counter()
+        nrep3 = 3
+        for _ in range(nrep3):
+            B.cgs2(m, wv)
+        ctx.sync()
+        u3_ms = 1e3 * (time.perf_counter() - t_u) / nrep3
+        u3_vs_k = {}
+        for kk in sorted({1, 2, 4, 8, 16, 32, 48, m}):
+            if kk > m:
+                continue
+            wv.rand(False, seed=9)
+            ctx.sync()
+            t_u = time.perf_counter()
+            B.cgs2(kk, wv)
+            ctx.sync()
+            u3_vs_k[str(kk)] = round(1e3 * (time.perf_counter() - t_u), 3)
+        del va, vb
+
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle restatement on a bounded sample
     cpu = None
@@ -271,8 +275,8 @@ def main():
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
                        "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
                        "global_elements": E * world,
-                       "operator_applies_per_s_per_field_per_gpu": round(u12_per_s, 1),
-                       "arnoldi_orthogonalisation_ms_at_k=m": round(u3_ms, 3),
+                       "operator_applies_per_s_per_field_per_gpu": None if u12_per_s is None else round(u12_per_s, 1),
+                       "arnoldi_orthogonalisation_ms_at_k=m": None if u3_ms is None else round(u3_ms, 3),
                        "arnoldi_orthogonalisation_ms_vs_k": u3_vs_k,
                        "parallelism": "1 process per GPU, contiguous element blocks, RCCL all-reduce for every reduction, "
                                       "RCCL send/recv halo for the gather-scatter"},

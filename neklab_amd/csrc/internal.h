@@ -272,17 +272,17 @@ int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped 
 void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
-int sem_gs(nlg_mesh *m, double *const *fields, int nf);              // in place QQ^T
-int sem_gs_pairs_fg(nlg_mesh *m, double *w);   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
+int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr);   // in place QQ^T; gate: device flag, non-zero = skip
+int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
                double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr);   // zf: fused u <- zf + beta u
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
-int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false);
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false, const double *gate = nullptr);
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false,
-              const double *pdot = nullptr, double *pw_part = nullptr);
+              const double *pdot = nullptr, double *pw_part = nullptr, const double *gate = nullptr);
 int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
-int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr);
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr, const double *gate = nullptr);
 int sem_ediag(nlg_mesh *m, double *out);
 int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, const double *Mx, const double *My,
                const double *Mz, const double *wt);

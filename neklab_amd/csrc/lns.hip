@@ -648,7 +648,7 @@ int helm_solve(nlg_linop *op, int order, double h2) {
             NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE));
         else
             NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part));
-        NLG_TRY(sem_gs(m, op->w, dim));
+        NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE));
         return 0;
     };
     int iters = 0;
@@ -707,7 +707,8 @@ int pres_solve(nlg_linop *op, double scale) {
             P.rz_n = (int)((m->E + 3) / 4);
         }
     }
-    auto apply = [&](double *) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w, pw_part); };
+    // gated: launches past convergence (the host only looks at the flag once per chunk) return at once
+    auto apply = [&](double *sflag) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w, pw_part, sflag + S_DONE); };
     // ---- residual projection (c.pproj): start from the A-orthogonal projection of the solution onto the span of the
     // previous increments of this matvec; the PCG then solves for the remainder
     hipStream_t st = m->ctx->stream;

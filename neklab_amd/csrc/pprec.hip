@@ -203,7 +203,6 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
                                                 const double *__restrict__ wq, double *__restrict__ W,
                                                 double *__restrict__ z) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
-    __shared__ double sS[WPB][3][N * N];
     __shared__ double sL[WPB][3][N];
     __shared__ double sA[WPB][NP], sB[WPB][NP];
     if (flag && flag[0] != 0.0) return;
@@ -211,7 +210,10 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
     const int64_t e = (int64_t)blockIdx.x * WPB + wv;
     const bool act = e < E;
     const int64_t ee = act ? e : 0;
-    for (int q = lane; q < 3 * N * N; q += 64) sS[wv][q / (N * N)][q % (N * N)] = S[ee * (3 * N * N) + q];
+    // the element index is wave-uniform: with the pointer made provably uniform the 1-D eigenvector matrices are read by
+    // scalar loads straight into FMA operands instead of 384 broadcast LDS reads per lane
+    const int eu = __builtin_amdgcn_readfirstlane((int)ee);
+    const double *__restrict__ Sg = S + (int64_t)eu * (3 * N * N);
     for (int q = lane; q < 3 * N; q += 64) sL[wv][q / N][q % N] = lam[ee * (3 * N) + q];
     const double *re = r + ee * NP2;
     double *We = W + ee * NP;
@@ -228,22 +230,22 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
         sA[wv][q] = v;
     }
     __syncthreads();
-    fdm_stage<N, 3, true, 0>(sA[wv], sB[wv], sS[wv][0], lane);
+    fdm_stage<N, 3, true, 0>(sA[wv], sB[wv], Sg + 0 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, true, 1>(sB[wv], sA[wv], sS[wv][1], lane);
+    fdm_stage<N, 3, true, 1>(sB[wv], sA[wv], Sg + 1 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, true, 2>(sA[wv], sB[wv], sS[wv][2], lane);
+    fdm_stage<N, 3, true, 2>(sA[wv], sB[wv], Sg + 2 * N * N, lane);
     __syncthreads();
     for (int q = lane; q < NP; q += 64) {
         const double den = sL[wv][0][q % N] + sL[wv][1][(q / N) % N] + sL[wv][2][q / (N * N)];
         sB[wv][q] = den > thr ? sB[wv][q] / den : 0.0;
     }
     __syncthreads();
-    fdm_stage<N, 3, false, 2>(sB[wv], sA[wv], sS[wv][2], lane);
+    fdm_stage<N, 3, false, 2>(sB[wv], sA[wv], Sg + 2 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, false, 1>(sA[wv], sB[wv], sS[wv][1], lane);
+    fdm_stage<N, 3, false, 1>(sA[wv], sB[wv], Sg + 1 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, false, 0>(sB[wv], sA[wv], sS[wv][0], lane);
+    fdm_stage<N, 3, false, 0>(sB[wv], sA[wv], Sg + 0 * N * N, lane);
     __syncthreads();
     if (act) {
         for (int q = lane; q < NP; q += 64) {
@@ -1071,7 +1073,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         // pprec_coarse has packed the adjacent layers into P.d_W (same stream)
         NLG_CHECK(P.overlap && m->dim == 3, "pprec: the overlapping variant is not set up for this mesh");
         const unsigned gb = (unsigned)((E + 3) / 4);
-        NLG_TRY(sem_gs_pairs_fg(m, P.d_W));
+        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
 #define FX_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
         hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
@@ -1081,7 +1083,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
             default: set_error("pprec: overlapping variant built for lx1 = 4..8, got %d", m->n); return 1;
         }
 #undef FX_CASE
-        NLG_TRY(sem_gs_pairs_fg(m, P.d_W));
+        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
 #define FF_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
         hipLaunchKernelGGL((k_sch_finish<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \

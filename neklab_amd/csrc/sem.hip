@@ -356,7 +356,8 @@ __global__ void k_mul(double *y, const double *a, const double *b, int64_t n) {
 // go through the general CSR path.  Sums run over ascending local index in every class.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const int *__restrict__ idx, int64_t ngroups,
-                                           int64_t npairs, int64_t nquads, F3 f) {
+                                           int64_t npairs, int64_t nquads, F3 f, const double *__restrict__ gate) {
+    if (gate && gate[0] != 0.0) return;
     const int64_t g = blockIdx.x * (int64_t)NT + threadIdx.x;
     if (g >= ngroups) return;
     if (g < npairs) {
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
     double *wc = c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2]);
     // fused direction update of the surrounding PCG (beta_p != null): u <- z + beta u before the operator is applied,
     // unless the solver has converged (the separate update kernel is gated the same way)
+    if (done_p && done_p[0] != 0.0) return;   // converged: nothing consumes w any more
     const bool upd = beta_p != nullptr && done_p[0] == 0.0;
     const double beta = upd ? beta_p[0] : 0.0;
     const double *zc = c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2]);
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     __shared__ double sD[N * N];
     __shared__ double sU[WPB][N * NQ], sR[WPB][N * NQ], sS[WPB][N * NQ];
     __shared__ double sred[WPB];
+    if (done_p && done_p[0] != 0.0) return;   // the surrounding PCG has converged: nothing consumes w any more
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int p = tid; p < NS; p += 64 * WPB) sD[p] = Dg[p];
     __syncthreads();   // the only block-wide barrier: the derivative matrix
@@ -770,7 +773,9 @@ struct PMats {
 
 // opgradt: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise)
 template <int N, int NC, bool FG>
-__global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w) {
+__global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w,
+                                                 const double *__restrict__ gate) {
+    if (gate && gate[0] != 0.0) return;   // the surrounding PCG has converged (device-side done flag)
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SA = N2 * N2 * N, SB = N2 * N * N;
@@ -865,7 +870,9 @@ __global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, c
 // part[E + e] = sum_q out_q over the element -- saves a separate pass over two pressure-mesh vectors.
 template <int N, int NC, bool FG>
 __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
-                                               double scale, const double *__restrict__ pdot, double *__restrict__ part) {
+                                               double scale, const double *__restrict__ pdot, double *__restrict__ part,
+                                               const double *__restrict__ gate) {
+    if (gate && gate[0] != 0.0) return;
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SB = N2 * N * N, SC = N2 * N2 * N;
@@ -1511,7 +1518,7 @@ double *sem_scratch2(nlg_mesh *m, int i) {
     return m->scratch2[i];
 }
 
-int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
+int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate) {
     if (m->gs.ngroups == 0 && !m->halo.active) return 0;
     ProfScope ps(m->ctx, P_GS);
     if (nf < 1 || nf > 3) {
@@ -1522,11 +1529,11 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf) {
         F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
         const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
         if (nf == 1)
-            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
+            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
         else if (nf == 2)
-            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
+            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
         else
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
         NLG_HIP(hipGetLastError());
     }
     return halo_exchange(m, fields, nf);   // no-op on a single rank
@@ -1543,13 +1550,13 @@ static int axhelm3_nslot(int N) {
     return nslot;
 }
 
-int sem_gs_pairs_fg(nlg_mesh *m, double *w) {
+int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate) {
     NLG_CHECK(m->gs.d_indices_fg, "sem_gs_pairs_fg: no face-grouped tables (3-D only)");
     if (m->gs.npairs == 0) return 0;
     F3 f = {{w, nullptr, nullptr}};
     const int grid = (int)((m->gs.npairs + NT - 1) / NT);
     hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.npairs,
-                       m->gs.npairs, (int64_t)0, f);
+                       m->gs.npairs, (int64_t)0, f, gate);
     NLG_HIP(hipGetLastError());
     return 0;
 }
@@ -1633,7 +1640,7 @@ static CF9 rst2w_ptrs(const nlg_mesh *m) {
     return g;
 }
 
-int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped) {
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped, const double *gate) {
     ProfScope ps(m->ctx, P_OPGRADT);
     F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
@@ -1644,13 +1651,13 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);    \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);   \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);    \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);   \
     }
         NLG_FOR_N(GT3)
 #undef GT3
@@ -1669,7 +1676,7 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
 }
 
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts, bool face_grouped,
-              const double *pdot, double *pw_part) {
+              const double *pdot, double *pw_part, const double *gate) {
     NLG_CHECK(!pw_part || m->dim == 3, "sem_opdiv: fused sums exist for the 3-D kernel only");
     ProfScope ps(m->ctx, P_OPDIV);
     CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
@@ -1682,13 +1689,13 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate);  \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
     }
         NLG_FOR_N(DV3)
 #undef DV3
@@ -1719,30 +1726,30 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
     return 0;
 }
 
-int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part) {
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, const double *gate) {
     double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
     NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
     if (m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg)) {
         // 3-D: the intermediate velocity-mesh fields use the face-grouped element layout, in which the copies of a
         // shared face are contiguous runs -> coalesced gather-scatter; the rank halo uses index lists in that layout
-        NLG_TRY(sem_opgradt(m, p, w, true));
+        NLG_TRY(sem_opgradt(m, p, w, true, gate));
         if (m->gs.ngroups > 0) {
             ProfScope ps(m->ctx, P_GS);
             F3 f = {{w[0], w[1], w[2]}};
             const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
             NLG_HIP(hipGetLastError());
         }
         if (m->halo.active) {
             ProfScope ps(m->ctx, P_GS);
             NLG_TRY(halo_exchange(m, w, 3, true));
         }
-        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part));
+        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part, gate));
         return 0;
     }
-    NLG_TRY(sem_opgradt(m, p, w));
-    NLG_TRY(sem_gs(m, w, m->dim));
-    NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv, false, p, pw_part));   // mask * binvm1 fused into the load
+    NLG_TRY(sem_opgradt(m, p, w, false, gate));
+    NLG_TRY(sem_gs(m, w, m->dim, gate));
+    NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv, false, p, pw_part, gate));   // mask * binvm1 fused into the load
     return 0;
 }
 
