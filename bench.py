@@ -65,8 +65,9 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
         return nshared * (16.0 * dim + 4.0)
     if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
         return 8.0 * (k * ncomp + ncomp + 1) * lvs
-    if cls == "block_axpy":   # k basis vectors + w in/out over all main fields and (consistent restart history,
-        return 8.0 * (k + 2) * main_len * lorder   # DESIGN.md 3.1) the lorder-1 history blocks of every vector
+    if cls == "block_axpy":   # k basis vectors + w in/out.  CGS2 launches it twice: first pass over the main fields only,
+        # second pass over main + the lorder-1 history blocks (consistent restart history) -> mean per launch
+        return 8.0 * (k + 2) * main_len * (1 + lorder) / 2.0
     return None
 
 

@@ -256,7 +256,8 @@ int allreduce_sum(nlg_ctx *ctx, double *d_buf, int count);
 int allreduce_max(nlg_ctx *ctx, double *d_buf, int count);
 
 int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc);
-int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign);
+int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign, const double *d_hh = nullptr,
+                         bool main_only = false);
 int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
 
 // ---- pprec.hip ----

@@ -180,13 +180,22 @@ __global__ __launch_bounds__(NT) void k_block_dot(const double *V, int64_t vstri
 
 // w -= sum_j h_j V_j on the main block; history slots of w receive the same correction
 // (reference axpby quirk) or the combination of the basis history (consistent mode).
+// `hh` (may be null): a second coefficient set used for the entries at or beyond blk2 (the history blocks of a sweep
+// that covers main + history in one range): CGS2 applies the second-pass coefficients to the main block and the SUM
+// of both passes to the history, which no inner product ever reads -> the history is swept once, not twice.
 __global__ __launch_bounds__(NT) void k_block_axpy(const double *V, int64_t vstride, int k, const double *h, double *w,
-                                                   int64_t n2, int nrst, int64_t blk2, int consistent, double sign) {
-    extern __shared__ double sh[];
-    for (int j = threadIdx.x; j < k; j += NT) sh[j] = h[j];
+                                                   int64_t n2, int nrst, int64_t blk2, int consistent, double sign,
+                                                   const double *hh) {
+    extern __shared__ double sh0[];
+    double *sh1 = sh0 + k;
+    for (int j = threadIdx.x; j < k; j += NT) {
+        sh0[j] = h[j];
+        sh1[j] = hh ? hh[j] : h[j];
+    }
     __syncthreads();
     double2 *w2 = reinterpret_cast<double2 *>(w);
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        const double *sh = (hh && i >= blk2) ? sh1 : sh0;
         double s0 = 0.0, s1 = 0.0;
         const double2 *v = reinterpret_cast<const double2 *>(V) + i;
         const int64_t vs2 = vstride >> 1;
@@ -538,19 +547,20 @@ int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_o
     return 0;
 }
 
-int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign) {
+int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign, const double *d_hh,
+                         bool main_only) {
     nlg_ctx *ctx = b->mesh->ctx;
     const int64_t n2 = w->main_len / 2;
     ProfScope ps(ctx, P_BLOCKAXPY);
     if (g_axpby_consistent) {
         // consistent history: main block and the nrst valid history blocks are one contiguous range in which every
         // entry receives the same linear combination -> one sweep through the unrolled path
-        const int64_t n2all = n2 * (1 + w->nrst);
-        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2all)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride,
-                           k, d_h, w->d, n2all, 0, n2, 0, sign);
+        const int64_t n2all = main_only ? n2 : n2 * (1 + w->nrst);
+        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2all)), dim3(NT), sizeof(double) * 2 * k, ctx->stream, b->d, b->stride,
+                           k, d_h, w->d, n2all, 0, n2, 0, sign, d_hh);
     } else {
-        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * k, ctx->stream, b->d, b->stride, k,
-                           d_h, w->d, n2, w->nrst, n2, 0, sign);
+        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * 2 * k, ctx->stream, b->d, b->stride, k,
+                           d_h, w->d, n2, w->nrst, n2, 0, sign, (const double *)nullptr);
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -563,9 +573,18 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
     double *h = b->d_h, *h2 = b->d_h + b->nvec + 8;
     if (k > 0) {
         NLG_TRY(basis_block_dot_dev(b, k, w, h, nullptr));
-        NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0));
-        NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));
-        NLG_TRY(basis_block_axpy_dev(b, k, h2, w, -1.0));
+        if (g_axpby_consistent) {
+            // first pass on the main block only; the second pass applies h2 to the main block and h + h2 (accumulated
+            // in h by the second block_dot) to the history blocks: the result is the one of two full sweeps up to
+            // rounding, at two thirds of the traffic
+            NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0, nullptr, true));
+            NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));
+            NLG_TRY(basis_block_axpy_dev(b, k, h2, w, -1.0, h, false));
+        } else {
+            NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0));
+            NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));
+            NLG_TRY(basis_block_axpy_dev(b, k, h2, w, -1.0));
+        }
     }
     // norm
     const int nblk = dot_nblk(w);
