@@ -15,6 +15,8 @@ CASES = [
     dict(nel=(3, 2, 2), n=6, periodic=(True, False, False)),
     dict(nel=(3, 3, 2), n=8, periodic=(False, False, True)),
     dict(nel=(2, 2, 2), n=5, periodic=(False, False, False)),
+    dict(nel=(2, 2, 2), n=10, periodic=(False, False, True)),     # lx1 > 8: the LDS-cube Helmholtz kernel, generic convection,
+    dict(nel=(2, 1, 2), n=12, periodic=(False, False, False)),    # NC = 1 pressure kernels, non-overlapping local solves
 ]
 
 
