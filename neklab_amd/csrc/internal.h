@@ -274,7 +274,8 @@ void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
 int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr);   // in place QQ^T; gate: device flag, non-zero = skip
-int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
+int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);
+int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
                double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr);   // zf: fused u <- zf + beta u
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part

@@ -328,6 +328,113 @@ __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ fl
     }
 }
 
+// ---- 2-D twins: the exchange array W is a velocity-shaped field in the natural layout (N x N per element), the ghost
+// layers are the interior points of the element edges, one lane per extended point.
+template <int N, bool FWD, int AX>
+__device__ __forceinline__ void fdm_stage2(const double *__restrict__ in, double *__restrict__ out,
+                                           const double *__restrict__ S, int p) {
+    // out[o, b] = sum_l Sop[o][l] in[l, b] along axis AX; Sop = S^T (FWD) or S;  S row-major [point][mode]
+    const int a = p % N, b = p / N;
+    const int o = AX == 0 ? a : b;
+    double acc = 0.0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        const double sv = FWD ? S[l * N + o] : S[o * N + l];
+        acc += sv * (AX == 0 ? in[l + N * b] : in[a + N * l]);
+    }
+    out[p] = acc;
+}
+
+template <int N>
+__global__ __launch_bounds__(NT) void k_fdm_ext2(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
+                                                 const double *__restrict__ lam, double thr, const double *__restrict__ r,
+                                                 const double *__restrict__ wq, double *__restrict__ W,
+                                                 double *__restrict__ z) {
+    static_assert(N * N <= 64, "one lane per extended point");
+    constexpr int N2 = N - 2, NP = N * N, NP2 = N2 * N2;
+    __shared__ double sS[4][2][N * N];
+    __shared__ double sA[4][NP], sB[4][NP];
+    if (flag && flag[0] != 0.0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 4 + wv;
+    const bool act = e < E;
+    const int64_t ee = act ? e : 0;
+    for (int q = lane; q < 2 * N * N; q += 64) sS[wv][q / (N * N)][q % (N * N)] = S[ee * (3 * N * N) + q];
+    const bool on = lane < NP;
+    const int p = on ? lane : 0;
+    const int a = p % N, b = p / N;
+    const int nb = (a == 0 || a == N - 1) + (b == 0 || b == N - 1);
+    const int a2 = min(max(a, 1), N - 2) - 1, b2 = min(max(b, 1), N - 2) - 1;
+    const int q2 = a2 + N2 * b2;
+    double v = 0.0;
+    if (nb <= 1) {
+        const double own = r[ee * NP2 + q2] * wq[ee * NP2 + q2];
+        v = nb == 0 ? own : W[ee * NP + p] - own;
+    }
+    if (on) sA[wv][p] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (on) fdm_stage2<N, true, 0>(sA[wv], sB[wv], sS[wv][0], p);
+    __syncthreads();
+    if (on) fdm_stage2<N, true, 1>(sB[wv], sA[wv], sS[wv][1], p);
+    __syncthreads();
+    if (on) {
+        const double den = lam[ee * (3 * N) + a] + lam[ee * (3 * N) + N + b];
+        sA[wv][p] = den > thr ? sA[wv][p] / den : 0.0;
+    }
+    __syncthreads();
+    if (on) fdm_stage2<N, false, 1>(sA[wv], sB[wv], sS[wv][1], p);
+    __syncthreads();
+    if (on) fdm_stage2<N, false, 0>(sB[wv], sA[wv], sS[wv][0], p);
+    __syncthreads();
+    (void)t;
+    if (act && on) {
+        if (nb == 1) {
+            W[e * NP + p] = sA[wv][p];
+        } else if (nb == 0) {
+            double o = sA[wv][p];
+            if (a == 1) o -= sA[wv][p - 1];
+            if (a == N - 2) o -= sA[wv][p + 1];
+            if (b == 1) o -= sA[wv][p - N];
+            if (b == N - 2) o -= sA[wv][p + N];
+            z[e * NP2 + q2] = o;
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(NT) void k_sch_finish2(const double *__restrict__ flag, int64_t E, const double *__restrict__ W,
+                                                    const double *__restrict__ r, const double *__restrict__ wq,
+                                                    const double *__restrict__ xc, const double *__restrict__ xa,
+                                                    const int *__restrict__ agg, const int *__restrict__ vg, Hat hat,
+                                                    double *__restrict__ z) {
+    constexpr int N2 = N - 2, NP = N * N, NP2 = N2 * N2;
+    if (flag && flag[0] != 0.0) return;
+    const int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x;
+    if (i >= E * NP2) return;
+    const int64_t e = i / NP2;
+    const int q = (int)(i % NP2), a = q % N2, b = q / N2;
+    const double *We = W + e * NP;
+    double v = z[i];
+    if (a == 0) v += We[0 + N * (b + 1)];
+    if (a == N2 - 1) v += We[(N - 1) + N * (b + 1)];
+    if (b == 0) v += We[(a + 1) + N * 0];
+    if (b == N2 - 1) v += We[(a + 1) + N * (N - 1)];
+    v *= wq[i];
+    if (xc) {
+        double cv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int vv = vg[e * 4 + c];
+            cv[c] = xc[vv] + xa[agg[vv]];
+        }
+        const double ha = hat.h1[a], hb = hat.h1[b];
+        const double c0 = cv[0] + ha * (cv[1] - cv[0]), c1 = cv[2] + ha * (cv[3] - cv[2]);
+        v += c0 + hb * (c1 - c0);
+    }
+    z[i] = v;
+}
+
 // t[e][c] = sum_q phi_c(q) r_e(q): the element-local part of R_1^T r, one wave per element
 template <int DIM>
 __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restrict__ flag, int64_t E, int n2, Hat hat,
@@ -346,6 +453,15 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restri
         const double v = r[e * np2 + q];
         const double ha = hat.h1[q % n2], hb = hat.h1[(q / n2) % n2];
         const double hc = DIM == 3 ? hat.h1[q / (n2 * n2)] : 0.0;
+        if (DIM == 2 && W) {
+            const int N = n2 + 2, a = q % n2, b = q / n2;
+            double *We = W + e * (int64_t)(N * N);
+            const double vw = v * wq[e * np2 + q];
+            if (a == 0) We[0 + N * (b + 1)] = vw;
+            if (a == n2 - 1) We[(N - 1) + N * (b + 1)] = vw;
+            if (b == 0) We[(a + 1)] = vw;
+            if (b == n2 - 1) We[(a + 1) + N * (N - 1)] = vw;
+        }
         if (DIM == 3 && W) {
             // overlapping Schwarz, pack: the layers adjacent to the element faces go to the face points of W
             const int N = n2 + 2, a = q % n2, b = (q / n2) % n2, c = q / (n2 * n2);
@@ -678,22 +794,23 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     NLG_TRY(up(hS, &P.d_S));
     NLG_TRY(up(hden, &P.d_invden));
 
-    // ---- 1b. overlapping variant (3-D): extended 1-D operators from the line left neighbour | element | right neighbour
-    if (dim == 3 && m->gs.d_indices_fg && m->gs.npairs > 0 && n <= 8) {
+    // ---- 1b. overlapping variant: extended 1-D operators from the line left neighbour | element | right neighbour
+    // (3-D: exchange array in the face-grouped layout; 2-D: natural layout)
+    if (((dim == 3 && m->gs.d_indices_fg) || dim == 2) && m->gs.npairs > 0 && n <= 8) {
         // normal edge length of the face neighbours, through the (rank-local) gather-scatter: every element puts its own
         // normal length on the interior points of its faces, the sum minus the own value is the neighbour's
         std::vector<double> hw((size_t)m->lvn, 0.0);
         auto face_node = [&](int dd, int side, int u, int v) {
-            int ijk[3];
+            int ijk[3] = {0, 0, 0};
             ijk[dd] = side == 0 ? 0 : n - 1;
-            ijk[(dd + 1) % 3] = u;
-            ijk[(dd + 2) % 3] = v;
+            ijk[(dd + 1) % dim] = u;
+            if (dim == 3) ijk[(dd + 2) % 3] = v;
             return ijk[0] + n * (ijk[1] + n * ijk[2]);
         };
         for (int64_t e = 0; e < E; ++e)
-            for (int dd = 0; dd < 3; ++dd)
+            for (int dd = 0; dd < dim; ++dd)
                 for (int side = 0; side < 2; ++side)
-                    for (int v = 1; v < n - 1; ++v)
+                    for (int v = 1; v < (dim == 3 ? n - 1 : 2); ++v)
                         for (int u = 1; u < n - 1; ++u) hw[(size_t)e * np1 + face_node(dd, side, u, v)] = Lall[(size_t)e * 3 + dd];
         double *dw = sem_scratch1(m, 0);
         NLG_CHECK(dw, "pprec_setup: scratch allocation failed");
@@ -719,11 +836,11 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         std::vector<double> hwq((size_t)E * np2, 1.0);
         double dmax = 0.0;
         for (int64_t e = 0; e < E; ++e) {
-            for (int dd = 0; dd < 3; ++dd) {
+            for (int dd = 0; dd < dim; ++dd) {
                 const double lm = Lall[(size_t)e * 3 + dd];
                 double ln[2];
                 for (int side = 0; side < 2; ++side) {
-                    const double sum = hw[(size_t)e * np1 + face_node(dd, side, mid, mid)];
+                    const double sum = hw[(size_t)e * np1 + face_node(dd, side, mid, dim == 3 ? mid : 0)];
                     ln[side] = sum - lm > 1e-10 * lm ? sum - lm : 0.0;
                 }
                 const double len[3] = {ln[0], lm, ln[1]};
@@ -778,7 +895,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
                 for (int a = 0; a < mx; ++a) hlx[((size_t)e * 3 + dd) * mx + a] = std::max(lx[a], 0.0);
             }
             double mxl = 0.0;
-            for (int dd = 0; dd < 3; ++dd) {
+            for (int dd = 0; dd < dim; ++dd) {
                 double mm = 0.0;
                 for (int a = 0; a < mx; ++a) mm = std::max(mm, hlx[((size_t)e * 3 + dd) * mx + a]);
                 mxl += mm;
@@ -1049,8 +1166,9 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
         hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq,
                            overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq);
     } else {
+        NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
         hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq,
-                           (double *)nullptr, (const double *)nullptr);
+                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq);
     }
     hipLaunchKernelGGL(k_q1_gather, dim3((nv + NT - 1) / NT), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x);
     hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
@@ -1069,6 +1187,34 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
     Hat hat;
     for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
     const int *vg = P.d_vg;
+    if (overlap && m->dim == 2) {
+        NLG_CHECK(P.overlap, "pprec: the overlapping variant is not set up for this mesh");
+        NLG_CHECK(!rz_part, "pprec: fused sums exist for the 3-D kernels only");
+        const unsigned gb = (unsigned)((E + 3) / 4);
+        NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+#define FX2_CASE(N_)                                                                                                  \
+    case N_:                                                                                                          \
+        hipLaunchKernelGGL((k_fdm_ext2<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
+        break;
+        switch (m->n) {
+            FX2_CASE(4) FX2_CASE(5) FX2_CASE(6) FX2_CASE(7) FX2_CASE(8)
+            default: set_error("pprec: overlapping variant built for lx1 = 4..8, got %d", m->n); return 1;
+        }
+#undef FX2_CASE
+        NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        const unsigned gf = (unsigned)((E * m->np2 + NT - 1) / NT);
+#define FF2_CASE(N_)                                                                                                  \
+    case N_:                                                                                                          \
+        hipLaunchKernelGGL((k_sch_finish2<N_>), dim3(gf), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z); \
+        break;
+        switch (m->n) {
+            FF2_CASE(4) FF2_CASE(5) FF2_CASE(6) FF2_CASE(7) FF2_CASE(8)
+            default: break;
+        }
+#undef FF2_CASE
+        NLG_HIP(hipGetLastError());
+        return 0;
+    }
     if (overlap) {
         // pprec_coarse has packed the adjacent layers into P.d_W (same stream)
         NLG_CHECK(P.overlap && m->dim == 3, "pprec: the overlapping variant is not set up for this mesh");

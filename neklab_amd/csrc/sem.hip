@@ -1550,6 +1550,16 @@ static int axhelm3_nslot(int N) {
     return nslot;
 }
 
+int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate) {
+    if (m->gs.npairs == 0) return 0;
+    F3 f = {{w, nullptr, nullptr}};
+    const int grid = (int)((m->gs.npairs + NT - 1) / NT);
+    hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.npairs,
+                       m->gs.npairs, (int64_t)0, f, gate);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate) {
     NLG_CHECK(m->gs.d_indices_fg, "sem_gs_pairs_fg: no face-grouped tables (3-D only)");
     if (m->gs.npairs == 0) return 0;
