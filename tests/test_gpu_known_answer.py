@@ -72,3 +72,28 @@ def test_cylinder_base_flow_is_fixed_point_and_newton_returns_to_it(gpu_ctx):
     sysm.set_tolerance(1e-8)                                    # the claim is checked with tighter solves than Newton used
     sysm.eval(X, F)
     assert F.norm() < 1e-5
+
+
+def test_poiseuille_re7500_orr_sommerfeld(gpu_ctx, tmp_path):
+    """Second known answer, independent of Nek5000: plane Poiseuille flow at Re = 7500, alpha = 1 (the reference's
+    examples/poiseuille/stability/direct, poiseuille.par:31, base flow 1 - y^2 at poiseuille.usr:140).  The leading
+    eigenvalue of exp(tau L), tau = 1, must be exp(-i c) with the Orr-Sommerfeld phase speed c = 0.24989146 +
+    0.00223497 i (computed by the Chebyshev collocation solver of scripts/poiseuille_oracle.py; Orszag 1971 gives
+    c = 0.24989154 + 0.00223498 i): mu = 0.97110724 - 0.24785212 i, |mu| = 1.00223747.
+    Measured: |mu - mu_OS| = 2.5e-5 on 10 x 12 elements, lx1 = 8 (profiles/r01_poiseuille_orr_sommerfeld_gpu.log)."""
+    from neklab_amd.mesh import box_mesh
+    mu_os = np.exp(-1j * (0.24989146 + 0.00223497j))
+    hm = box_mesh((10, 12), 8, lengths=(2 * np.pi, 2.0), periodic=(True, False), deform=0.0, origin=(0.0, -1.0))
+    gm = host.Mesh(gpu_ctx, hm)
+    bf = host.nek_dvector(gm)
+    bf.set_field(host.VX, 1.0 - hm.y ** 2)
+    A = host.exptA_linop(1.0, bf, re=7500.0, torder=3, vtol=1e-11, ptol=1e-10, maxit_p=4000)
+    A.init()
+    eigvals, residuals, eigvecs, mu, nmv = host.linear_stability_analysis_fixed_point(
+        A, 160, 2, tol=1e-6, outdir=str(tmp_path), seed=1)
+    m = mu[0] if mu[0].imag < 0 else np.conj(mu[0])
+    assert residuals[0] < 1e-6
+    assert abs(m - mu_os) < 1e-4, (m, mu_os)
+    assert abs(abs(m) - 1.00223747) < 5e-5          # a weakly UNSTABLE mode: growth rate 2.2e-3 resolved to 2 %
+    st = A.stats()
+    assert st["p_iters"] / st["steps"] < 60          # overlapping Schwarz + vertex coarse space + projection in 2-D
