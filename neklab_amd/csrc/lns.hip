@@ -636,7 +636,7 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     // w = QQ^T (nu A + h2 B) p.  The Dirichlet mask is not applied to w: p is masked (z = pc r with pc = mask/diag), so
     // (p, w) does not see the masked entries, and k_cg_update zeroes the residual where pc == 0.
     // 3-D: (p, w) = sum over the local dofs of p . w_local (p is continuous), summed inside the operator kernel.
-    double *pw_part = dim == 3 ? op->d_part : nullptr;
+    double *pw_part = op->d_part;   // both the 2-D and the 3-D operator kernels sum (p, w) and update p themselves
     if (pw_part) {
         P.pw_part = pw_part;
         P.pw_n = sem_axhelm_blocks(m, dim);

@@ -650,13 +650,19 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
 template <int N, int NF>
 __global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) void k_axhelm2(
     int64_t E, const double *__restrict__ Dg, const double *__restrict__ G0, const double *__restrict__ G1,
-    const double *__restrict__ G2, const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2) {
+    const double *__restrict__ G2, const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
+    double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p, const double *__restrict__ done_p) {
     constexpr int EPB = (NT / (N * N)) > 0 ? (NT / (N * N)) : 1;
     constexpr int NP = N * N;
     __shared__ double sD[N * N];
     __shared__ double sU[EPB][NF][NP];
     __shared__ double sR[EPB][NF][NP];
     __shared__ double sS[EPB][NF][NP];
+    __shared__ double sred[8];
+    // same PCG fusions as the 3-D kernel: skip after convergence, u <- z + beta u on load, (u, w_local) sums
+    if (done_p && done_p[0] != 0.0) return;
+    const bool upd = beta_p != nullptr;
+    const double beta = upd ? beta_p[0] : 0.0;
     const int tid = threadIdx.x;
     const int le = tid / NP, ij = tid % NP, i = ij % N, j = ij / N;
     for (int p = tid; p < N * N; p += EPB * NP) sD[p] = Dg[p];
@@ -667,6 +673,10 @@ __global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) 
 #pragma unroll
     for (int c = 0; c < NF; ++c) {
         uu[c] = act ? u.p[c][q] : 0.0;
+        if (upd && act) {
+            uu[c] = zf.p[c][q] + beta * uu[c];
+            const_cast<double *>(u.p[c])[q] = uu[c];
+        }
         sU[le][c][ij] = uu[c];
     }
     const double g0 = G0[q], g1 = G1[q], g2 = G2[q], bm = bm1[q];
@@ -683,13 +693,27 @@ __global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) 
         sS[le][c][ij] = g1 * ur + g2 * us;
     }
     __syncthreads();
+    double pw = 0.0;
     if (act) {
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             double a = 0.0;
 #pragma unroll
             for (int l = 0; l < N; ++l) a += sD[l * N + i] * sR[le][c][l + N * j] + sD[l * N + j] * sS[le][c][i + N * l];
-            w.p[c][q] = h1 * a + h2 * bm * uu[c];
+            const double wv = h1 * a + h2 * bm * uu[c];
+            w.p[c][q] = wv;
+            pw += wv * uu[c];
+        }
+    }
+    if (pw_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+        if ((tid & 63) == 0) sred[tid >> 6] = pw;
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0;
+            for (int q2 = 0; q2 < (int)((blockDim.x + 63) >> 6); ++q2) a += sred[q2];
+            pw_part[blockIdx.x] = a;
         }
     }
 }
@@ -1572,6 +1596,10 @@ int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate) {
 }
 
 int sem_axhelm_blocks(nlg_mesh *m, int nf) {
+    if (m->dim == 2) {
+        const int epb = NT / (m->n * m->n) > 0 ? NT / (m->n * m->n) : 1;
+        return (int)((m->E + epb - 1) / epb);
+    }
     const int nslot = axhelm3_nslot(m->n);
     return (int)((m->E * nf + nslot - 1) / nslot);
 }
@@ -1583,8 +1611,7 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
     F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
     hipStream_t s = m->ctx->stream;
-    NLG_CHECK(!pw_part || m->dim == 3, "sem_axhelm: the fused u.w sums exist in the 3-D kernel only");
-    NLG_CHECK(!beta_p || (m->dim == 3 && zf && done_p), "sem_axhelm: the fused direction update exists in the 3-D kernel only");
+    NLG_CHECK(!beta_p || (zf && done_p), "sem_axhelm: the fused direction update needs zf and the done flag");
     CF3 cz = {{zf ? zf[0] : nullptr, (zf && nf > 1) ? zf[1] : nullptr, (zf && nf > 2) ? zf[2] : nullptr}};
     if (m->dim == 3) {
 #define AX3(N_)                                                                                                       \
@@ -1609,13 +1636,13 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         const int grid = (int)((m->E + EPB - 1) / EPB);                                                               \
         if (nf == 1)                                                                                                  \
             hipLaunchKernelGGL((k_axhelm2<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2);                                       \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
         else if (nf == 2)                                                                                             \
             hipLaunchKernelGGL((k_axhelm2<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2);                                       \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
         else                                                                                                          \
             hipLaunchKernelGGL((k_axhelm2<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2);                                       \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
     }
         NLG_FOR_N(AX2)
 #undef AX2
