@@ -469,6 +469,7 @@ struct nlg_linop {
     int nonlinear = 0;         // 1: full Navier-Stokes step, N(u) = (u.grad)u = half of the linearised term about U = u
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
+    std::vector<int> pit_hist, vit_hist;   // iteration counts of the previous matvec, by time-step index (the pattern repeats)
 };
 
 namespace {
@@ -507,7 +508,8 @@ struct CGProblem {
     double tol2;         // squared tolerance on sum r^2 nw
     int use_tol, maxit;
     double *s;           // device scalars
-    int chunk;
+    int chunk;           // iterations launched before the host first looks at the done flag (the prediction)
+    int chunk_next = 2;  // ... and per look afterwards
     double inv_n;        // 1/n for the mean-free projected solve, 0 = no projection
     // non-pointwise M^-1 (nf = 1): writes the element-wise part to z and returns the coarse part per element in *xc
     std::function<int(const double *flag, const double *r, double *z, const double **xc)> precond;
@@ -576,7 +578,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     int launched = 0;
     int iters = 0;
     while (true) {
-        int todo = P.chunk;
+        int todo = launched == 0 ? P.chunk : P.chunk_next;
         if (launched + todo > P.maxit) todo = P.maxit - launched;
         for (int it = 0; it < todo; ++it) {
             NLG_TRY(apply(s));
@@ -631,7 +633,12 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     P.maxit = c.fixed_iters_v > 0 ? c.fixed_iters_v : c.maxit_v;
     P.s = op->d_s;
     P.inv_n = 0.0;
-    P.chunk = std::max(4, std::min(op->last_viters + 1, 32));
+    // the iteration count barely changes from one time step to the next: launch exactly the previous count, then look at
+    // the flag every second iteration; launches issued after convergence are gated on the device but still cost a launch
+    {
+        const int pred = (op->istep < (int)op->vit_hist.size() && op->vit_hist[op->istep] > 0) ? op->vit_hist[op->istep] : op->last_viters;
+        P.chunk = std::max(2, std::min(pred, 64));
+    }
     const double nu = 1.0 / c.re;
     // w = QQ^T (nu A + h2 B) p.  The Dirichlet mask is not applied to w: p is masked (z = pc r with pc = mask/diag), so
     // (p, w) does not see the masked entries, and k_cg_update zeroes the residual where pc == 0.
@@ -655,6 +662,8 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     NLG_TRY(run_pcg(op, P, apply, &iters));
     op->st_viters += iters;
     op->last_viters = iters;
+    if ((int)op->vit_hist.size() <= op->istep) op->vit_hist.resize(op->istep + 1, 0);
+    op->vit_hist[op->istep] = iters;
     return 0;
 }
 
@@ -695,7 +704,10 @@ int pres_solve(nlg_linop *op, double scale) {
             return 0;
         };
     }
-    P.chunk = std::max(8, std::min(op->last_piters / 4 + 1, 64));
+    {
+        const int pred = (op->istep < (int)op->pit_hist.size() && op->pit_hist[op->istep] > 0) ? op->pit_hist[op->istep] : op->last_piters;
+        P.chunk = std::max(2, std::min(pred, 96));
+    }
     const bool fuse = m->dim == 3;   // the fused first-stage sums are rank-local; the all-reduce follows the second stage
     double *pw_part = nullptr;
     if (fuse) {
@@ -732,6 +744,8 @@ int pres_solve(nlg_linop *op, double scale) {
     NLG_TRY(run_pcg(op, P, apply, &iters));
     op->st_piters += iters;
     op->last_piters = iters;
+    if ((int)op->pit_hist.size() <= op->istep) op->pit_hist.resize(op->istep + 1, 0);
+    op->pit_hist[op->istep] = iters;
     if (proj) {
         // new member from the increment d = pr_x: w = A d, A-orthogonalised against the old members, normalised
         NLG_TRY(sem_cdabdtp(m, op->pr_x, op->pr_w));
