@@ -95,6 +95,51 @@ def run(mesh, U_fields, re, dt, kdim, v_iters, p_iters, steps_per_matvec, budget
         float(np.sum(p * pw))
         pw[...] = z + 0.5 * pw
 
+    impl = "numpy restatement (oracle/): tensor contractions on the BLAS thread pool (`cores`), element-wise work single-threaded"
+    # the C + OpenMP port of the same operators (oracle/c/sem_cpu.c, checked against the numpy restatement in
+    # tests/test_cpu_oracle.py) when it is built and the mesh is 3-D: every unit on all host threads
+    cp = None
+    if dim == 3:
+        try:
+            from .cport import CPort, load
+            if load() is not None:
+                cp = CPort(sem)
+        except Exception:
+            cp = None
+    if cp is not None:
+        cores = cp.threads()
+        impl = "C + OpenMP restatement (oracle/c/sem_cpu.c, gcc -O3 -mavx2 -mfma), element loops over `cores` threads"
+        bm1 = np.ascontiguousarray(sem.bm1)
+        vm = np.ascontiguousarray(sem.vmult * np.ones(sem.shape1))
+        bm2 = np.ascontiguousarray(sem.bm2)
+        zz = [np.zeros(sem.shape1) for _ in range(dim)]
+        xx = [np.zeros(sem.shape1) for _ in range(dim)]
+        pz, px = np.zeros(sem.shape2), np.zeros(sem.shape2)
+
+        def helm():
+            return cp.helm(u, nu, h2)
+
+        def eop():
+            return cp.cdabdtp(p)
+
+        def conv():
+            return cp.lns_conv_weak(U, u)
+
+        def dot1():
+            return sum(cp.glsc3(u[i], U[i], bm1) for i in range(dim))
+
+        def axpby1():
+            for i in range(dim):
+                cp.axpby(0.3, u[i], 1.0, w[i])
+            cp.axpby(0.3, p, 1.0, pw)
+
+        def cgvec_v():
+            for i in range(dim):
+                cp.cgvec(xx[i], w[i], zz[i], xx[i], u[i], vm, vm)
+
+        def cgvec_p():
+            cp.cgvec(px, pw, pz, px, p, bm2, bm2)
+
     t_h = _time(helm, per)
     t_e = _time(eop, per)
     t_c = _time(conv, per, max_rep=2)
@@ -108,7 +153,7 @@ def run(mesh, U_fields, re, dt, kdim, v_iters, p_iters, steps_per_matvec, budget
     total = t_matvec + t_orth
     return {
         "value": 1.0 / total, "unit": "matvecs/s", "cores": cores, "kind": "port",
-        "implementation": "numpy restatement (oracle/): tensor contractions on the BLAS thread pool (`cores`), element-wise work single-threaded",
+        "implementation": impl,
         "sample": ("unit times on the same E=%d lx1=%d mesh: Helmholtz apply(3 comp)=%.3fs, E apply=%.3fs, "
                    "dealiased convection=%.3fs, per-vector dot=%.4fs, per-vector axpby=%.4fs, CG vector work "
                    "v=%.3fs p=%.4fs; composed with the GPU run's counts (%.1f time steps/matvec, %d Helmholtz and "

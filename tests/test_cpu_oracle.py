@@ -256,3 +256,33 @@ def test_oracle_gmres_and_nonlinear_map():
     d = F1.copy()
     d.axpby(-1.0, Jb, 1.0)
     assert d.norm() < 1e-3 * Jb.norm(), (d.norm(), Jb.norm())
+
+
+def test_c_port_matches_numpy_restatement():
+    """oracle/c/sem_cpu.c (the C + OpenMP port timed by bench.py's cpu_baseline) against oracle/sem.py."""
+    import subprocess
+    from oracle.cport import CPort, load
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if load() is None:
+        subprocess.run(["make", "-C", os.path.join(root, "oracle", "c")], check=True, capture_output=True)
+    hm = box_mesh((3, 2, 2), 6, periodic=(True, False, False), deform=0.05)
+    sem = SEM(hm)
+    cp = CPort(sem)
+    rng = np.random.default_rng(0)
+    u = [rng.standard_normal(sem.shape1) for _ in range(3)]
+    U = [rng.standard_normal(sem.shape1) for _ in range(3)]
+    p = rng.standard_normal(sem.shape2)
+
+    def err(a, b):
+        return np.max(np.abs(a - b)) / np.max(np.abs(b))
+
+    assert err(cp.axhelm_local(u[0], 0.3, 2.0), sem.axhelm_local(u[0], 0.3, 2.0)) < 1e-13
+    assert err(cp.gs(u[1].copy()), sem.gs(u[1])) < 1e-14
+    assert max(err(a, b) for a, b in zip(cp.opgradt(p), sem.opgradt(p))) < 1e-13
+    assert err(cp.opdiv(u), sem.opdiv(u)) < 1e-13
+    assert err(cp.cdabdtp(p), sem.cdabdtp(p)) < 1e-13
+    assert max(err(a, b) for a, b in zip(cp.lns_conv_weak(U, u), sem.lns_conv_weak(U, u))) < 1e-13
+    assert abs(cp.glsc3(u[0], U[0], np.ascontiguousarray(sem.bm1)) - sem.glsc3(u[0], U[0])) < 1e-12 * abs(sem.glsc3(u[0], U[0])) + 1e-12
+    y = u[2].copy()
+    cp.axpby(0.3, u[0], 0.5, y)
+    assert err(y, 0.5 * u[2] + 0.3 * u[0]) < 1e-15
