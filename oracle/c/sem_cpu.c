@@ -10,6 +10,7 @@
 #include <string.h>
 
 int nl_threads(void) { return omp_get_max_threads(); }
+void nl_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 /* out[c][b][a'] = sum_a M[a'][a] in[c][b][a]  (x fastest), M is mo x mi row-major */
 static void apx(const double *M, int mo, int mi, const double *in, double *out, int ny, int nz) {

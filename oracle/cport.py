@@ -69,6 +69,9 @@ class CPort:
     def threads(self):
         return int(self.lib.nl_threads())
 
+    def set_threads(self, n):
+        self.lib.nl_set_threads(int(n))
+
     def gs(self, f):
         self.lib.nl_gs(C.c_long(self.ngroups), self.off.ctypes.data_as(C.POINTER(C.c_long)), self.idx.ctypes.data_as(C.POINTER(C.c_long)), _p(f))
         return f
