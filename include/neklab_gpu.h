@@ -58,6 +58,16 @@ int nlg_ctx_rank(const nlg_ctx *ctx, int *rank, int *nranks);
  * Returns the total number of shared entries, or -1 if `capacity` is too small. */
 int64_t nlg_halo_plan(int rank, int nranks, const int64_t *counts, const int64_t *labels_concat,
                       int64_t *neigh_counts, int64_t *shared_out, int64_t capacity);
+/* The two remaining pure-host steps of that set-up, exported so that the index lists the GPU exchange uses can be
+ * checked on the CPU with emulated ranks (tests/test_cpu_dist.py): the ascending unique labels of the element-boundary
+ * dofs of one rank (its contribution to labels_concat; returns their number, -1 if capacity is too small), and the
+ * lists themselves -- send_idx[e] = local dof packed for entry e of the send buffer (entries ordered neighbour after
+ * neighbour, labels ascending), and per shared label l < *nlab_out the positions rpos[roff[l]:roff[l+1]] of the received
+ * contributions and the local copies cidx[coff[l]:coff[l+1]] that receive their sum.  Returns the number of entries. */
+int64_t nlg_halo_boundary_labels(int n, int dim, int64_t E, const int64_t *glo, int64_t *labels_out, int64_t capacity);
+int64_t nlg_halo_lists(int n, int dim, int64_t E, const int64_t *glo, int rank, int nranks, const int64_t *counts,
+                       const int64_t *labels_concat, int64_t *neigh_counts, int32_t *send_idx, int64_t cap_send,
+                       int32_t *roff, int32_t *rpos, int32_t *coff, int32_t *cidx, int64_t cap_copies, int64_t *nlab_out);
 /* Per-kernel-class timing with HIP events recorded on the launch stream (the reference's counterpart
  * is LightKrylov's timer object, src/neklab_analysis.f90:66-67, :98-101).  Classes: "axhelm", "gs",
  * "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops". */

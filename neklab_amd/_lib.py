@@ -57,6 +57,10 @@ SIGNATURES = {
     "nlg_ctx_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "nlg_ctx_rank": (C.c_int, [vp, c_int_p, c_int_p]),
     "nlg_halo_plan": (C.c_int64, [C.c_int, C.c_int, c_int64_p, c_int64_p, c_int64_p, c_int64_p, C.c_int64]),
+    "nlg_halo_boundary_labels": (C.c_int64, [C.c_int, C.c_int, C.c_int64, c_int64_p, c_int64_p, C.c_int64]),
+    "nlg_halo_lists": (C.c_int64, [C.c_int, C.c_int, C.c_int64, c_int64_p, C.c_int, C.c_int, c_int64_p, c_int64_p, c_int64_p,
+                                   C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.c_int64, c_int64_p]),
     "nlg_prof_enable": (C.c_int, [vp, C.c_int]),
     "nlg_prof_reset": (C.c_int, [vp]),
     "nlg_prof_get": (C.c_int, [vp, C.c_char_p, c_int64_p, c_double_p]),

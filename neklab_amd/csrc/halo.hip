@@ -96,6 +96,88 @@ extern "C" int64_t nlg_halo_plan(int rank, int nranks, const int64_t *counts, co
     return tot;
 }
 
+// Pure host: the sorted unique labels of the element-boundary dofs of one rank (what it contributes to the all-gather of
+// the set-up).  Returns their number, or -1 if `capacity` is too small.
+namespace {
+struct BoundaryLabels {
+    std::vector<int> bidx;       // local boundary dofs sorted by (label, index)
+    std::vector<int64_t> ulab;   // unique labels, ascending
+    std::vector<int> ubeg;       // begin of each label's copies in bidx (+ end sentinel)
+};
+BoundaryLabels boundary_labels(int n, int dim, int64_t E, const int64_t *glo) {
+    BoundaryLabels b;
+    const int np1 = dim == 3 ? n * n * n : n * n;
+    b.bidx.reserve((size_t)(E * np1) / 2);
+    for (int64_t e = 0; e < E; ++e)
+        for (int p = 0; p < np1; ++p) {
+            const int i = p % n, j = (p / n) % n, k = p / (n * n);
+            const bool onb = i == 0 || i == n - 1 || j == 0 || j == n - 1 || (dim == 3 && (k == 0 || k == n - 1));
+            if (onb) b.bidx.push_back((int)(e * np1 + p));
+        }
+    std::sort(b.bidx.begin(), b.bidx.end(), [glo](int a, int c) { return glo[a] < glo[c] || (glo[a] == glo[c] && a < c); });
+    for (size_t q = 0; q < b.bidx.size(); ++q)
+        if (q == 0 || glo[b.bidx[q]] != glo[b.bidx[q - 1]]) {
+            b.ulab.push_back(glo[b.bidx[q]]);
+            b.ubeg.push_back((int)q);
+        }
+    b.ubeg.push_back((int)b.bidx.size());
+    return b;
+}
+struct HaloLists {
+    std::vector<int64_t> ncnt;   // per rank: number of shared labels
+    int64_t tot = 0, nlab = 0;
+    std::vector<int> send_idx, roff{0}, rpos, coff{0}, cidx;
+};
+// index lists of one rank from its boundary labels and the labels of all ranks; false if the plan failed
+bool halo_lists(const BoundaryLabels &b, int rank, int nranks, const int64_t *counts, const int64_t *labels_concat, HaloLists &L) {
+    L.ncnt.assign(nranks, 0);
+    std::vector<int64_t> shared(b.ulab.size() * (size_t)std::max(nranks - 1, 1) + 1);
+    L.tot = nlg_halo_plan(rank, nranks, counts, labels_concat, L.ncnt.data(), shared.data(), (int64_t)shared.size());
+    if (L.tot < 0) return false;
+    L.send_idx.resize((size_t)L.tot);
+    auto find_lab = [&](int64_t lab) { return (int)(std::lower_bound(b.ulab.begin(), b.ulab.end(), lab) - b.ulab.begin()); };
+    std::vector<std::vector<int>> rpos_of(b.ulab.size());   // per unique label: entry positions, ascending neighbour
+    for (int64_t e = 0; e < L.tot; ++e) {
+        const int u = find_lab(shared[e]);
+        L.send_idx[e] = b.bidx[b.ubeg[u]];
+        rpos_of[u].push_back((int)e);
+    }
+    for (size_t u = 0; u < b.ulab.size(); ++u) {
+        if (rpos_of[u].empty()) continue;
+        ++L.nlab;
+        L.rpos.insert(L.rpos.end(), rpos_of[u].begin(), rpos_of[u].end());
+        L.roff.push_back((int)L.rpos.size());
+        for (int q = b.ubeg[u]; q < b.ubeg[u + 1]; ++q) L.cidx.push_back(b.bidx[q]);
+        L.coff.push_back((int)L.cidx.size());
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int64_t nlg_halo_boundary_labels(int n, int dim, int64_t E, const int64_t *glo, int64_t *labels_out, int64_t capacity) {
+    const BoundaryLabels b = boundary_labels(n, dim, E, glo);
+    if ((int64_t)b.ulab.size() > capacity) return -1;
+    std::copy(b.ulab.begin(), b.ulab.end(), labels_out);
+    return (int64_t)b.ulab.size();
+}
+
+extern "C" int64_t nlg_halo_lists(int n, int dim, int64_t E, const int64_t *glo, int rank, int nranks, const int64_t *counts,
+                                  const int64_t *labels_concat, int64_t *neigh_counts, int32_t *send_idx, int64_t cap_send,
+                                  int32_t *roff, int32_t *rpos, int32_t *coff, int32_t *cidx, int64_t cap_copies, int64_t *nlab_out) {
+    const BoundaryLabels b = boundary_labels(n, dim, E, glo);
+    HaloLists L;
+    if (!halo_lists(b, rank, nranks, counts, labels_concat, L)) return -1;
+    if (L.tot > cap_send || (int64_t)L.cidx.size() > cap_copies) return -1;
+    std::copy(L.ncnt.begin(), L.ncnt.end(), neigh_counts);
+    std::copy(L.send_idx.begin(), L.send_idx.end(), send_idx);
+    std::copy(L.roff.begin(), L.roff.end(), roff);
+    std::copy(L.rpos.begin(), L.rpos.end(), rpos);
+    std::copy(L.coff.begin(), L.coff.end(), coff);
+    std::copy(L.cidx.begin(), L.cidx.end(), cidx);
+    *nlab_out = L.nlab;
+    return L.tot;
+}
+
 namespace nlg {
 
 int halo_setup(nlg_mesh *m, const int64_t *glo) {
@@ -106,24 +188,10 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     hipStream_t st = ctx->stream;
     const int nr = ctx->nranks, me = ctx->rank;
     const int n = m->n, dim = m->dim, np1 = m->np1;
-    // ---- local element-boundary labels -> sorted unique, with the list of local copies of each
-    std::vector<int> bidx;
-    bidx.reserve((size_t)m->lvn / 2);
-    for (int64_t e = 0; e < m->E; ++e)
-        for (int p = 0; p < np1; ++p) {
-            const int i = p % n, j = (p / n) % n, k = p / (n * n);
-            const bool onb = i == 0 || i == n - 1 || j == 0 || j == n - 1 || (dim == 3 && (k == 0 || k == n - 1));
-            if (onb) bidx.push_back((int)(e * np1 + p));
-        }
-    std::sort(bidx.begin(), bidx.end(), [glo](int a, int b) { return glo[a] < glo[b] || (glo[a] == glo[b] && a < b); });
-    std::vector<int64_t> ulab;
-    std::vector<int> ubeg;   // begin of each unique label's copies in bidx
-    for (size_t q = 0; q < bidx.size(); ++q)
-        if (q == 0 || glo[bidx[q]] != glo[bidx[q - 1]]) {
-            ulab.push_back(glo[bidx[q]]);
-            ubeg.push_back((int)q);
-        }
-    ubeg.push_back((int)bidx.size());
+    // ---- local element-boundary labels -> sorted unique, with the list of local copies of each (pure host code,
+    // shared with the CPU test of the list construction)
+    const BoundaryLabels bl = boundary_labels(n, dim, m->E, glo);
+    const std::vector<int64_t> &ulab = bl.ulab;
     // ---- gather counts and labels of all ranks (device buffers, RCCL)
     int64_t *d_cnt = nullptr;
     NLG_HIP(hipMalloc(&d_cnt, sizeof(int64_t) * (nr + 1)));
@@ -145,10 +213,11 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     hipFree(d_cnt);
     hipFree(d_lab);
     for (int q = 0; q < nr; ++q) concat.insert(concat.end(), padded.begin() + (size_t)q * maxc, padded.begin() + (size_t)q * maxc + counts[q]);
-    // ---- plan
-    std::vector<int64_t> ncnt(nr), shared((size_t)mycnt * std::max(nr - 1, 1) + 1);
-    const int64_t tot = nlg_halo_plan(me, nr, counts.data(), concat.data(), ncnt.data(), shared.data(), (int64_t)shared.size());
-    NLG_CHECK(tot >= 0, "halo_setup: plan capacity exceeded");
+    // ---- plan + index lists
+    HaloLists L;
+    NLG_CHECK(halo_lists(bl, me, nr, counts.data(), concat.data(), L), "halo_setup: plan capacity exceeded");
+    const std::vector<int64_t> &ncnt = L.ncnt;
+    const int64_t tot = L.tot;
     h.neigh.clear();
     h.noff.clear();
     h.ncnt.clear();
@@ -162,26 +231,8 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
         }
     h.ntot = tot;
     if (tot == 0) return 0;
-    // ---- index lists
-    std::vector<int> send_idx((size_t)tot);
-    // label -> position in ulab
-    auto find_lab = [&](int64_t lab) { return (int)(std::lower_bound(ulab.begin(), ulab.end(), lab) - ulab.begin()); };
-    std::vector<std::vector<int>> rpos_of(ulab.size());   // per unique label: entry positions, ascending neighbour
-    for (int64_t e = 0; e < tot; ++e) {
-        const int u = find_lab(shared[e]);
-        send_idx[e] = bidx[ubeg[u]];
-        rpos_of[u].push_back((int)e);
-    }
-    std::vector<int> roff{0}, rpos, coff{0}, cidx;
-    int64_t nlab = 0;
-    for (size_t u = 0; u < ulab.size(); ++u) {
-        if (rpos_of[u].empty()) continue;
-        ++nlab;
-        rpos.insert(rpos.end(), rpos_of[u].begin(), rpos_of[u].end());
-        roff.push_back((int)rpos.size());
-        for (int q = ubeg[u]; q < ubeg[u + 1]; ++q) cidx.push_back(bidx[q]);
-        coff.push_back((int)cidx.size());
-    }
+    const std::vector<int> &send_idx = L.send_idx, &roff = L.roff, &rpos = L.rpos, &coff = L.coff, &cidx = L.cidx;
+    const int64_t nlab = L.nlab;
     h.nlab = nlab;
     auto up = [&](const std::vector<int> &v, int **d) -> int {
         NLG_HIP(hipMalloc(d, sizeof(int) * std::max<size_t>(v.size(), 1)));
