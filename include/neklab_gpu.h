@@ -206,6 +206,18 @@ int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
 int nlg_linop_nonlinear_map(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
 int nlg_linop_set_baseflow(nlg_linop *op, const nlg_vec *baseflow);
 int nlg_linop_set_tolerances(nlg_linop *op, double vtol, double ptol);
+/* Wavenumber-projected propagator (exptA_proj_linop, src/linops/neklab_linops.f90:130-152,
+ * exponential_propagator_proj.f90): after this call matvec / rmatvec project the initial condition and the final state
+ * onto the cos(alpha x_idir) / sin(alpha x_idir) content along the homogeneous direction idir (1-based):
+ * u <- cv <2 u cv> + sv <2 u sv> with the bm1-weighted average <.> over every line of points along that direction
+ * (proj_alpha, :135-173).  line_label[i] identifies the line of local velocity dof i (what Nek5000's gtpp_gs_setup
+ * derives from nelx, nely, nelz).  line_label2 / x2 (both or neither): the same for the pressure mesh, with the
+ * coordinate along idir of every pressure point -- the pressure is then projected as well (bm2 weights); the reference
+ * projects the velocity only, see DESIGN.md for why that is not enough behind an inner product that ignores the
+ * pressure.  Single rank.  nlg_linop_project applies the projection to the state held by a vector. */
+int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_t *line_label, const int64_t *line_label2,
+                             const double *x2);
+int nlg_linop_project(nlg_linop *op, nlg_vec *v);
 /* %tau read/written by the driver (src/neklab_analysis.f90:84; apply_exptA neklab_linops.f90:252) */
 int nlg_linop_set_tau(nlg_linop *op, double tau);
 int nlg_linop_get_info(const nlg_linop *op, double *tau, double *dt, int *nsteps, double *cfl);

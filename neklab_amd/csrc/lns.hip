@@ -358,6 +358,54 @@ __global__ __launch_bounds__(NT) void k_proj_store(int64_t n, const double *__re
     }
 }
 
+// ---- wavenumber projection of the projected propagator (proj_alpha, src/linops/exponential_propagator_proj.f90:135-173):
+// every velocity component keeps only its cos(alpha x) / sin(alpha x) content along the homogeneous direction,
+//   u <- cv <2 u cv> + sv <2 u sv>,   <f> = sum_line bm1 f / sum_line bm1 over the points of a line along that direction
+// (Nek5000's planar_avg over the gtpp gather-scatter handle).  One wave per line.
+template <int NF>
+__global__ __launch_bounds__(NT) void k_proj_alpha(int64_t nlines, const int *__restrict__ off, const int *__restrict__ idx,
+                                                   const double *__restrict__ bm1, const double *__restrict__ cv,
+                                                   const double *__restrict__ sv, const double *__restrict__ inv_den, F3 u) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (g >= nlines) return;
+    const int b = off[g], e = off[g + 1];
+    double ac[NF], as[NF];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) ac[c] = as[c] = 0.0;
+    for (int q = b + lane; q < e; q += 64) {
+        const int i = idx[q];
+        const double w = 2.0 * bm1[i], c0 = cv[i], s0 = sv[i];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double v = u.p[c][i];
+            ac[c] += w * v * c0;
+            as[c] += w * v * s0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NF; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ac[c] += __shfl_xor(ac[c], o, 64);
+            as[c] += __shfl_xor(as[c], o, 64);
+        }
+    }
+    const double id = inv_den[g];
+    for (int q = b + lane; q < e; q += 64) {
+        const int i = idx[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) u.p[c][i] = cv[i] * (ac[c] * id) + sv[i] * (as[c] * id);
+    }
+}
+__global__ __launch_bounds__(NT) void k_cossin(int64_t n, const double *__restrict__ x, double alpha, double *__restrict__ cv,
+                                               double *__restrict__ sv) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        cv[i] = cos(alpha * x[i]);
+        sv[i] = sin(alpha * x[i]);
+    }
+}
+
 // generic pointwise helpers
 template <int NF>
 __global__ __launch_bounds__(NT) void k_colmul_gated(const double *s, F3 w, CF3 wt, int64_t n) {
@@ -466,6 +514,10 @@ struct nlg_linop {
     double *d_part = nullptr;  // first-stage sums written by opdiv ([2][E]) and by the FDM kernel ([2][E/4])
     double *h_s = nullptr;     // pinned
     int istep = 0, adjoint = 0;
+    // wavenumber projection (exptA_proj_linop): lines along the homogeneous direction, cos / sin of alpha x, 1 / sum bm1
+    int proj_nlines = 0, proj_nlines2 = 0;     // velocity-mesh lines; pressure-mesh lines (0 = pressure not projected)
+    int *proj_off = nullptr, *proj_idx = nullptr, *proj_off2 = nullptr, *proj_idx2 = nullptr;
+    double *proj_cv = nullptr, *proj_sv = nullptr, *proj_iden = nullptr, *proj_cv2 = nullptr, *proj_sv2 = nullptr, *proj_iden2 = nullptr;
     int nonlinear = 0;         // 1: full Navier-Stokes step, N(u) = (u.grad)u = half of the linearised term about U = u
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
@@ -873,6 +925,34 @@ int store_state(nlg_linop *op, nlg_vec *v, int irst) {
     return 0;
 }
 
+// no-op unless nlg_linop_set_projection has been called
+int project_alpha(nlg_linop *op, int slot = 0) {
+    if (op->proj_nlines == 0) return 0;
+    nlg_mesh *m = op->mesh;
+    const unsigned grid = (unsigned)((op->proj_nlines + NT / 64 - 1) / (NT / 64));
+    F3 u = f3(op->ubuf[slot], m->dim);
+    if (m->dim == 3)
+        hipLaunchKernelGGL(k_proj_alpha<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
+                           (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
+                           (const double *)op->proj_iden, u);
+    else
+        hipLaunchKernelGGL(k_proj_alpha<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
+                           (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
+                           (const double *)op->proj_iden, u);
+    if (op->proj_nlines2 > 0 && slot == 0) {
+        // the pressure is part of the state the integrator starts from (lagged pressure of the correction scheme) but not
+        // of the inner product: left unprojected it is a subspace the Arnoldi norm cannot see (observed: a spurious
+        // |mu| = 1.41 for plane Poiseuille flow at alpha = 2 instead of 0.945)
+        const unsigned grid2 = (unsigned)((op->proj_nlines2 + NT / 64 - 1) / (NT / 64));
+        F3 pp = {{op->p, nullptr, nullptr}};
+        hipLaunchKernelGGL(k_proj_alpha<1>, dim3(grid2), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines2, (const int *)op->proj_off2,
+                           (const int *)op->proj_idx2, (const double *)m->d_bm2, (const double *)op->proj_cv2, (const double *)op->proj_sv2,
+                           (const double *)op->proj_iden2, pp);
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     NLG_CHECK(op && vin && vout, "exptA matvec: NULL argument");
     NLG_CHECK(op->inited, "exptA matvec: nlg_linop_init has not been called (reference: exptA%%init(), 1cyl.usr:20)");
@@ -895,10 +975,22 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     op->adjoint = adjoint;
     op->nproj = 0;   // the projection space belongs to one matvec: the result must not depend on earlier calls
     NLG_TRY(load_state(op, vin, 0));
+    NLG_TRY(project_alpha(op));                       // exptA_proj_matvec: initial condition, exponential_propagator_proj.f90:51
     for (int istep = 1; istep <= op->nsteps; ++istep) {
         NLG_TRY(advance(op));
-        if (istep <= nrst && vin->nrst > 0) NLG_TRY(load_state(op, vin, istep));   // get_rst, :129-142
+        if (istep <= nrst && vin->nrst > 0) {
+            NLG_TRY(load_state(op, vin, istep));   // get_rst, :129-142
+            NLG_TRY(project_alpha(op));            // (projected operator: replayed states are projected as well, see below)
+        }
     }
+    // ... and the final state, :66.  The reference projects the initial condition and the final state only.  Here the
+    // replayed history states and the lagged states of the multistep scheme are projected too: otherwise the extended map
+    // (state, history) that the Arnoldi process iterates has a spurious unstable mode -- observed for plane Poiseuille flow
+    // at alpha = 2, Re = 7500: a "converged" |mu| = 1.41 in front of the Orr-Sommerfeld pair |mu| = 0.9448; with the
+    // consistent projection the leading pair is 0.94454.
+    NLG_TRY(project_alpha(op));
+    NLG_TRY(project_alpha(op, 1));
+    NLG_TRY(project_alpha(op, 2));
     // vec_out is intent(out): default-initialised (history cleared, nrst = 0), then filled
     NLG_TRY(nlg_vec_zero(vout));
     NLG_TRY(store_state(op, vout, 0));
@@ -1007,6 +1099,16 @@ int nlg_linop_destroy(nlg_linop *op) {
     fr(op->prX);
     fr(op->prB);
     fr(op->d_pc);
+    fr(op->proj_cv);
+    fr(op->proj_sv);
+    fr(op->proj_iden);
+    fr(op->proj_cv2);
+    fr(op->proj_sv2);
+    fr(op->proj_iden2);
+    if (op->proj_off) hipFree(op->proj_off);
+    if (op->proj_idx) hipFree(op->proj_idx);
+    if (op->proj_off2) hipFree(op->proj_off2);
+    if (op->proj_idx2) hipFree(op->proj_idx2);
     fr(op->nwv);
     fr(op->nwp);
     fr(op->d_s);
@@ -1113,6 +1215,79 @@ int nlg_linop_set_baseflow(nlg_linop *op, const nlg_vec *baseflow) {
     NLG_CHECK(op && baseflow && baseflow->mesh == op->mesh, "nlg_linop_set_baseflow: bad argument");
     NLG_TRY(nlg_vec_copy(op->baseflow, baseflow));
     return nlg_linop_init(op);
+}
+
+int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_t *line_label, const int64_t *line_label2,
+                             const double *x2) {
+    NLG_CHECK(op && line_label, "nlg_linop_set_projection: NULL argument");
+    nlg_mesh *m = op->mesh;
+    NLG_CHECK(idir >= 1 && idir <= m->dim, "nlg_linop_set_projection: idir %d out of range", idir);
+    NLG_CHECK(!m->ctx->comm, "nlg_linop_set_projection: lines across ranks are not supported (single rank only)");
+    NLG_CHECK(op->inited, "nlg_linop_set_projection: call init first");
+    NLG_CHECK((line_label2 == nullptr) == (x2 == nullptr), "nlg_linop_set_projection: pressure-mesh labels and coordinates go together");
+    hipStream_t st = m->ctx->stream;
+    // one set of lists per mesh: lines = groups of local dofs with the same label, ordered by label then by index
+    auto build = [&](int64_t n, const int64_t *lab, const double *d_w, const double *d_x, const double *h_x, int *nl, int **d_off, int **d_idx,
+                     double **d_cv, double **d_sv, double **d_iden) -> int {
+        std::vector<int> order((size_t)n);
+        for (int64_t i = 0; i < n; ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [lab](int a, int b) { return lab[a] < lab[b] || (lab[a] == lab[b] && a < b); });
+        std::vector<int> off{0};
+        for (int64_t q = 1; q <= n; ++q)
+            if (q == n || lab[order[q]] != lab[order[q - 1]]) off.push_back((int)q);
+        const int nlines = (int)off.size() - 1;
+        std::vector<double> wt((size_t)n), iden((size_t)nlines);
+        NLG_HIP(hipMemcpyAsync(wt.data(), d_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        for (int g = 0; g < nlines; ++g) {
+            double sum = 0.0;
+            for (int q = off[g]; q < off[g + 1]; ++q) sum += wt[order[q]];
+            NLG_CHECK(sum > 0.0, "nlg_linop_set_projection: empty line");
+            iden[g] = 1.0 / sum;
+        }
+        if (*d_off) hipFree(*d_off);
+        if (*d_idx) hipFree(*d_idx);
+        if (*d_cv) hipFree(*d_cv);
+        if (*d_sv) hipFree(*d_sv);
+        if (*d_iden) hipFree(*d_iden);
+        NLG_HIP(hipMalloc(d_off, sizeof(int) * off.size()));
+        NLG_HIP(hipMalloc(d_idx, sizeof(int) * (size_t)n));
+        NLG_HIP(hipMalloc(d_iden, sizeof(double) * (size_t)nlines));
+        NLG_HIP(hipMalloc(d_cv, sizeof(double) * (size_t)n));
+        NLG_HIP(hipMalloc(d_sv, sizeof(double) * (size_t)n));
+        NLG_HIP(hipMemcpy(*d_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
+        NLG_HIP(hipMemcpy(*d_idx, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+        NLG_HIP(hipMemcpy(*d_iden, iden.data(), sizeof(double) * (size_t)nlines, hipMemcpyHostToDevice));
+        const double *xs = d_x;
+        double *tmp = nullptr;
+        if (!xs) {   // coordinates given on the host (pressure mesh)
+            NLG_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)n));
+            NLG_HIP(hipMemcpy(tmp, h_x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+            xs = tmp;
+        }
+        hipLaunchKernelGGL(k_cossin, dim3(grid_for(n)), dim3(NT), 0, st, n, xs, alpha, *d_cv, *d_sv);
+        NLG_HIP(hipGetLastError());
+        NLG_HIP(hipStreamSynchronize(st));
+        if (tmp) hipFree(tmp);
+        *nl = nlines;
+        return 0;
+    };
+    NLG_TRY(build(m->lvn, line_label, m->d_bm1, m->d_x[idir - 1], nullptr, &op->proj_nlines, &op->proj_off, &op->proj_idx, &op->proj_cv,
+                  &op->proj_sv, &op->proj_iden));
+    op->proj_nlines2 = 0;
+    if (line_label2)
+        NLG_TRY(build(m->lpn, line_label2, m->d_bm2, nullptr, x2, &op->proj_nlines2, &op->proj_off2, &op->proj_idx2, &op->proj_cv2,
+                      &op->proj_sv2, &op->proj_iden2));
+    return 0;
+}
+
+int nlg_linop_project(nlg_linop *op, nlg_vec *v) {
+    NLG_CHECK(op && v && v->mesh == op->mesh, "nlg_linop_project: bad argument");
+    NLG_CHECK(op->proj_nlines > 0, "nlg_linop_project: no projection set (nlg_linop_set_projection)");
+    NLG_TRY(load_state(op, v, 0));
+    NLG_TRY(project_alpha(op));
+    NLG_TRY(store_state(op, v, 0));
+    return 0;
 }
 
 int nlg_linop_set_tolerances(nlg_linop *op, double vtol, double ptol) {

@@ -332,6 +332,76 @@ class exptA_linop:
             self.h = None
 
 
+def line_labels(mesh: "Mesh", idir: int, decimals: int = 9) -> np.ndarray:
+    """One label per line of velocity points along direction idir (1-based): points with the same remaining coordinates
+    (rounded) share it.  What Nek5000's gtpp_gs_setup derives from (nelx, nely, nelz) for extruded box meshes
+    (init_exptA_proj, src/linops/exponential_propagator_proj.f90:18-22); needs a mesh that is not deformed along idir."""
+    hm = mesh.host
+    coords = [hm.x, hm.y] + ([hm.z] if hm.dim == 3 else [])
+    others = [np.round(np.asarray(c).ravel(), decimals) for d, c in enumerate(coords) if d != idir - 1]
+    key = np.stack(others, axis=1)
+    _, lab = np.unique(key, axis=0, return_inverse=True)
+    return np.ascontiguousarray(lab.ravel(), dtype=np.int64)
+
+
+def _gll_to_gl_matrix(n: int) -> np.ndarray:
+    """(n-2 x n) Lagrange interpolation from the GLL velocity points to the Gauss-Legendre pressure points."""
+    from .mesh import gll_points
+    z1 = gll_points(n)
+    z2 = np.polynomial.legendre.leggauss(n - 2)[0]
+    M = np.ones((n - 2, n))
+    for k in range(n):
+        for l in range(n):
+            if l != k:
+                M[:, k] *= (z2 - z1[l]) / (z1[k] - z1[l])
+    return M
+
+
+def pressure_mesh_coords(mesh: "Mesh"):
+    """Coordinates of the pressure (GL) points: the isoparametric map evaluated there."""
+    hm = mesh.host
+    n, dim, E = hm.n, hm.dim, hm.E
+    M = _gll_to_gl_matrix(n)
+    out = []
+    for c in [hm.x, hm.y] + ([hm.z] if dim == 3 else []):
+        a = np.asarray(c).reshape((E,) + (n,) * dim)
+        for ax in range(1, dim + 1):
+            a = np.moveaxis(np.tensordot(M, a, axes=([1], [ax])), 0, ax)
+        out.append(a.reshape(-1))
+    return out
+
+
+def line_labels_pressure(mesh: "Mesh", idir: int, decimals: int = 9):
+    """(labels, coordinate along idir) of the pressure points, see line_labels."""
+    X2 = pressure_mesh_coords(mesh)
+    key = np.stack([np.round(c, decimals) for d, c in enumerate(X2) if d != idir - 1], axis=1)
+    _, lab = np.unique(key, axis=0, return_inverse=True)
+    return np.ascontiguousarray(lab.ravel(), dtype=np.int64), np.ascontiguousarray(X2[idir - 1], dtype=np.float64)
+
+
+class exptA_proj_linop(exptA_linop):
+    """reference: exptA_proj_linop(tau=, baseflow=, alpha=) (src/linops/neklab_linops.f90:130-152; constructed with
+    keywords at examples/poiseuille/stability/direct_alpha_1/poiseuille.usr:24): the propagator restricted to the
+    streamwise wavenumber alpha by projecting the initial condition and the final state."""
+
+    def __init__(self, tau: float, baseflow: nek_dvector, alpha: float, idir: int = 1, project_pressure: bool = True, **cfg):
+        super().__init__(tau, baseflow, **cfg)
+        self.alpha, self.idir, self.project_pressure = float(alpha), int(idir), bool(project_pressure)
+
+    def init(self):
+        super().init()
+        lab = line_labels(self.mesh, self.idir)
+        if self.project_pressure:
+            lab2, x2 = line_labels_pressure(self.mesh, self.idir)
+            check(self.lib.nlg_linop_set_projection(self.h, self.alpha, self.idir, lab.ctypes.data_as(_lib.c_int64_p),
+                                                    lab2.ctypes.data_as(_lib.c_int64_p), x2.ctypes.data_as(_lib.c_double_p)))
+        else:
+            check(self.lib.nlg_linop_set_projection(self.h, self.alpha, self.idir, lab.ctypes.data_as(_lib.c_int64_p), None, None))
+
+    def proj(self, vec: nek_dvector):
+        check(self.lib.nlg_linop_project(self.h, vec.h))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Newton-Krylov fixed-point solver (SURVEY.md 8f row 3).  Reference: nek_system / nek_jacobian
 # (src/systems/neklab_systems.f90, fixed_point.f90:4-96) driven by LightKrylov's `newton` + `gmres_rdp`

@@ -233,12 +233,22 @@ class ExptA:
         nrst = self.cfg.torder - 1
         vec_out = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)   # intent(out): default-initialised
         self._reset_state(vec_in, adjoint)
+        if getattr(self, "proj_lab", None) is not None:
+            self.u = self.proj(self.u)                               # exptA_proj_matvec, exponential_propagator_proj.f90:51
+            self.p = self.proj_pressure(self.p)
         for istep in range(1, self.nsteps + 1):
             self.advance()
             if istep <= nrst and vec_in.has_rst_fields():          # get_rst, :129-142
                 tmp = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)
                 vec_in.get_rst(tmp, istep)
                 self._load(tmp)
+                if getattr(self, "proj_lab", None) is not None:      # replayed states are projected too (csrc/lns.hip do_matvec)
+                    self.u = self.proj(self.u)
+                    self.p = self.proj_pressure(self.p)
+        if getattr(self, "proj_lab", None) is not None:
+            self.u = self.proj(self.u)                               # :66
+            self.p = self.proj_pressure(self.p)
+            self.ulag = [self.proj(a) for a in self.ulag]            # ... and the lagged states of the multistep scheme
         self._store(vec_out)
         # compute_rst, :109-127
         for irst in range(1, nrst + 1):
@@ -250,6 +260,40 @@ class ExptA:
 
     def rmatvec(self, vec_in):
         return self.matvec(vec_in, adjoint=True)
+
+    # ---------------- reference: exponential_propagator_proj.f90:18-28, :135-173 ----------------
+    def set_projection(self, alpha, idir, line_label, line_label2=None, x2=None):
+        """Wavenumber projection of the projected propagator: lines of points along direction idir (1-based); with
+        line_label2 / x2 the pressure is projected as well (lines and coordinate along idir of the pressure points)."""
+        s = self.sem
+        self.proj_lab = np.asarray(line_label).reshape(-1)
+        self.proj_cv = np.cos(alpha * s.X[idir - 1])
+        self.proj_sv = np.sin(alpha * s.X[idir - 1])
+        self.proj_den = np.bincount(self.proj_lab, weights=s.bm1.ravel())
+        self.proj_lab2 = None
+        if line_label2 is not None:
+            self.proj_lab2 = np.asarray(line_label2).reshape(-1)
+            self.proj_cv2 = np.cos(alpha * np.asarray(x2).reshape(s.shape2))
+            self.proj_sv2 = np.sin(alpha * np.asarray(x2).reshape(s.shape2))
+            self.proj_den2 = np.bincount(self.proj_lab2, weights=s.bm2.ravel())
+
+    def proj_pressure(self, p):
+        if getattr(self, "proj_lab2", None) is None:
+            return p
+        s = self.sem
+        c = np.bincount(self.proj_lab2, weights=(2.0 * p * self.proj_cv2 * s.bm2).ravel()) / self.proj_den2
+        d = np.bincount(self.proj_lab2, weights=(2.0 * p * self.proj_sv2 * s.bm2).ravel()) / self.proj_den2
+        return self.proj_cv2 * c[self.proj_lab2].reshape(s.shape2) + self.proj_sv2 * d[self.proj_lab2].reshape(s.shape2)
+
+    def proj(self, u):
+        """u <- cv <2 u cv> + sv <2 u sv>, <.> the bm1-weighted average along the line (proj_alpha)."""
+        s = self.sem
+        out = []
+        for a in u:
+            c = np.bincount(self.proj_lab, weights=(2.0 * a * self.proj_cv * s.bm1).ravel()) / self.proj_den
+            d = np.bincount(self.proj_lab, weights=(2.0 * a * self.proj_sv * s.bm1).ravel()) / self.proj_den
+            out.append(self.proj_cv * c[self.proj_lab].reshape(s.shape1) + self.proj_sv * d[self.proj_lab].reshape(s.shape1))
+        return out
 
     # ---------------- reference: src/systems/fixed_point.f90:4-38 ----------------
     def set_baseflow(self, baseflow):

@@ -1,0 +1,99 @@
+"""Wavenumber-projected propagator (exptA_proj_linop, exponential_propagator_proj.f90): projection and
+projected matvec against the oracle twins, and the Orr-Sommerfeld eigenvalue of a wavenumber that is NOT the leading
+one of the box."""
+import numpy as np
+import pytest
+
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+from oracle.lns import ExptA, LNSConfig
+from oracle.orr_sommerfeld import orr_sommerfeld
+from oracle.sem import SEM
+from oracle.vectors import NekDVector
+
+pytestmark = pytest.mark.gpu
+
+
+def channel(ctx, dim, nel, n):
+    if dim == 2:
+        hm = box_mesh(nel, n, lengths=(2 * np.pi, 2.0), periodic=(True, False), deform=0.0, origin=(0.0, -1.0))
+    else:
+        hm = box_mesh(nel, n, lengths=(2 * np.pi, 2.0, 1.0), periodic=(True, False, True), deform=0.0, origin=(0.0, -1.0, 0.0))
+    return hm, SEM(hm), host.Mesh(ctx, hm)
+
+
+@pytest.mark.parametrize("dim,nel", [(2, (4, 3)), (3, (3, 2, 2))])
+def test_projection_and_projected_matvec_match_oracle(gpu_ctx, dim, nel):
+    hm, sem, gm = channel(gpu_ctx, dim, nel, 6)
+    U = [1.0 - sem.X[1] ** 2] + [np.zeros(sem.shape1) for _ in range(dim - 1)]
+    gb = host.nek_dvector(gm)
+    gb.set_field(0, U[0])
+    alpha, tau, re = 2.0, 0.1, 200.0
+    kw = dict(re=re, torder=3, tau=tau, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    oA = ExptA(sem, U, LNSConfig(**kw))
+    gA = host.exptA_proj_linop(tau, gb, alpha, idir=1, **{k: v for k, v in kw.items() if k != "tau"})
+    gA.init()
+    lab = host.line_labels(gm, 1)
+    nlines = 1
+    for d in range(1, dim):
+        nlines *= hm.n * nel[d] - (nel[d] - 1)                     # distinct coordinates in the other directions
+    assert lab.max() + 1 == nlines
+    lab2, x2 = host.line_labels_pressure(gm, 1)
+    assert np.max(np.abs(x2.reshape(sem.shape2) - sem.to_mesh2(sem.X[0]))) < 1e-13
+    oA.set_projection(alpha, 1, lab, lab2, x2)
+    rng = np.random.default_rng(0)
+    ov, gv = NekDVector(sem), host.nek_dvector(gm)
+    for i in range(dim):
+        ov.v[i][...] = sem.mask[i] * sem.dsavg(rng.standard_normal(sem.shape1))
+        gv.set_field(i, ov.v[i])
+    # projection itself
+    pg = gv.copy()
+    gA.proj(pg)
+    po = oA.proj(ov.v)
+    sc = max(np.abs(a).max() for a in po)
+    for i in range(dim):
+        assert np.max(np.abs(pg.get_field(i).reshape(sem.shape1) - po[i])) < 1e-13 * sc
+    pg2 = pg.copy()
+    gA.proj(pg2)                                                      # idempotent up to the quadrature of cos^2 on GLL points
+    for i in range(dim):
+        assert np.max(np.abs(pg2.get_field(i) - pg.get_field(i))) < 1e-3 * sc     # 3e-5 on this coarse mesh
+    # a pure wavenumber-alpha field passes, another wavenumber is removed
+    keep, kill = host.nek_dvector(gm), host.nek_dvector(gm)
+    keep.set_field(0, np.cos(alpha * sem.X[0] + 0.3) * (1 - sem.X[1] ** 2))
+    kill.set_field(0, np.cos((alpha + 1) * sem.X[0]) * (1 - sem.X[1] ** 2))
+    k0 = keep.get_field(0).copy()
+    gA.proj(keep)
+    gA.proj(kill)
+    assert np.max(np.abs(keep.get_field(0) - k0)) < 1e-3 and np.max(np.abs(kill.get_field(0))) < 1e-3
+    # projected matvec
+    gout = host.nek_dvector(gm)
+    gA.matvec(gv, gout)
+    oout = oA.matvec(ov)
+    sc = max(np.abs(a).max() for a in oout.v)
+    for i in range(dim):
+        assert np.max(np.abs(gout.get_field(i).reshape(sem.shape1) - oout.v[i])) < 1e-9 * sc
+    assert np.max(np.abs(gout.get_field(host.PR).reshape(sem.shape2) - oout.pr)) < 1e-7 * max(np.abs(oout.pr).max(), 1e-30)
+
+
+def test_poiseuille_alpha2_orr_sommerfeld(gpu_ctx, tmp_path):
+    """In the 2 pi box the unprojected propagator is led by alpha = 1 (|mu| = 1.0022, tests/test_gpu_known_answer.py); the
+    projected one must return the leading alpha = 2 mode instead: c = 0.97111322 - 0.02840471 i from the Orr-Sommerfeld
+    solver (oracle/orr_sommerfeld.py, which reproduces Orszag's Re = 10^4 value to 8 digits), mu = exp(-2 i c)."""
+    c = orr_sommerfeld(7500.0, 2.0)[0]
+    assert abs(orr_sommerfeld(10000.0, 1.0)[0] - (0.23752649 + 0.00373967j)) < 1e-8
+    mu_os = np.exp(-2j * c)
+    hm, sem, gm = channel(gpu_ctx, 2, (10, 12), 8)
+    bf = host.nek_dvector(gm)
+    bf.set_field(host.VX, 1.0 - hm.y ** 2)
+    A = host.exptA_proj_linop(1.0, bf, 2.0, idir=1, re=7500.0, torder=3, vtol=1e-11, ptol=1e-10, maxit_p=4000)
+    A.init()
+    eigvals, residuals, eigvecs, mu, nmv = host.linear_stability_analysis_fixed_point(
+        A, 100, 2, tol=1e-6, outdir=str(tmp_path), seed=1)
+    m = mu[0] if mu[0].imag < 0 else np.conj(mu[0])
+    # two Orr-Sommerfeld modes 1.4e-4 apart lead at alpha = 2 (c = 0.97111322 - 0.02840471 i, 0.97115623 - 0.02848835 i):
+    # the Krylov space is exhausted (everything else has decayed below the solver tolerances) before the pair separates
+    # to 1e-6, so the residual bar is the one reached
+    assert residuals[0] < 2e-4
+    assert abs(abs(m) - abs(mu_os)) < 5e-4 and abs(m - mu_os) < 1e-3, (m, mu_os)      # measured 2.4e-4 / 2.5e-4
+    assert abs(m) < 0.96                                              # the alpha = 1 mode (|mu| = 1.0022) is projected out
+    assert all(abs(x) < 0.96 for x in mu)                             # and no spurious mode of the extended (state, history) map
