@@ -218,6 +218,14 @@ int nlg_linop_set_tolerances(nlg_linop *op, double vtol, double ptol);
 int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_t *line_label, const int64_t *line_label2,
                              const double *x2);
 int nlg_linop_project(nlg_linop *op, nlg_vec *v);
+/* Resolvent operator by time stepping (resolvent_linop, src/linops/resolvent.f90): the building
+ * block of evaluate_rhs (:80-111) and evaluate_imaginary_part (:133-166): vec_out = state after the nsteps of one
+ * application started from `ic` (NULL: rest, zero pressure) under the body force Re[(f_re + i f_im) exp(i s omega t)]
+ * (velocity fields of f_re / f_im; f_im may be NULL), s = +1 direct, -1 adjoint; the force enters the explicit term and
+ * is evaluated at the time level each step starts from.  The driver (real part through GMRES on I - exp(tau L), imaginary
+ * part from a quarter period) lives on the host: neklab_amd/host.py resolvent_linop. */
+int nlg_linop_integrate_forced(nlg_linop *op, const nlg_vec *ic, const nlg_vec *f_re, const nlg_vec *f_im, double omega, int adjoint,
+                               nlg_vec *vec_out);
 /* %tau read/written by the driver (src/neklab_analysis.f90:84; apply_exptA neklab_linops.f90:252) */
 int nlg_linop_set_tau(nlg_linop *op, double tau);
 int nlg_linop_get_info(const nlg_linop *op, double *tau, double *dt, int *nsteps, double *cfl);

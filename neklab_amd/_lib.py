@@ -103,6 +103,7 @@ SIGNATURES = {
     "nlg_linop_set_tolerances": (C.c_int, [vp, C.c_double, C.c_double]),
     "nlg_linop_set_projection": (C.c_int, [vp, C.c_double, C.c_int, c_int64_p, c_int64_p, c_double_p]),
     "nlg_linop_project": (C.c_int, [vp, vp]),
+    "nlg_linop_integrate_forced": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_int, vp]),
     "nlg_linop_matvec": (C.c_int, [vp, vp, vp]),
     "nlg_linop_rmatvec": (C.c_int, [vp, vp, vp]),
     "nlg_linop_set_tau": (C.c_int, [vp, C.c_double]),

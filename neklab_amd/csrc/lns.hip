@@ -406,6 +406,16 @@ __global__ __launch_bounds__(NT) void k_cossin(int64_t n, const double *__restri
     }
 }
 
+// F -= bm1 (cr f_re + ci f_im): a body force in the explicit term (the stored F is +N, the right-hand side takes -EXT(F))
+template <int NF>
+__global__ __launch_bounds__(NT) void k_add_force(int64_t n, F3 F, const double *__restrict__ bm1, CF3 fre, CF3 fim, double cr, double ci) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double b = bm1[i];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) F.p[c][i] -= b * (cr * fre.p[c][i] + (fim.p[c] ? ci * fim.p[c][i] : 0.0));
+    }
+}
+
 // generic pointwise helpers
 template <int NF>
 __global__ __launch_bounds__(NT) void k_colmul_gated(const double *s, F3 w, CF3 wt, int64_t n) {
@@ -518,6 +528,9 @@ struct nlg_linop {
     int proj_nlines = 0, proj_nlines2 = 0;     // velocity-mesh lines; pressure-mesh lines (0 = pressure not projected)
     int *proj_off = nullptr, *proj_idx = nullptr, *proj_off2 = nullptr, *proj_idx2 = nullptr;
     double *proj_cv = nullptr, *proj_sv = nullptr, *proj_iden = nullptr, *proj_cv2 = nullptr, *proj_sv2 = nullptr, *proj_iden2 = nullptr;
+    // time-harmonic body force Re(f exp(i s omega t)) of the resolvent integrations (null = none)
+    const nlg_vec *force_re = nullptr, *force_im = nullptr;
+    double force_omega = 0.0, force_sign = 1.0;
     int nonlinear = 0;         // 1: full Navier-Stokes step, N(u) = (u.grad)u = half of the linearised term about U = u
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
@@ -839,6 +852,16 @@ int advance(nlg_linop *op) {
     double **Fnew = op->fbuf[2];
     if (op->nonlinear) NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));   // the "base flow" is the current state
     NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
+    if (op->force_re) {
+        // forcing of this step: evaluated at the time level the step starts from, (istep - 1) dt, like the explicit terms
+        // (resolvent.f90:97-103: alpha = exp(sign i omega time) before nek_advance)
+        const double ph = op->force_sign * op->force_omega * (op->istep - 1) * dt;
+        CF3 fr = {{op->force_re->vel(0), op->force_re->vel(1), dim == 3 ? op->force_re->vel(2) : nullptr}};
+        CF3 fi = {{nullptr, nullptr, nullptr}};
+        if (op->force_im) fi = CF3{{op->force_im->vel(0), op->force_im->vel(1), dim == 3 ? op->force_im->vel(2) : nullptr}};
+        launch_nf(dim, k_add_force<1>, k_add_force<2>, k_add_force<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(Fnew, dim),
+                  (const double *)m->d_bm1, fr, fi, std::cos(ph), -std::sin(ph));
+    }
     {
         double *t0 = op->fbuf[2][0], *t1 = op->fbuf[2][1], *t2 = op->fbuf[2][2];
         for (int c = 0; c < 3; ++c) {
@@ -1000,6 +1023,40 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
         vout->nrst = std::max(vout->nrst, irst);
     }
     op->st_matvecs += 1;
+    return 0;
+}
+
+// vec_out = state after the nsteps of one application started from `ic` (null: rest) under the time-harmonic body force
+// Re[(f_re + i f_im) exp(i s omega t)], s = -1 for the adjoint equations: evaluate_rhs / evaluate_imaginary_part of the
+// resolvent (src/linops/resolvent.f90:80-111, :133-166).  No restart-history replay, no history in the result.
+int do_integrate_forced(nlg_linop *op, const nlg_vec *ic, const nlg_vec *f_re, const nlg_vec *f_im, double omega, int adjoint, nlg_vec *vout) {
+    NLG_CHECK(op && f_re && vout, "integrate_forced: NULL argument");
+    NLG_CHECK(op->inited, "integrate_forced: nlg_linop_init has not been called");
+    nlg_mesh *m = op->mesh;
+    NLG_CHECK(f_re->mesh == m && vout->mesh == m && (!ic || ic->mesh == m) && (!f_im || f_im->mesh == m), "integrate_forced: vector on a different mesh");
+    NLG_CHECK(vout != f_re && vout != f_im && vout != ic, "integrate_forced: the output must be distinct from the inputs");
+    NLG_CHECK(f_re->nscal == 0 && vout->nscal == 0, "integrate_forced: scalar (temperature) coupling is not built yet");
+    hipStream_t st = m->ctx->stream;
+    for (int s = 0; s < 3; ++s)
+        for (int c = 0; c < m->dim; ++c) {
+            NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
+            NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
+        }
+    NLG_HIP(hipMemsetAsync(op->p, 0, sizeof(double) * (size_t)m->lps, st));
+    op->istep = 0;
+    op->adjoint = adjoint;
+    op->nproj = 0;
+    if (ic) NLG_TRY(load_state(op, ic, 0));
+    op->force_re = f_re;
+    op->force_im = f_im;
+    op->force_omega = omega;
+    op->force_sign = adjoint ? -1.0 : 1.0;
+    int rc = 0;
+    for (int istep = 1; istep <= op->nsteps && rc == 0; ++istep) rc = advance(op);
+    op->force_re = op->force_im = nullptr;
+    if (rc) return rc;
+    NLG_TRY(nlg_vec_zero(vout));
+    NLG_TRY(store_state(op, vout, 0));
     return 0;
 }
 
@@ -1210,6 +1267,11 @@ int nlg_linop_matvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out) { r
 int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out) { return do_matvec(op, vec_in, vec_out, 1); }
 
 int nlg_linop_nonlinear_map(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out) { return do_nonlinear_map(op, vec_in, vec_out); }
+
+int nlg_linop_integrate_forced(nlg_linop *op, const nlg_vec *ic, const nlg_vec *f_re, const nlg_vec *f_im, double omega, int adjoint,
+                               nlg_vec *vec_out) {
+    return do_integrate_forced(op, ic, f_re, f_im, omega, adjoint, vec_out);
+}
 
 int nlg_linop_set_baseflow(nlg_linop *op, const nlg_vec *baseflow) {
     NLG_CHECK(op && baseflow && baseflow->mesh == op->mesh, "nlg_linop_set_baseflow: bad argument");

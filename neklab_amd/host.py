@@ -332,6 +332,83 @@ class exptA_linop:
             self.h = None
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Resolvent operator by time stepping.  Reference: resolvent_linop (src/linops/neklab_linops.f90:198-205,
+# src/linops/resolvent.f90) acting on nek_zvector = (re, im) pairs of nek_dvector (src/vectors/neklab_vectors.f90).
+class nek_zvector:
+    """Complex state as a pair of real vectors (the reference's nek_zvector holds `re` and `im` of type nek_dvector)."""
+
+    def __init__(self, mesh: "Mesh"):
+        self.mesh = mesh
+        self.re, self.im = nek_dvector(mesh), nek_dvector(mesh)
+
+    def zero(self):
+        self.re.zero()
+        self.im.zero()
+
+    def axpby(self, alpha: complex, vec: "nek_zvector", beta: complex):
+        """self = alpha * vec + beta * self with complex scalars."""
+        a, b = complex(alpha), complex(beta)
+        re, im = self.re.copy(), self.im.copy()
+        self.re.scal(b.real)
+        self.re.axpby(-b.imag, im, 1.0)
+        self.re.axpby(a.real, vec.re, 1.0)
+        self.re.axpby(-a.imag, vec.im, 1.0)
+        self.im.scal(b.real)
+        self.im.axpby(b.imag, re, 1.0)
+        self.im.axpby(a.real, vec.im, 1.0)
+        self.im.axpby(a.imag, vec.re, 1.0)
+
+    def dot(self, vec: "nek_zvector") -> complex:
+        """<self, vec> = sum conj(self) vec in the mass-weighted velocity inner product."""
+        return complex(self.re.dot(vec.re) + self.im.dot(vec.im), self.re.dot(vec.im) - self.im.dot(vec.re))
+
+    def norm(self) -> float:
+        return float(np.sqrt(self.re.dot(self.re) + self.im.dot(self.im)))
+
+
+def integrate_forced(exptA: exptA_linop, ic, f_re: nek_dvector, f_im, omega: float, adjoint: bool, out: nek_dvector):
+    check(exptA.lib.nlg_linop_integrate_forced(exptA.h, ic.h if ic is not None else None, f_re.h,
+                                               f_im.h if f_im is not None else None, float(omega), int(bool(adjoint)), out.h))
+
+
+class resolvent_linop:
+    """R(omega) f: the time-periodic response to the forcing Re[f exp(i omega t)] about `baseflow`, by time stepping
+    (resolvent_matvec, src/linops/resolvent.f90:17-44): b = one period from rest under the forcing (evaluate_rhs),
+    Re x from (I - exp(T L)) x = b by GMRES(64), rtol 1e-6 (solve_resolvent_real_part, :113-131), Im part = the state a
+    quarter period later (evaluate_imaginary_part).  `rmatvec` integrates the adjoint equations with exp(-i omega t)."""
+
+    def __init__(self, omega: float, baseflow: nek_dvector, **cfg):
+        self.omega, self.baseflow, self.cfg = float(omega), baseflow, dict(cfg)
+        self.mesh = baseflow.mesh
+        self.gmres_matvecs = 0
+
+    def _apply(self, vin: nek_zvector, vout: nek_zvector, adjoint: bool):
+        tau = 1.0 if self.omega == 0.0 else 2.0 * np.pi / abs(self.omega)
+        A = exptA_linop(tau, self.baseflow, **self.cfg)
+        A.init()
+        b = nek_dvector(self.mesh)
+        integrate_forced(A, None, vin.re, vin.im, self.omega, adjoint, b)
+        # (I - exp(T L)) x = b  <=>  (exp(T L) - I) x = -b
+        rhs = b.copy()
+        rhs.scal(-1.0)
+        x = nek_dvector(self.mesh)
+        res, nmv = gmres(A, rhs, x, atol=max(1.0e-6 * b.norm(), 1.0e-12), kdim=64, transpose=adjoint)
+        self.gmres_matvecs += nmv
+        x.clear_rst_fields()
+        vout.re.assign(x)
+        A.tau = tau / 4.0                      # exptA%tau = tau/4; call exptA%init(), resolvent.f90:35
+        integrate_forced(A, x, vin.re, vin.im, self.omega, adjoint, vout.im)
+        self.last_operator = A
+        return res
+
+    def matvec(self, vin: nek_zvector, vout: nek_zvector):
+        return self._apply(vin, vout, False)
+
+    def rmatvec(self, vin: nek_zvector, vout: nek_zvector):
+        return self._apply(vin, vout, True)
+
+
 def line_labels(mesh: "Mesh", idir: int, decimals: int = 9) -> np.ndarray:
     """One label per line of velocity points along direction idir (1-based): points with the same remaining coordinates
     (rounded) share it.  What Nek5000's gtpp_gs_setup derives from (nelx, nely, nelz) for extruded box meshes
@@ -452,7 +529,7 @@ def nek_constant_tol(tol_old: float, target: float, rnorm: float):
 
 
 def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim: int = 30, maxiter: int = 10,
-          shift: float = -1.0, basis: "KrylovBasis | None" = None, replay_history: bool = False):
+          shift: float = -1.0, basis: "KrylovBasis | None" = None, replay_history: bool = False, transpose: bool = False):
     """Restarted GMRES(kdim) for (A + shift I) x = b, zero initial guess, stop at |residual| <= atol.  The Krylov space of
     A + shift I is that of A, so the Arnoldi relation comes from the device Arnoldi step of A (`nlg_arnoldi_step`:
     matvec + block CGS2) with `shift` added to the diagonal of H.  Returns (residual norm, number of matvecs).
@@ -482,7 +559,7 @@ def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim:
         g[0] = beta
         k = 0
         while k < kdim:
-            arnoldi_step(exptA, B, k, H)
+            arnoldi_step(exptA, B, k, H, transpose)
             nmv += 1
             if not replay_history:
                 B[k + 1].clear_rst_fields()
@@ -510,7 +587,7 @@ def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim:
             break
         # true residual for the restart: r = b - (A + shift I) x
         Ax = nek_dvector(mesh, b.nscal, b.lorder)
-        exptA.matvec(x, Ax)
+        (exptA.rmatvec if transpose else exptA.matvec)(x, Ax)
         nmv += 1
         r.assign(b)
         r.axpby(-1.0, Ax, 1.0)

@@ -311,3 +311,20 @@ def newton(nonlinear_map, jacobian_for, set_tolerance, X, tol, tol_mode=1, maxit
         nmv_total += nmv
         X.axpby(1.0, dx, 1.0)
     return {"converged": converged, "iterations": len(residuals) - 1, "residuals": residuals, "gmres_matvecs": nmv_total}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Resolvent by time stepping: twin of neklab_amd/host.py resolvent_linop (/root/reference/src/linops/resolvent.f90:17-44).
+def resolvent_apply(A, f_re, f_im, omega, adjoint=False):
+    """A: oracle ExptA built with tau = 2 pi / |omega| (1 for omega = 0).  Returns (x_re, x_im, b, gmres matvecs)."""
+    tau = A.cfg.tau
+    b = A.integrate_forced(None, f_re, f_im, omega, adjoint)
+    rhs = b.copy()
+    rhs.scal(-1.0)
+    mv = (lambda v: A.matvec(v, adjoint=True)) if adjoint else A.matvec
+    x, res, nmv = gmres(mv, rhs, atol=max(1.0e-6 * b.norm(), 1.0e-12), kdim=64)
+    x.clear_rst_fields()
+    A.set_tau(tau / 4.0)
+    y = A.integrate_forced(x, f_re, f_im, omega, adjoint)
+    A.set_tau(tau)
+    return x, y, b, nmv

@@ -187,6 +187,7 @@ class ExptA:
         k = min(self.istep, cfg.torder)
         b0, bd = BDF[k]
         ab = EXT[k]
+        force = getattr(self, "force", None)
         if getattr(self, "nonlinear", False):
             # full Navier-Stokes step (nonlinear_map, /root/reference/src/systems/fixed_point.f90:4-38):
             # (u.grad)u = 1/2 [(U.grad)u + (u.grad)U] at U = u
@@ -194,6 +195,12 @@ class ExptA:
         else:
             N = s.lns_conv_weak(self.U, self.u, adjoint=self.adjoint)
         F = [-a for a in N]
+        if force is not None:
+            # time-harmonic body force Re[f exp(i s omega t)] at the level the step starts from (resolvent.f90:97-103)
+            f_re, f_im, omega, sign = force
+            ph = sign * omega * (self.istep - 1) * dt
+            for i in range(dim):
+                F[i] = F[i] + s.bm1 * (np.cos(ph) * f_re[i] - (np.sin(ph) * f_im[i] if f_im is not None else 0.0))
         hist_f = [F] + self.flag
         hist_u = [self.u] + self.ulag
         rhs = []
@@ -293,6 +300,28 @@ class ExptA:
             c = np.bincount(self.proj_lab, weights=(2.0 * a * self.proj_cv * s.bm1).ravel()) / self.proj_den
             d = np.bincount(self.proj_lab, weights=(2.0 * a * self.proj_sv * s.bm1).ravel()) / self.proj_den
             out.append(self.proj_cv * c[self.proj_lab].reshape(s.shape1) + self.proj_sv * d[self.proj_lab].reshape(s.shape1))
+        return out
+
+    # ---------------- reference: src/linops/resolvent.f90:80-111, :133-166 ----------------
+    def set_tau(self, tau):
+        self.cfg.tau = tau
+        self.set_baseflow(self.U)
+
+    def integrate_forced(self, ic, f_re, f_im, omega, adjoint=False):
+        """State after nsteps from `ic` (None: rest) under the body force Re[(f_re + i f_im) exp(i s omega t)]."""
+        start = ic if ic is not None else NekDVector(self.sem)
+        self._reset_state(start, adjoint)
+        if ic is None:
+            self.p = np.zeros(self.sem.shape2)
+        self.force = ([np.asarray(a) for a in f_re], None if f_im is None else [np.asarray(a) for a in f_im], omega,
+                      -1.0 if adjoint else 1.0)
+        try:
+            for _ in range(self.nsteps):
+                self.advance()
+        finally:
+            self.force = None
+        out = NekDVector(self.sem)
+        self._store(out)
         return out
 
     # ---------------- reference: src/systems/fixed_point.f90:4-38 ----------------
