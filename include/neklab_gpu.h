@@ -183,6 +183,14 @@ typedef struct nlg_exptA_config {
                           in 3-D for lx1 <= 8 + vertex coarse space), 1 = Jacobi, 2 = two-level without overlap    */
     int pproj;         /* pressure residual projection onto the previous increments of the matvec (Nek5000
                           `residualProj = yes`, examples/cylinder/stability/direct/1cyl.par:23): 0 = off, 1 = on    */
+    int ifheat;        /* Boussinesq coupling with one scalar (temperature): the vectors carry theta (nscal = 1), the base
+                          flow its base temperature.  rhocp (d/dt + U.grad) theta + rhocp u.grad Theta = conductivity
+                          lap theta, momentum forcing buoy[i] * theta -- Nek5000's [TEMPERATURE] block and the buoyancy of
+                          the case's userf (examples/rayBen/baseflow/rayBen.par:39-45, rayBen.usr:77-103).  Direct
+                          equations only.                                                                           */
+    double conductivity;
+    double rhocp;
+    double buoy[3];
 } nlg_exptA_config;
 
 int nlg_exptA_config_default(nlg_exptA_config *cfg);

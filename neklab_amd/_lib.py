@@ -36,6 +36,7 @@ class ExptAConfig(C.Structure):
         ("ptol", C.c_double), ("dt", C.c_double),
         ("torder", C.c_int), ("maxit_v", C.c_int), ("maxit_p", C.c_int),
         ("fixed_iters_v", C.c_int), ("fixed_iters_p", C.c_int), ("pprecond", C.c_int), ("pproj", C.c_int),
+        ("ifheat", C.c_int), ("conductivity", C.c_double), ("rhocp", C.c_double), ("buoy", C.c_double * 3),
     ]
 
 

@@ -416,6 +416,18 @@ __global__ __launch_bounds__(NT) void k_add_force(int64_t n, F3 F, const double 
     }
 }
 
+// F_i -= bm1 * buoy_i * theta : Boussinesq buoyancy in the explicit term (the stored F is +N)
+template <int NF>
+__global__ __launch_bounds__(NT) void k_buoyancy(int64_t n, F3 F, const double *__restrict__ bm1, const double *__restrict__ theta,
+                                                 double b0, double b1, double b2) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double t = bm1[i] * theta[i];
+        F.p[0][i] -= b0 * t;
+        if (NF > 1) F.p[1][i] -= b1 * t;
+        if (NF > 2) F.p[2][i] -= b2 * t;
+    }
+}
+
 // generic pointwise helpers
 template <int NF>
 __global__ __launch_bounds__(NT) void k_colmul_gated(const double *s, F3 w, CF3 wt, int64_t n) {
@@ -531,6 +543,12 @@ struct nlg_linop {
     // time-harmonic body force Re(f exp(i s omega t)) of the resolvent integrations (null = none)
     const nlg_vec *force_re = nullptr, *force_im = nullptr;
     double force_omega = 0.0, force_sign = 1.0;
+    // Boussinesq coupling (cfg.ifheat): temperature levels, its explicit terms, PCG work fields, Jacobi preconditioners per
+    // BDF order, gradient of the base temperature on the fine mesh
+    double *tbuf[3] = {}, *ftbuf[3] = {}, *trhs = nullptr, *tx = nullptr, *tz = nullptr, *tpv = nullptr, *tw = nullptr;
+    double *pct[4] = {}, *GT[3] = {};
+    int64_t st_titers = 0;
+    int last_titers = 8;
     int nonlinear = 0;         // 1: full Navier-Stokes step, N(u) = (u.grad)u = half of the linearised term about U = u
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
@@ -732,6 +750,92 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     return 0;
 }
 
+// One scalar (temperature) step of the Boussinesq coupling, see oracle/lns.py advance (ifheat branch):
+//   rhocp (b0 theta^{n+1} - sum bd_j theta^{n-j}) / dt = -rhocp EXT[(U.grad) theta + (u.grad) Theta] + conductivity lap theta^{n+1}
+// in residual form, Jacobi-PCG; the new level ends in tbuf[0].
+int heat_step(nlg_linop *op, int k, double b0) {
+    nlg_mesh *m = op->mesh;
+    hipStream_t st = m->ctx->stream;
+    const auto &c = op->cfg;
+    const double dt = op->dt, rc = c.rhocp;
+    // explicit term into the oldest buffer, then rotate
+    NLG_TRY(sem_conv_scalar_apply(m, op->Ur, op->GT, op->ubuf[0], op->tbuf[0], op->ftbuf[2]));
+    {
+        double *t = op->ftbuf[2];
+        op->ftbuf[2] = op->ftbuf[1];
+        op->ftbuf[1] = op->ftbuf[0];
+        op->ftbuf[0] = t;
+    }
+    Hist h;
+    h.k = k;
+    for (int j = 0; j < 3; ++j) {
+        h.ab[j] = -rc * EXT_C[k][j];
+        h.bd[j] = BDF_C[k][j];
+        for (int q = 0; q < 3; ++q) {
+            h.f[j][q] = q == 0 ? op->ftbuf[j] : nullptr;
+            h.u[j][q] = q == 0 ? op->tbuf[j] : nullptr;
+        }
+    }
+    F3 rhs = {{op->trhs, nullptr, nullptr}};
+    hipLaunchKernelGGL(k_rhs<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, h, (const double *)m->d_bm1, rc / dt, rhs);
+    const double h1 = c.conductivity, h2 = rc * b0 / dt;
+    double *tin[1] = {op->tbuf[0]}, *tw[1] = {op->tw}, *trhs[1] = {op->trhs};
+    NLG_TRY(sem_axhelm(m, tin, tw, 1, h1, h2));
+    {
+        CF3 a = {{op->trhs, nullptr, nullptr}}, b = {{op->tw, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
+        hipLaunchKernelGGL(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, rhs, a, b, -1.0, none, 0.0);
+    }
+    NLG_TRY(sem_gs(m, trhs, 1));
+    {
+        CF3 mk = {{m->d_tmask, nullptr, nullptr}};
+        hipLaunchKernelGGL(k_colmul_gated<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, (const double *)nullptr, rhs, mk, m->lvn);
+    }
+    // Jacobi-PCG, one field; the operator kernel sums (p, w) and updates p itself
+    double *x[1] = {op->tx}, *z[1] = {op->tz}, *p[1] = {op->tpv}, *pc[1] = {op->pct[k]};
+    CGProblem P;
+    P.nf = 1;
+    P.n = m->lvn;
+    P.x = x;
+    P.r = trhs;
+    P.z = z;
+    P.p = p;
+    P.w = tw;
+    P.pc = pc;
+    P.ipw = m->d_vmult;
+    P.nw = op->nwv;
+    P.tol2 = c.vtol * c.vtol;
+    P.use_tol = c.fixed_iters_v > 0 ? 0 : 1;
+    P.maxit = c.fixed_iters_v > 0 ? c.fixed_iters_v : c.maxit_v;
+    P.s = op->d_s;
+    P.inv_n = 0.0;
+    P.chunk = std::max(2, std::min(op->last_titers, 64));
+    P.pw_part = op->d_part;
+    P.pw_n = sem_axhelm_blocks(m, 1);
+    P.pw_sum = false;
+    P.fused_pupdate = true;
+    auto apply = [&](double *) -> int {
+        NLG_TRY(sem_axhelm(m, p, tw, 1, h1, h2, op->d_part, z, op->d_s + S_BETA, op->d_s + S_DONE));
+        NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE));
+        return 0;
+    };
+    int iters = 0;
+    NLG_TRY(run_pcg(op, P, apply, &iters));
+    op->st_titers += iters;
+    op->last_titers = iters;
+    // theta^{n+1} = theta^n + x into the oldest level, then rotate: new -> current
+    {
+        F3 y = {{op->tbuf[2], nullptr, nullptr}};
+        CF3 a = {{op->tbuf[0], nullptr, nullptr}}, b = {{op->tx, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
+        hipLaunchKernelGGL(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0);
+        double *t = op->tbuf[2];
+        op->tbuf[2] = op->tbuf[1];
+        op->tbuf[1] = op->tbuf[0];
+        op->tbuf[0] = t;
+    }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 int pres_solve(nlg_linop *op, double scale) {
     nlg_mesh *m = op->mesh;
     const auto &c = op->cfg;
@@ -848,10 +952,14 @@ int advance(nlg_linop *op) {
     NLG_TRY(sem_ortho(m, op->p));
     const int k = std::min(op->istep, op->cfg.torder);
     const double b0 = BDF_B0[k];
+    if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
     if (op->nonlinear) NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));   // the "base flow" is the current state
     NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
+    if (op->cfg.ifheat)
+        launch_nf(dim, k_buoyancy<1>, k_buoyancy<2>, k_buoyancy<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(Fnew, dim),
+                  (const double *)m->d_bm1, (const double *)op->tbuf[0], op->cfg.buoy[0], op->cfg.buoy[1], op->cfg.buoy[2]);
     if (op->force_re) {
         // forcing of this step: evaluated at the time level the step starts from, (istep - 1) dt, like the explicit terms
         // (resolvent.f90:97-103: alpha = exp(sign i omega time) before nek_advance)
@@ -936,6 +1044,8 @@ int load_state(nlg_linop *op, const nlg_vec *v, int irst) {
     for (int c = 0; c < m->dim; ++c)
         NLG_HIP(hipMemcpyAsync(op->ubuf[0][c], v->vel(c, irst), sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToDevice, st));
     NLG_HIP(hipMemcpyAsync(op->p, v->pr(irst), sizeof(double) * (size_t)m->lpn, hipMemcpyDeviceToDevice, st));
+    if (op->cfg.ifheat)
+        NLG_HIP(hipMemcpyAsync(op->tbuf[0], v->theta(0, irst), sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -945,6 +1055,8 @@ int store_state(nlg_linop *op, nlg_vec *v, int irst) {
     for (int c = 0; c < m->dim; ++c)
         NLG_HIP(hipMemcpyAsync(v->vel(c, irst), op->ubuf[0][c], sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToDevice, st));
     NLG_HIP(hipMemcpyAsync(v->pr(irst), op->p, sizeof(double) * (size_t)m->lpn, hipMemcpyDeviceToDevice, st));
+    if (op->cfg.ifheat)
+        NLG_HIP(hipMemcpyAsync(v->theta(0, irst), op->tbuf[0], sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -982,7 +1094,9 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     nlg_mesh *m = op->mesh;
     NLG_CHECK(vin->mesh == m && vout->mesh == m,
               "exptA matvec: vector on a different mesh (reference: type_error, exponential_propagator.f90:53-58)");
-    NLG_CHECK(vin->nscal == 0 && vout->nscal == 0, "exptA matvec: scalar (temperature) coupling is not built yet");
+    NLG_CHECK(vin->nscal == (op->cfg.ifheat ? 1 : 0) && vout->nscal == vin->nscal,
+              "exptA matvec: the vectors carry %d scalar(s), the operator expects %d (cfg.ifheat)", vin->nscal, op->cfg.ifheat ? 1 : 0);
+    NLG_CHECK(!(op->cfg.ifheat && adjoint), "exptA rmatvec: the adjoint Boussinesq coupling is not built");
     NLG_CHECK(vin->lorder >= op->cfg.torder && vout->lorder >= op->cfg.torder,
               "exptA matvec: vector lorder %d < time order %d", vin->lorder, op->cfg.torder);
     NLG_CHECK(vin != vout, "exptA matvec: vec_in and vec_out must be distinct (intent(in) / intent(out))");
@@ -993,6 +1107,11 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
         for (int c = 0; c < m->dim; ++c) {
             NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
             NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
+        }
+    if (op->cfg.ifheat)
+        for (int q = 0; q < 3; ++q) {
+            NLG_HIP(hipMemsetAsync(op->tbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
+            NLG_HIP(hipMemsetAsync(op->ftbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
         }
     op->istep = 0;
     op->adjoint = adjoint;
@@ -1108,6 +1227,9 @@ int nlg_exptA_config_default(nlg_exptA_config *c) {
     c->torder = 3;
     c->maxit_v = 200;
     c->maxit_p = 2000;
+    c->ifheat = 0;
+    c->conductivity = 1.0;
+    c->rhocp = 1.0;
     c->pproj = 1;   // residualProj = yes for the pressure, as in the reference's cylinder case (1cyl.par:23)
     return 0;
 }
@@ -1117,6 +1239,8 @@ int nlg_linop_create(nlg_mesh *mesh, const nlg_exptA_config *cfg, const nlg_vec 
     NLG_CHECK(baseflow->mesh == mesh, "nlg_linop_create: baseflow lives on a different mesh");
     NLG_CHECK(cfg->torder >= 1 && cfg->torder <= 3, "nlg_linop_create: torder %d unsupported (1..3)", cfg->torder);
     NLG_CHECK(cfg->tau > 0.0 && cfg->re > 0.0, "nlg_linop_create: tau and re must be positive");
+    NLG_CHECK(!cfg->ifheat || (baseflow->nscal >= 1 && cfg->conductivity > 0.0 && cfg->rhocp > 0.0),
+              "nlg_linop_create: ifheat needs a base flow with its temperature (nscal >= 1) and positive conductivity / rhocp");
     nlg_linop *op = new nlg_linop();
     op->mesh = mesh;
     op->cfg = *cfg;
@@ -1153,6 +1277,13 @@ int nlg_linop_destroy(nlg_linop *op) {
     fr(op->pr_p);
     fr(op->pr_w);
     fr(op->pce);
+    for (int q = 0; q < 3; ++q) {
+        fr(op->tbuf[q]);
+        fr(op->ftbuf[q]);
+        fr(op->GT[q]);
+    }
+    for (int k = 0; k < 4; ++k) fr(op->pct[k]);
+    for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) fr(*v);
     fr(op->prX);
     fr(op->prB);
     fr(op->d_pc);
@@ -1246,6 +1377,27 @@ int nlg_linop_init(nlg_linop *op) {
         for (int c = 0; c < dim; ++c)
             hipLaunchKernelGGL(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pcv[k][c], (const double *)dg,
                                (const double *)m->d_mask[c]);
+    }
+    if (op->cfg.ifheat) {
+        if (!op->trhs) {
+            for (int q = 0; q < 3; ++q) {
+                NLG_TRY(lalloc(op, &op->tbuf[q], m->lvs));
+                NLG_TRY(lalloc(op, &op->ftbuf[q], m->lvs));
+            }
+            for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) NLG_TRY(lalloc(op, v, m->lvs));
+            for (int k = 1; k <= op->cfg.torder; ++k) NLG_TRY(lalloc(op, &op->pct[k], m->lvs));
+            for (int q = 0; q < dim; ++q) NLG_HIP(hipMalloc(&op->GT[q], sizeof(double) * (size_t)m->lfn));
+        }
+        NLG_TRY(sem_conv_scalar_setup(m, op->baseflow->theta(0), op->GT));
+        for (int k = 1; k <= op->cfg.torder; ++k) {
+            double *dg = sem_scratch1(m, 3);
+            NLG_CHECK(dg, "nlg_linop_init: scratch allocation failed");
+            NLG_TRY(sem_helm_diag(m, dg, op->cfg.conductivity, op->cfg.rhocp * BDF_B0[k] / op->dt));
+            double *f[1] = {dg};
+            NLG_TRY(sem_gs(m, f, 1));
+            hipLaunchKernelGGL(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pct[k], (const double *)dg,
+                               (const double *)m->d_tmask);
+        }
     }
     {
         double *ed = sem_scratch2(m, 5);

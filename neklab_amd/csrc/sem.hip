@@ -1857,6 +1857,45 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
     return 0;
 }
 
+// Scalar (temperature) transport of the Boussinesq coupling: GT[m] = sum_j rstdw[j][m] dTheta/dr_j of the base temperature
+// (the gradient part of u . grad Theta on the fine mesh), precomputed like GU
+int sem_conv_scalar_setup(nlg_mesh *m, const double *Theta, double **GT) {
+    const int dim = m->dim;
+    CF9 rd;
+    for (int q = 0; q < 9; ++q) rd.p[q] = m->d_rstdw[q];
+    double *t[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
+    NLG_CHECK(t[0] && t[1], "sem_conv_scalar_setup: scratch allocation failed");
+    for (int j = 0; j < dim; ++j)
+        NLG_TRY(sem_tensor(m, Theta, t[j], m->n, m->nd, j == 0 ? m->d_DJd : m->d_Jd, j == 1 ? m->d_DJd : m->d_Jd,
+                           j == 2 ? m->d_DJd : m->d_Jd, nullptr));
+    CF3 du = {{t[0], t[1], t[2]}};
+    F3 gt = {{GT[0], GT[1], dim == 3 ? GT[2] : nullptr}};
+    hipLaunchKernelGGL(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, du, gt);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+// out = J^T W [(U . grad) theta + (u . grad) Theta]   (weak, element-local), oracle: conv_weak(U, theta) + conv_weak(u, Theta)
+int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, double *const *u, const double *theta, double *out) {
+    ProfScope ps(m->ctx, P_CONV);
+    const int dim = m->dim;
+    double *uf[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
+    double *dt[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), dim == 3 ? sem_scratchd(m, 5) : nullptr};
+    double *acc = sem_scratchd(m, 6);
+    NLG_CHECK(uf[0] && dt[0] && acc, "sem_conv_scalar_apply: scratch allocation failed");
+    for (int i = 0; i < dim; ++i) NLG_TRY(sem_tensor(m, u[i], uf[i], m->n, m->nd, m->d_Jd, m->d_Jd, m->d_Jd, nullptr));
+    for (int j = 0; j < dim; ++j)
+        NLG_TRY(sem_tensor(m, theta, dt[j], m->n, m->nd, j == 0 ? m->d_DJd : m->d_Jd, j == 1 ? m->d_DJd : m->d_Jd,
+                           j == 2 ? m->d_DJd : m->d_Jd, nullptr));
+    CF3 cur = {{Ur[0], Ur[1], dim == 3 ? Ur[2] : nullptr}};
+    CF3 cdt = {{dt[0], dt[1], dt[2]}}, cuf = {{uf[0], uf[1], uf[2]}};
+    CF3 cgt = {{GT[0], GT[1], dim == 3 ? GT[2] : nullptr}};
+    hipLaunchKernelGGL(k_conv_combine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdt, cuf, cgt, 1.0, acc);
+    NLG_TRY(sem_tensor(m, acc, out, m->nd, m->n, m->d_Jdt, m->d_Jdt, m->d_Jdt, nullptr));
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 // out_i = weak linearised convective term (B-weighted, element-local), see oracle/sem.py lns_conv_weak
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
     ProfScope ps(m->ctx, P_CONV);

@@ -288,6 +288,8 @@ class exptA_linop:
         for k, v in cfg.items():
             if not hasattr(c, k):
                 raise TypeError("unknown exptA option %r" % k)
+            if k == "buoy":
+                v = (C.c_double * 3)(*[float(a) for a in tuple(v) + (0.0,) * (3 - len(tuple(v)))])
             setattr(c, k, v)
         self.cfg = c
         self.baseflow = baseflow

@@ -44,6 +44,13 @@ class LNSConfig:
     fixed_iters_v: int = 0      # >0: run exactly this many PCG iterations (parity mode)
     fixed_iters_p: int = 0
     dt: float = 0.0             # >0: skip the CFL rule and use nsteps = ceil(tau/dt)
+    # Boussinesq coupling (Nek5000 [TEMPERATURE] block + the buoyancy written in the case's userf, e.g.
+    # examples/rayBen/baseflow/rayBen.par:39-45, rayBen.usr:77-103): rhocp (d/dt + U.grad) theta + rhocp u.grad Theta =
+    # conductivity lap theta ; momentum forcing buoy_i * theta
+    ifheat: bool = False
+    conductivity: float = 1.0
+    rhocp: float = 1.0
+    buoy: tuple = (0.0, 0.0, 0.0)
 
 
 def dt_rule(tau, cfl_at_unit_dt, cfl_limit):
@@ -54,10 +61,13 @@ def dt_rule(tau, cfl_at_unit_dt, cfl_limit):
 
 
 class ExptA:
-    def __init__(self, sem, baseflow, cfg: LNSConfig):
+    def __init__(self, sem, baseflow, cfg: LNSConfig, baseflow_theta=None):
         self.sem = sem
         self.cfg = cfg
         self.U = [sem.f1(a).copy() for a in baseflow]
+        self.Theta = None if baseflow_theta is None else sem.f1(baseflow_theta).copy()
+        if cfg.ifheat and self.Theta is None:
+            raise ValueError("ifheat needs the base temperature")
         if cfg.dt > 0:
             self.nsteps = int(math.ceil(cfg.tau / cfg.dt - 1e-12))
             self.dt = cfg.tau / self.nsteps
@@ -119,6 +129,42 @@ class ExptA:
         self.stats["v_iters"] += it
         return x
 
+    def pcg_heat(self, b, h1, h2):
+        """Jacobi-PCG for the scalar Helmholtz problem tmask QQ^T (h1 A + h2 B) x = b (same stopping rule as the velocity)."""
+        s, cfg = self.sem, self.cfg
+        minv = s.tmask / s.gs(s.helm_diag_local(h1, h2))
+        wnorm = s.binvm1 * s.vmult / s.volvm1
+
+        def A(p):
+            return s.tmask * s.gs(s.axhelm_local(p, h1, h2))
+
+        x = np.zeros(s.shape1)
+        r = b.copy()
+        z = minv * r
+        p = z.copy()
+        rz = np.sum(r * z * s.vmult)
+        it, rn2_0 = 0, None
+        maxit = cfg.fixed_iters_v if cfg.fixed_iters_v > 0 else cfg.maxit_v
+        while it < maxit:
+            rn2 = np.sum(r * r * wnorm)
+            if rn2_0 is None:
+                rn2_0 = rn2
+            if rn2 <= FLOOR2 * rn2_0:
+                break
+            if cfg.fixed_iters_v <= 0 and rn2 < cfg.vtol ** 2:
+                break
+            w = A(p)
+            alpha = rz / np.sum(p * w * s.vmult)
+            x += alpha * p
+            r -= alpha * w
+            z = minv * r
+            rz_new = np.sum(r * z * s.vmult)
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+            it += 1
+        self.stats["t_iters"] = self.stats.get("t_iters", 0) + it
+        return x
+
     def pcg_E(self, b, scale):
         """Solve E x = b; converged when scale*||r||_p < ptol (remaining divergence).
 
@@ -175,6 +221,12 @@ class ExptA:
         self.flag = [[np.zeros(s.shape1) for _ in range(s.dim)] for _ in range(2)]
         self.istep = 0
         self.adjoint = adjoint
+        if self.cfg.ifheat:
+            if adjoint:
+                raise NotImplementedError("adjoint Boussinesq coupling is not built")
+            self.t = vec.theta[0].copy()
+            self.tlag = [np.zeros(s.shape1) for _ in range(2)]
+            self.ftlag = [np.zeros(s.shape1) for _ in range(2)]
 
     def advance(self):
         s, cfg = self.sem, self.cfg
@@ -187,6 +239,20 @@ class ExptA:
         k = min(self.istep, cfg.torder)
         b0, bd = BDF[k]
         ab = EXT[k]
+        if cfg.ifheat:
+            # scalar first, then the fluid with the buoyancy of the NEW temperature in its explicit term (the order of
+            # Nek5000's nek_advance: heat, then fluid, whose userf reads the updated scalar)
+            rc = cfg.rhocp
+            Nt = s.conv_weak(self.U, self.t) + s.conv_weak(self.u, self.Theta)
+            Ft = -rc * Nt
+            hist_ft = [Ft] + self.ftlag
+            hist_t = [self.t] + self.tlag
+            rhs_t = sum(ab[j] * hist_ft[j] for j in range(k)) + (rc * s.bm1 / dt) * sum(bd[j] * hist_t[j] for j in range(k))
+            self.ftlag = [Ft, self.ftlag[0]]
+            self.tlag = [self.t.copy(), self.tlag[0]]
+            h1t, h2t = cfg.conductivity, rc * b0 / dt
+            res_t = s.tmask * s.gs(rhs_t - s.axhelm_local(self.t, h1t, h2t))
+            self.t = self.t + self.pcg_heat(res_t, h1t, h2t)
         force = getattr(self, "force", None)
         if getattr(self, "nonlinear", False):
             # full Navier-Stokes step (nonlinear_map, /root/reference/src/systems/fixed_point.f90:4-38):
@@ -201,6 +267,10 @@ class ExptA:
             ph = sign * omega * (self.istep - 1) * dt
             for i in range(dim):
                 F[i] = F[i] + s.bm1 * (np.cos(ph) * f_re[i] - (np.sin(ph) * f_im[i] if f_im is not None else 0.0))
+        if cfg.ifheat:
+            for i in range(dim):
+                if cfg.buoy[i] != 0.0:
+                    F[i] = F[i] + s.bm1 * cfg.buoy[i] * self.t
         hist_f = [F] + self.flag
         hist_u = [self.u] + self.ulag
         rhs = []
@@ -229,11 +299,15 @@ class ExptA:
     def _load(self, vec):
         self.u = [a.copy() for a in vec.v]
         self.p = vec.pr.copy()
+        if self.cfg.ifheat:
+            self.t = vec.theta[0].copy()
 
     def _store(self, vec):
         for a, b in zip(vec.v, self.u):
             a[...] = b
         vec.pr[...] = self.p
+        if self.cfg.ifheat:
+            vec.theta[0][...] = self.t
 
     # ---------------- reference: exponential_propagator.f90:15-60 / :62-107 ----------------
     def matvec(self, vec_in: NekDVector, adjoint=False) -> NekDVector:

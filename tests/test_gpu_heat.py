@@ -1,0 +1,84 @@
+"""Boussinesq (temperature) coupling of the propagator: matvec against the oracle, and the classical known answer the
+reference's Rayleigh-Benard case quotes -- onset at Ra_c = 1707.762 for the wavenumber 3.117, rigid-rigid
+(Chandrasekhar 1961, Table III; examples/rayBen/baseflow/rayBen.par:9)."""
+import numpy as np
+import pytest
+
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+from oracle.lns import ExptA, LNSConfig
+from oracle.sem import SEM
+from oracle.vectors import NekDVector
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_boussinesq_matvec_matches_oracle(gpu_ctx, dim):
+    if dim == 2:
+        hm = box_mesh((3, 2), 6, lengths=(2.0, 1.0), periodic=(True, False), deform=0.03)
+    else:
+        hm = box_mesh((2, 2, 2), 6, lengths=(2.0, 1.0, 1.0), periodic=(True, False, True), deform=0.03)
+    sem = SEM(hm)
+    gm = host.Mesh(gpu_ctx, hm)
+    U = [sem.mask[0] * (4 * sem.X[1] * (1 - sem.X[1]))] + [np.zeros(sem.shape1) for _ in range(dim - 1)]
+    Theta = 1.0 - sem.X[1] + 0.1 * np.sin(np.pi * sem.X[0]) * np.sin(np.pi * sem.X[1])
+    gb = host.nek_dvector(gm, 1)
+    gb.set_field(0, U[0])
+    gb.set_field(host.THETA, Theta)
+    buoy = (0.0, 50.0, 0.0)
+    kw = dict(re=5.0, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=600, maxit_p=4000, dt=0.01)
+    heat = dict(ifheat=True, conductivity=0.3, rhocp=1.5, buoy=buoy)
+    oA = ExptA(sem, U, LNSConfig(tau=0.05, **kw, **heat), Theta)
+    gA = host.exptA_linop(0.05, gb, **kw, **{**heat, "ifheat": 1})
+    gA.init()
+    rng = np.random.default_rng(0)
+    ov, gv = NekDVector(sem, 1), host.nek_dvector(gm, 1)
+    for i in range(dim):
+        ov.v[i][...] = sem.mask[i] * sem.dsavg(rng.standard_normal(sem.shape1))
+        gv.set_field(i, ov.v[i])
+    ov.theta[0][...] = sem.tmask * sem.dsavg(rng.standard_normal(sem.shape1))
+    gv.set_field(host.THETA, ov.theta[0])
+    gout = host.nek_dvector(gm, 1)
+    gA.matvec(gv, gout)
+    oout = oA.matvec(ov)
+    sc = max(np.abs(a).max() for a in oout.v)
+    for i in range(dim):
+        assert np.max(np.abs(gout.get_field(i).reshape(sem.shape1) - oout.v[i])) < 1e-9 * sc
+    st = np.abs(oout.theta[0]).max()
+    assert np.max(np.abs(gout.get_field(host.THETA).reshape(sem.shape1) - oout.theta[0])) < 1e-9 * st
+    # second application: the restart history carries the temperature as well
+    g2 = host.nek_dvector(gm, 1)
+    gA.matvec(gout, g2)
+    o2 = oA.matvec(oout)
+    assert np.max(np.abs(g2.get_field(host.THETA).reshape(sem.shape1) - o2.theta[0])) < 1e-8 * np.abs(o2.theta[0]).max()
+    # a vector without the scalar is refused, and so is the adjoint
+    with pytest.raises(host.NlgError):
+        gA.matvec(host.nek_dvector(gm), host.nek_dvector(gm))
+    with pytest.raises(host.NlgError):
+        gA.rmatvec(gv, gout)
+
+
+def test_rayleigh_benard_onset(gpu_ctx, tmp_path):
+    """Conduction state Theta = 1 - y, U = 0, Pr = 1, box of one critical wavelength 2 pi / 3.117: the growth rate of the
+    leading mode changes sign at Ra_c = 1707.762.  Measured with dt = 0.005 (first-order splitting of the coupling):
+    sigma(1600) = -0.825, sigma(1707.762) = +0.071, sigma(1800) = +0.822, i.e. a zero crossing at Ra = 1699 (0.5 %)."""
+    hm = box_mesh((3, 3), 8, lengths=(2 * np.pi / 3.117, 1.0), periodic=(True, False), deform=0.0)
+    gm = host.Mesh(gpu_ctx, hm)
+    bf = host.nek_dvector(gm, 1)
+    bf.set_field(host.THETA, 1.0 - hm.y)
+    sig = {}
+    for Ra in (1600.0, 1800.0):
+        A = host.exptA_linop(0.1, bf, re=1.0, torder=3, dt=0.005, vtol=1e-11, ptol=1e-11, maxit_v=2000, maxit_p=4000,
+                             ifheat=1, conductivity=1.0, rhocp=1.0, buoy=(0.0, Ra, 0.0))
+        A.init()
+        eigvecs = [host.nek_dvector(gm, 1, 3)]
+        mu, res, info = host.eigs(A, eigvecs, kdim=16, tol=1e-8, logfile=str(tmp_path / "eigs.txt"), seed=1)
+        assert res[0] < 1e-7 and abs(mu[0].imag) < 1e-9            # onset is stationary (exchange of stabilities)
+        sig[Ra] = np.log(abs(mu[0])) / 0.1
+        # the marginal mode is a pair of counter-rotating rolls: vertical velocity and temperature in phase
+        v, th = eigvecs[0].get_field(1), eigvecs[0].get_field(host.THETA)
+        assert abs(np.corrcoef(v, th)[0, 1]) > 0.95
+    assert sig[1600.0] < 0 < sig[1800.0]
+    ra_c = 1600.0 - sig[1600.0] * 200.0 / (sig[1800.0] - sig[1600.0])
+    assert abs(ra_c - 1707.762) < 0.01 * 1707.762, (sig, ra_c)
