@@ -76,6 +76,7 @@ contains
       A%cfg%vtol = 1.0e-13_dp; A%cfg%ptol = 1.0e-13_dp; A%cfg%dt = dt
       A%cfg%torder = 3; A%cfg%maxit_v = 400; A%cfg%maxit_p = 4000
       A%cfg%fixed_iters_v = 0; A%cfg%fixed_iters_p = 0; A%cfg%pprecond = 0; A%cfg%pproj = 1
+      A%cfg%ifheat = 0; A%cfg%conductivity = 1.0_dp; A%cfg%rhocp = 1.0_dp; A%cfg%buoy = 0.0_dp
    end subroutine
 
    !> one Arnoldi step written against the abstract API only (CGS2 with k separate dots and axpbys)

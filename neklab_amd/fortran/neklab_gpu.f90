@@ -36,8 +36,8 @@ module neklab_gpu
    type, bind(C), public :: nlg_exptA_config
       real(c_double) :: tau, re, cfl_limit, vtol, ptol, dt
       integer(c_int) :: torder, maxit_v, maxit_p, fixed_iters_v, fixed_iters_p, pprecond, pproj
-      integer(c_int) :: ifheat
-      real(c_double) :: conductivity, rhocp, buoy(3)
+      integer(c_int) :: ifheat = 0
+      real(c_double) :: conductivity = 1.0_c_double, rhocp = 1.0_c_double, buoy(3) = 0.0_c_double
    end type
 
    interface
