@@ -769,7 +769,7 @@ int heat_step(nlg_linop *op, int k, double b0) {
     Hist h;
     h.k = k;
     for (int j = 0; j < 3; ++j) {
-        h.ab[j] = -rc * EXT_C[k][j];
+        h.ab[j] = -(op->nonlinear ? 0.5 : 1.0) * rc * EXT_C[k][j];   // nonlinear: (u.grad)theta = 1/2 [(U.grad)theta + (u.grad)Theta] at U = u, Theta = theta
         h.bd[j] = BDF_C[k][j];
         for (int q = 0; q < 3; ++q) {
             h.f[j][q] = q == 0 ? op->ftbuf[j] : nullptr;
@@ -952,14 +952,19 @@ int advance(nlg_linop *op) {
     NLG_TRY(sem_ortho(m, op->p));
     const int k = std::min(op->istep, op->cfg.torder);
     const double b0 = BDF_B0[k];
+    if (op->nonlinear) {   // the "base flow" is the current state (velocity, and temperature when coupled)
+        NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));
+        if (op->cfg.ifheat) NLG_TRY(sem_conv_scalar_setup(m, op->tbuf[0], op->GT));
+    }
     if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
-    if (op->nonlinear) NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));   // the "base flow" is the current state
     NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
-    if (op->cfg.ifheat)
+    if (op->cfg.ifheat) {
+        const double bs = op->nonlinear ? 2.0 : 1.0;   // the nonlinear step halves the whole stored term (F holds 2 N there)
         launch_nf(dim, k_buoyancy<1>, k_buoyancy<2>, k_buoyancy<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(Fnew, dim),
-                  (const double *)m->d_bm1, (const double *)op->tbuf[0], op->cfg.buoy[0], op->cfg.buoy[1], op->cfg.buoy[2]);
+                  (const double *)m->d_bm1, (const double *)op->tbuf[0], bs * op->cfg.buoy[0], bs * op->cfg.buoy[1], bs * op->cfg.buoy[2]);
+    }
     if (op->force_re) {
         // forcing of this step: evaluated at the time level the step starts from, (istep - 1) dt, like the explicit terms
         // (resolvent.f90:97-103: alpha = exp(sign i omega time) before nek_advance)
@@ -1185,7 +1190,8 @@ int do_nonlinear_map(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout) {
     NLG_CHECK(op && vin && vout, "nonlinear_map: NULL argument");
     nlg_mesh *m = op->mesh;
     NLG_CHECK(vin->mesh == m && vout->mesh == m, "nonlinear_map: vector on a different mesh (reference: type_error, fixed_point.f90:31-36)");
-    NLG_CHECK(vin->nscal == 0 && vout->nscal == 0, "nonlinear_map: scalar (temperature) coupling is not built yet");
+    NLG_CHECK(vin->nscal == (op->cfg.ifheat ? 1 : 0) && vout->nscal == vin->nscal,
+              "nonlinear_map: the vectors carry %d scalar(s), the operator expects %d (cfg.ifheat)", vin->nscal, op->cfg.ifheat ? 1 : 0);
     NLG_CHECK(vin != vout, "nonlinear_map: vec_in and vec_out must be distinct");
     hipStream_t st = m->ctx->stream;
     // "setup_nonlinear_solver(recompute_dt = .true.)": the time step follows the state that is integrated
@@ -1195,6 +1201,11 @@ int do_nonlinear_map(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout) {
         for (int c = 0; c < m->dim; ++c) {
             NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
             NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
+        }
+    if (op->cfg.ifheat)
+        for (int q = 0; q < 3; ++q) {
+            NLG_HIP(hipMemsetAsync(op->tbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
+            NLG_HIP(hipMemsetAsync(op->ftbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
         }
     op->istep = 0;
     op->adjoint = 0;

@@ -243,7 +243,10 @@ class ExptA:
             # scalar first, then the fluid with the buoyancy of the NEW temperature in its explicit term (the order of
             # Nek5000's nek_advance: heat, then fluid, whose userf reads the updated scalar)
             rc = cfg.rhocp
-            Nt = s.conv_weak(self.U, self.t) + s.conv_weak(self.u, self.Theta)
+            if getattr(self, "nonlinear", False):
+                Nt = s.conv_weak(self.u, self.t)                  # full equation: (u.grad) theta
+            else:
+                Nt = s.conv_weak(self.U, self.t) + s.conv_weak(self.u, self.Theta)
             Ft = -rc * Nt
             hist_ft = [Ft] + self.ftlag
             hist_t = [self.t] + self.tlag
@@ -413,6 +416,8 @@ class ExptA:
     def nonlinear_map(self, vec_in: NekDVector) -> NekDVector:
         """F(X) = Phi_tau(X) - X with the nonlinear integrator; the time step follows the CFL number of X."""
         self.set_baseflow(vec_in.v)
+        if self.cfg.ifheat:
+            self.Theta = vec_in.theta[0].copy()
         vec_out = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)
         self._reset_state(vec_in, False)
         self.nonlinear = True

@@ -82,3 +82,33 @@ def test_rayleigh_benard_onset(gpu_ctx, tmp_path):
     assert sig[1600.0] < 0 < sig[1800.0]
     ra_c = 1600.0 - sig[1600.0] * 200.0 / (sig[1800.0] - sig[1600.0])
     assert abs(ra_c - 1707.762) < 0.01 * 1707.762, (sig, ra_c)
+
+
+def test_nonlinear_map_with_temperature_matches_oracle(gpu_ctx):
+    """nonlinear_map of the temperature-coupled system (nek_system_temp of examples/thermosyphon/baseflow/tsyphon.usr:12,38):
+    full convection of velocity and temperature, buoyancy, F(X) = Phi_tau(X) - X including the scalar."""
+    hm = box_mesh((3, 2), 6, lengths=(2.0, 1.0), periodic=(True, False), deform=0.03)
+    sem = SEM(hm)
+    gm = host.Mesh(gpu_ctx, hm)
+    rng = np.random.default_rng(1)
+    oX, gX = NekDVector(sem, 1), host.nek_dvector(gm, 1)
+    for i in range(2):
+        oX.v[i][...] = sem.mask[i] * sem.dsavg(0.5 * np.sin(np.pi * sem.X[0] + i) * np.sin(np.pi * sem.X[1]))
+        gX.set_field(i, oX.v[i])
+    oX.theta[0][...] = 1.0 - sem.X[1] + 0.2 * sem.tmask * sem.dsavg(np.sin(np.pi * sem.X[0]) * np.sin(np.pi * sem.X[1]))
+    gX.set_field(host.THETA, oX.theta[0])
+    kw = dict(re=5.0, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=600, maxit_p=4000, cfl_limit=0.4)
+    heat = dict(conductivity=0.3, rhocp=1.0, buoy=(0.0, 20.0, 0.0))
+    oA = ExptA(sem, oX.v, LNSConfig(tau=0.1, ifheat=True, **kw, **heat), oX.theta[0])
+    oF = oA.nonlinear_map(oX)
+    gA = host.exptA_linop(0.1, gX, ifheat=1, **kw, **heat)
+    gA.init()
+    gF = host.nek_dvector(gm, 1)
+    host.check(gpu_ctx.lib.nlg_linop_nonlinear_map(gA.h, gX.h, gF.h))
+    assert gA.info()["nsteps"] == oA.nsteps
+    sc = max(np.abs(a).max() for a in oF.v)
+    for i in range(2):
+        assert np.max(np.abs(gF.get_field(i).reshape(sem.shape1) - oF.v[i])) < 1e-9 * sc
+    assert np.max(np.abs(gF.get_field(host.THETA).reshape(sem.shape1) - oF.theta[0])) < 1e-9 * np.abs(oF.theta[0]).max()
+    # Dirichlet values of the temperature stay: F vanishes on the walls
+    assert np.max(np.abs(gF.get_field(host.THETA).reshape(sem.shape1) * (1 - sem.tmask))) == 0.0
