@@ -35,6 +35,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
+                    help="shm: REHEARSAL of the N>1 path with all ranks on GPU 0 through the library's shared-memory "
+                         "validation transport (RCCL refuses two ranks per device); its numbers are not bench results")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nel", type=str, default="25,20,20", help="elements per direction (E = product)")
@@ -90,8 +93,12 @@ def main():
     nel = tuple(int(x) for x in args.nel.split(","))
     n, dim, m = args.lx1, len(nel), args.kdim
     E = int(np.prod(nel))
-    ctx = host.Context(local_rank)
-    if world > 1:
+    ctx = host.Context(local_rank if args.transport == "rccl" else 0)
+    if world > 1 and args.transport == "shm":
+        seg = ["/nlg_bench_%d" % os.getpid() if rank == 0 else None]
+        dist.broadcast_object_list(seg, src=0)
+        ctx.comm_init_shm(rank, world, seg[0], 256 << 20)
+    elif world > 1:
         uid = [host.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, world, uid[0])
@@ -268,7 +275,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if args.transport == "rccl" else "synthetic; REHEARSAL on one GPU (shm transport), not a result",
             "config": {"workload": "3-D deformed box E=%d (%s) lx1=%d (N=%d), Krylov dim m=%d, exptA: Re=%g bdf3/ext3 "
                                    "nsteps=%d(+2 history steps), tol 1e-9/1e-7, one Arnoldi iteration per step at k=m"
                                    % (E, "x".join(map(str, nel)), n, n - 1, m, args.re, args.nsteps),

@@ -51,6 +51,11 @@ int nlg_ctx_sync(nlg_ctx *ctx);
 int nlg_comm_unique_id(void *out128);
 int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id128);
 int nlg_ctx_rank(const nlg_ctx *ctx, int *rank, int *nranks);
+/* VALIDATION transport, not a product path: the same four collectives staged through a POSIX shared-memory
+ * segment `name` (slot_bytes per rank), so that several ranks can share ONE GPU — which RCCL refuses — and the
+ * whole distributed path except the RCCL calls themselves can be tested on a one-GPU box
+ * (tests/test_gpu_multirank.py).  Every wait times out with an error after 120 s. */
+int nlg_ctx_comm_init_shm(nlg_ctx *ctx, int rank, int nranks, const char *name, int64_t slot_bytes);
 /* Host-side planning step of the multi-rank gather-scatter (gslib's gs_setup behind opdssum,
  * src/vectors/real_vectors.f90:100): given the ascending unique labels of every rank, concatenated rank after
  * rank (counts[q] each), return for `rank` the labels it shares with every other rank (neigh_counts[q], and the

@@ -57,6 +57,7 @@ SIGNATURES = {
     "nlg_comm_unique_id": (C.c_int, [vp]),
     "nlg_ctx_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "nlg_ctx_rank": (C.c_int, [vp, c_int_p, c_int_p]),
+    "nlg_ctx_comm_init_shm": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "nlg_halo_plan": (C.c_int64, [C.c_int, C.c_int, c_int64_p, c_int64_p, c_int64_p, c_int64_p, C.c_int64]),
     "nlg_halo_boundary_labels": (C.c_int64, [C.c_int, C.c_int, C.c_int64, c_int64_p, c_int64_p, C.c_int64]),
     "nlg_halo_lists": (C.c_int64, [C.c_int, C.c_int, C.c_int64, c_int64_p, C.c_int, C.c_int, c_int64_p, c_int64_p, c_int64_p,

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libneklab_gpu.so")
-SOURCES = ["ctx.hip", "vec.hip", "sem.hip", "halo.hip", "pprec.hip", "lns.hip", "krylov.hip", "dense_eig.cpp"]
+SOURCES = ["ctx.hip", "shm_transport.hip", "vec.hip", "sem.hip", "halo.hip", "pprec.hip", "lns.hip", "krylov.hip", "dense_eig.cpp"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "neklab_gpu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
@@ -60,7 +60,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-            + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+            + ["-L/opt/rocm/lib", "-lrccl", "-lrocsolver", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

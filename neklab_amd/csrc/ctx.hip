@@ -16,12 +16,25 @@ void set_error(const char *fmt, ...) {
 }
 
 int allreduce_sum(nlg_ctx *ctx, double *d_buf, int count) {
+    if (ctx->shm) return shm_allreduce(ctx, d_buf, count, false);
     if (ctx->comm) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
     return 0;
 }
 
 int allreduce_max(nlg_ctx *ctx, double *d_buf, int count) {
+    if (ctx->shm) return shm_allreduce(ctx, d_buf, count, true);
     if (ctx->comm) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    return 0;
+}
+
+int allgather_f64(nlg_ctx *ctx, const double *d_in, double *d_out, int64_t count) {
+    if (ctx->shm)
+        return shm_allgather_i64(ctx, reinterpret_cast<const int64_t *>(d_in), reinterpret_cast<int64_t *>(d_out), count);
+    if (ctx->comm) {
+        NLG_NCCL(ncclAllGather(d_in, d_out, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+        return 0;
+    }
+    NLG_HIP(hipMemcpyAsync(d_out, d_in, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 
@@ -159,6 +172,7 @@ int nlg_ctx_destroy(nlg_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
+    shm_close(ctx);
     if (ctx->d_partial) hipFree(ctx->d_partial);
     if (ctx->d_scalars) hipFree(ctx->d_scalars);
     if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
@@ -188,6 +202,7 @@ int nlg_comm_unique_id(void *out128) {
 int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id128) {
     NLG_CHECK(ctx && unique_id128, "nlg_ctx_comm_init: NULL argument");
     NLG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "nlg_ctx_comm_init: bad rank %d / %d", rank, nranks);
+    NLG_CHECK(!ctx->comm && !ctx->shm, "nlg_ctx_comm_init: the context already has a communicator");
     NLG_HIP(hipSetDevice(ctx->device));
     ctx->rank = rank;
     ctx->nranks = nranks;

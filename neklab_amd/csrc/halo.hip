@@ -184,7 +184,7 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     nlg_ctx *ctx = m->ctx;
     nlg_halo &h = m->halo;
     h.active = false;
-    if (!ctx->comm) return 0;
+    if (!ctx->distributed()) return 0;
     hipStream_t st = ctx->stream;
     const int nr = ctx->nranks, me = ctx->rank;
     const int n = m->n, dim = m->dim, np1 = m->np1;
@@ -197,7 +197,10 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     NLG_HIP(hipMalloc(&d_cnt, sizeof(int64_t) * (nr + 1)));
     int64_t mycnt = (int64_t)ulab.size();
     NLG_HIP(hipMemcpy(d_cnt + nr, &mycnt, sizeof(int64_t), hipMemcpyHostToDevice));
-    NLG_NCCL(ncclAllGather(d_cnt + nr, d_cnt, 1, ncclInt64, ctx->comm, st));
+    if (ctx->shm)
+        NLG_TRY(shm_allgather_i64(ctx, d_cnt + nr, d_cnt, 1));
+    else
+        NLG_NCCL(ncclAllGather(d_cnt + nr, d_cnt, 1, ncclInt64, ctx->comm, st));
     std::vector<int64_t> counts(nr);
     NLG_HIP(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int64_t) * nr, hipMemcpyDeviceToHost, st));
     NLG_HIP(hipStreamSynchronize(st));
@@ -206,7 +209,10 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     NLG_HIP(hipMalloc(&d_lab, sizeof(int64_t) * (size_t)maxc * (nr + 1)));
     NLG_HIP(hipMemsetAsync(d_lab, 0xff, sizeof(int64_t) * (size_t)maxc * (nr + 1), st));
     NLG_HIP(hipMemcpyAsync(d_lab + (size_t)maxc * nr, ulab.data(), sizeof(int64_t) * ulab.size(), hipMemcpyHostToDevice, st));
-    NLG_NCCL(ncclAllGather(d_lab + (size_t)maxc * nr, d_lab, maxc, ncclInt64, ctx->comm, st));
+    if (ctx->shm)
+        NLG_TRY(shm_allgather_i64(ctx, d_lab + (size_t)maxc * nr, d_lab, maxc));
+    else
+        NLG_NCCL(ncclAllGather(d_lab + (size_t)maxc * nr, d_lab, maxc, ncclInt64, ctx->comm, st));
     std::vector<int64_t> padded((size_t)maxc * nr), concat;
     NLG_HIP(hipMemcpyAsync(padded.data(), d_lab, sizeof(int64_t) * padded.size(), hipMemcpyDeviceToHost, st));
     NLG_HIP(hipStreamSynchronize(st));
@@ -240,6 +246,7 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
         return 0;
     };
     NLG_TRY(up(send_idx, &h.d_send_idx));
+    h.h_cidx = cidx;
     NLG_TRY(up(roff, &h.d_roff));
     NLG_TRY(up(rpos, &h.d_rpos));
     NLG_TRY(up(coff, &h.d_coff));
@@ -275,13 +282,17 @@ int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped)
         hipLaunchKernelGGL(k_halo_pack<2>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
     else
         hipLaunchKernelGGL(k_halo_pack<3>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
-    NLG_NCCL(ncclGroupStart());
-    for (size_t q = 0; q < h.neigh.size(); ++q)
-        for (int c = 0; c < nf; ++c) {
-            NLG_NCCL(ncclSend(h.d_send + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
-            NLG_NCCL(ncclRecv(h.d_recv + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
-        }
-    NLG_NCCL(ncclGroupEnd());
+    if (ctx->shm) {
+        NLG_TRY(shm_exchange(ctx, h, nf));
+    } else {
+        NLG_NCCL(ncclGroupStart());
+        for (size_t q = 0; q < h.neigh.size(); ++q)
+            for (int c = 0; c < nf; ++c) {
+                NLG_NCCL(ncclSend(h.d_send + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
+                NLG_NCCL(ncclRecv(h.d_recv + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
+            }
+        NLG_NCCL(ncclGroupEnd());
+    }
     const int g2 = (int)((h.nlab + NT - 1) / NT);
     if (nf == 1)
         hipLaunchKernelGGL(k_halo_unpack<1>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);

@@ -65,6 +65,10 @@ struct nlg_prof_slot {
     int64_t count = 0;
 };
 
+namespace nlg {
+struct nlg_shm;   // host-staged validation transport (shm_transport.hip)
+}
+
 struct nlg_ctx {
     int prof_on = 0;
     nlg_prof_slot prof[P_COUNT];
@@ -73,6 +77,8 @@ struct nlg_ctx {
     hipStream_t stream2 = nullptr;            // side stream: coarse-grid branch of the pressure preconditioner
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ncclComm_t comm = nullptr;
+    nlg::nlg_shm *shm = nullptr;              // set only by nlg_ctx_comm_init_shm (several test ranks on one GPU)
+    bool distributed() const { return comm != nullptr || shm != nullptr; }
     int rank = 0, nranks = 1;
     // reduction workspace
     double *d_partial = nullptr;   // [kMaxVecReduce * kMaxBlocksReduce]
@@ -143,6 +149,7 @@ struct nlg_halo {
     int *d_coff = nullptr, *d_cidx = nullptr;   // per distinct shared label: all local copies
     int *d_send_idx_fg = nullptr, *d_cidx_fg = nullptr;   // d_send_idx / d_cidx for the face-grouped element layout
     double *d_send = nullptr, *d_recv = nullptr;
+    std::vector<int> h_cidx;         // host copy of d_cidx: every local dof that another rank shares
 };
 
 // two-level preconditioner of the pressure operator (pprec.hip)
@@ -162,7 +169,9 @@ struct nlg_pprec {
     double *d_Sx = nullptr, *d_lamx = nullptr, *d_W = nullptr, *d_wq = nullptr;   // d_wq: count^-1/2 weights [E][n2^3]
     double thrx = 0.0;
     int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;
-    double *d_Ainv = nullptr;                    // dense inverse on the aggregates
+    double *d_Ainv = nullptr;                    // dense inverse on the aggregates: this rank's rows, [na][ncols]
+    int na_max = 0, ncols = 0;                   // several ranks: ncols = nranks * na_max columns (global aggregate level)
+    double *d_rag = nullptr;                     // [ncols] aggregate residuals of all ranks (all-gather of d_ra)
     double *d_rc = nullptr, *d_x = nullptr, *d_ra = nullptr, *d_xa = nullptr;
 };
 
@@ -254,6 +263,11 @@ int dev_dot(const nlg_vec *a, const nlg_vec *b, int slot);
 int scalars_to_host(nlg_ctx *ctx, int first, int count, double *out);   // syncs the stream
 int allreduce_sum(nlg_ctx *ctx, double *d_buf, int count);
 int allreduce_max(nlg_ctx *ctx, double *d_buf, int count);
+int allgather_f64(nlg_ctx *ctx, const double *d_in, double *d_out, int64_t count);   // count doubles per rank
+int shm_allreduce(nlg_ctx *ctx, double *d_buf, int count, bool is_max);
+int shm_allgather_i64(nlg_ctx *ctx, const int64_t *d_in, int64_t *d_out, int64_t count);
+int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf);
+void shm_close(nlg_ctx *ctx);
 
 int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc);
 int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *w, double sign, const double *d_hh = nullptr,

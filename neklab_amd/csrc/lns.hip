@@ -622,7 +622,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     CF3 cr = cf3(P.r, nf);
     const Red rd_std = {{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
     auto reduce_post = [&](const Red &rd, int nsums, int gate, int mode) -> int {
-        if (!ctx->comm) {
+        if (!ctx->distributed()) {
             hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
                                P.inv_n, 1);
         } else {
@@ -1447,7 +1447,7 @@ int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_
     NLG_CHECK(op && line_label, "nlg_linop_set_projection: NULL argument");
     nlg_mesh *m = op->mesh;
     NLG_CHECK(idir >= 1 && idir <= m->dim, "nlg_linop_set_projection: idir %d out of range", idir);
-    NLG_CHECK(!m->ctx->comm, "nlg_linop_set_projection: lines across ranks are not supported (single rank only)");
+    NLG_CHECK(!m->ctx->distributed(), "nlg_linop_set_projection: lines across ranks are not supported (single rank only)");
     NLG_CHECK(op->inited, "nlg_linop_set_projection: call init first");
     NLG_CHECK((line_label2 == nullptr) == (x2 == nullptr), "nlg_linop_set_projection: pressure-mesh labels and coordinates go together");
     hipStream_t st = m->ctx->stream;

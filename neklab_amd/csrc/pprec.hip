@@ -31,6 +31,8 @@
 #include <numeric>
 #include <unordered_map>
 
+#include <rocsolver/rocsolver.h>
+
 #include "internal.h"
 
 using namespace nlg;
@@ -528,6 +530,56 @@ __global__ __launch_bounds__(NT) void k_q1_probe(int64_t E, int n2, Hat hat, con
     p[i] = w;
 }
 
+// probing vector of the GLOBAL aggregate operator (several ranks): p = R_1 P_a e_a, the prolongation of the indicator
+// of aggregate `a` (a < 0: this rank is not the probing one, p = 0)
+template <int DIM>
+__global__ __launch_bounds__(NT) void k_agg_probe(int64_t E, int n2, Hat hat, const int *__restrict__ vg,
+                                                  const int *__restrict__ agg, int a, double *__restrict__ p) {
+    constexpr int NC = 1 << DIM;
+    const int np2 = DIM == 3 ? n2 * n2 * n2 : n2 * n2;
+    const int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x;
+    if (i >= E * np2) return;
+    double w = 0.0;
+    if (a >= 0) {
+        const int64_t e = i / np2;
+        const int q = (int)(i % np2);
+        const double ha = hat.h1[q % n2], hb = hat.h1[(q / n2) % n2];
+        const double hc = DIM == 3 ? hat.h1[q / (n2 * n2)] : 0.0;
+        for (int c = 0; c < NC; ++c)
+            if (agg[vg[e * NC + c]] == a) {
+                double t = ((c & 1) ? ha : 1.0 - ha) * ((c & 2) ? hb : 1.0 - hb);
+                if (DIM == 3) t *= (c & 4) ? hc : 1.0 - hc;
+                w += t;
+            }
+    }
+    p[i] = w;
+}
+
+// column `col` of this rank's rows of the global aggregate operator
+__global__ void k_store_col(int na, const double *__restrict__ ra, double *__restrict__ rows, int64_t ncols, int64_t col) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) rows[(size_t)i * ncols + col] = ra[i];
+}
+
+// gathered operator -> invertible: unit diagonal on the padding rows, symmetrised, constant null space shifted
+__global__ void k_glob_fix(int64_t n, int na_max, const int *__restrict__ na_of, double alpha, double *__restrict__ A) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n || j < i) return;
+    const bool ri = (int)(i % na_max) < na_of[i / na_max], rj = (int)(j % na_max) < na_of[j / na_max];
+    double v;
+    if (ri && rj)
+        v = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]) + alpha;
+    else
+        v = i == j ? 1.0 : 0.0;
+    A[(size_t)i * n + j] = v;
+    A[(size_t)j * n + i] = v;
+}
+
+__global__ void k_mirror_upper(int n, double *__restrict__ A) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j < i) A[(size_t)i * n + j] = A[(size_t)j * n + i];
+}
+
 // ra[a] = sum of rr over the members of aggregate a, one wave per aggregate
 __global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na, const int *__restrict__ ap,
                                                      const int *__restrict__ am, const double *__restrict__ rr,
@@ -544,14 +596,14 @@ __global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na,
 }
 
 // xa = Ainv ra (dense, row-major), one wave per row
-__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, const double *__restrict__ Ainv,
+__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, int ncols, const double *__restrict__ Ainv,
                                                    const double *__restrict__ ra, double *__restrict__ xa) {
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     if (row >= na) return;
     double s = 0.0;
-    for (int j = lane; j < na; j += 64) s += Ainv[(size_t)row * na + j] * ra[j];
+    for (int j = lane; j < ncols; j += 64) s += Ainv[(size_t)row * ncols + j] * ra[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) xa[row] = s;
@@ -797,7 +849,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     // ---- 1b. overlapping variant: extended 1-D operators from the line left neighbour | element | right neighbour
     // (3-D: exchange array in the face-grouped layout; 2-D: natural layout)
     if (((dim == 3 && m->gs.d_indices_fg) || dim == 2) && m->gs.npairs > 0 && n <= 8) {
-        // normal edge length of the face neighbours, through the (rank-local) gather-scatter: every element puts its own
+        // normal edge length of the face neighbours, through the gather-scatter: every element puts its own
         // normal length on the interior points of its faces, the sum minus the own value is the neighbour's
         std::vector<double> hw((size_t)m->lvn, 0.0);
         auto face_node = [&](int dd, int side, int u, int v) {
@@ -816,12 +868,10 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         NLG_CHECK(dw, "pprec_setup: scratch allocation failed");
         NLG_HIP(hipMemcpyAsync(dw, hw.data(), sizeof(double) * (size_t)m->lvn, hipMemcpyHostToDevice, st));
         {
-            const bool halo_was = m->halo.active;
-            m->halo.active = false;
+            // halo on: a face neighbour on another rank counts like a local one (its ghost layer travels with the
+            // halo exchange of the array W, pprec_fine)
             double *f1[1] = {dw};
-            const int rc = sem_gs(m, f1, 1);
-            m->halo.active = halo_was;
-            if (rc) return rc;
+            NLG_TRY(sem_gs(m, f1, 1));
         }
         NLG_HIP(hipMemcpyAsync(hw.data(), dw, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToHost, st));
         NLG_HIP(hipStreamSynchronize(st));
@@ -1048,6 +1098,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     }
     // ---- 4. aggregates of vertices (greedy over the vertices that share an element) and the dense inverse on them
     std::vector<int> agg((size_t)nvert, -1);
+    std::vector<char> viface((size_t)nvert, 0);   // vertex on a rank boundary
     int na = 0;
     int exact_max = 2048;
     if (const char *ev = getenv("NLG_COARSE_EXACT_MAX")) exact_max = atoi(ev);
@@ -1065,6 +1116,39 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
             out.erase(std::unique(out.begin(), out.end()), out.end());
         };
         std::vector<int> nb;
+        // several ranks: the hats of the vertices on a rank boundary are cut there, and the two halves of one hat are
+        // coupled as strongly as the operator penalises a jump, which inflates the diagonal the vertex-level Jacobi term
+        // divides by.  Such vertices therefore become aggregates of their own (mode 1): the aggregate level is global,
+        // knows the coupling between the halves and solves them exactly; their Jacobi term is dropped.
+        // 3 x 16^3 elements, pressure iterations per time step: plain 2x2x2 aggregates 41.75, planar 2x2 patches of
+        // boundary vertices 21 (mode 2), the same without their Jacobi term 16.5 (mode 3), singletons 12.75 (mode 1);
+        // one rank 12.5.
+        int iface_mode = 1;
+        if (const char *ev = getenv("NLG_IFACE_AGG")) iface_mode = atoi(ev);
+        if (!(ctx->distributed() && ctx->nranks > 1)) iface_mode = 0;
+        if (iface_mode) {
+            for (int idx : m->halo.h_cidx) {
+                const int64_t e = idx / np1;
+                const int pt = idx % np1;
+                for (int c = 0; c < NC; ++c) {
+                    const int i = (c & 1) ? n - 1 : 0, j = (c & 2) ? n - 1 : 0, k = (c & 4) ? n - 1 : 0;
+                    if (pt == i + n * (j + n * k)) viface[vg[(size_t)e * NC + c]] = 1;
+                }
+            }
+            for (int64_t e = 0; e < E; ++e) {
+                int cnt = 0;
+                for (int c = 0; c < NC; ++c) {
+                    const int v = vg[(size_t)e * NC + c];
+                    if (viface[v] && agg[v] < 0) ++cnt;
+                }
+                if (iface_mode == 1 ? cnt < 1 : cnt < NC / 2) continue;
+                for (int c = 0; c < NC; ++c) {
+                    const int v = vg[(size_t)e * NC + c];
+                    if (viface[v] && agg[v] < 0) agg[v] = iface_mode == 1 ? na++ : na;
+                }
+                if (iface_mode != 1) ++na;
+            }
+        }
         // an element whose corners are all free becomes an aggregate (2 x 2 x 2 vertices on structured meshes): the
         // aggregate-level operator stays small enough for a dense inverse (nvert / 8 rows) and, unlike the
         // vertex-plus-all-neighbours aggregates used first (27 vertices), accurate enough for the overlapping local
@@ -1077,57 +1161,51 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
             for (int c = 0; c < NC; ++c) agg[vg[(size_t)e * NC + c]] = na;
             ++na;
         }
+        if (iface_mode)   // the far-side corners of the boundary elements
+            for (int64_t e = 0; e < E; ++e) {
+                int cnt = 0;
+                for (int c = 0; c < NC; ++c)
+                    if (agg[vg[(size_t)e * NC + c]] < 0) ++cnt;
+                if (cnt < NC / 2) continue;
+                for (int c = 0; c < NC; ++c)
+                    if (agg[vg[(size_t)e * NC + c]] < 0) agg[vg[(size_t)e * NC + c]] = na;
+                ++na;
+            }
         for (int v = 0; v < nvert; ++v) {
             if (agg[v] >= 0) continue;
             near(v, nb);
             int best = -1;
             double bv = -1.0;
-            for (int w : nb) {
-                if (w == v || agg[w] < 0) continue;
-                auto it = rows[v].find(w);
-                const double cv = it == rows[v].end() ? 0.0 : std::fabs(it->second);
-                if (cv > bv) {
-                    bv = cv;
-                    best = agg[w];
+            for (int pass = 0; pass < 2 && best < 0; ++pass)   // first among the vertices of the same kind
+                for (int w : nb) {
+                    if (w == v || agg[w] < 0 || (pass == 0 && viface[w] != viface[v])) continue;
+                    auto it = rows[v].find(w);
+                    const double cv = it == rows[v].end() ? 0.0 : std::fabs(it->second);
+                    if (cv > bv) {
+                        bv = cv;
+                        best = agg[w];
+                    }
                 }
-            }
             agg[v] = best >= 0 ? best : na++;
         }
+        if (iface_mode == 1 || iface_mode == 3)
+            for (int v = 0; v < nvert; ++v)
+                if (viface[v]) dinv[v] = 0.0;
     }
     std::vector<double> Acc((size_t)na * na, 0.0);
     for (int u = 0; u < nvert; ++u)
         for (int q = rp[u]; q < rp[u + 1]; ++q) Acc[(size_t)agg[u] * na + agg[ci[q]]] += av[q];
     for (int i = 0; i < na; ++i)
         for (int j = i + 1; j < na; ++j) Acc[(size_t)i * na + j] = Acc[(size_t)j * na + i] = 0.5 * (Acc[(size_t)i * na + j] + Acc[(size_t)j * na + i]);
-    if (!m->has_outflow && ctx->nranks <= 1) {
+    const bool multi = ctx->distributed() && ctx->nranks > 1;
+    if (!m->has_outflow && !multi) {
         // constant null space (the hats sum to one): shift it so that the inverse acts as the pseudo-inverse on
-        // mean-free data.  With several ranks the rank-local operator (no halo) is positive definite as it is.
+        // mean-free data.  (Several ranks: the shift is applied to the gathered global operator below.)
         double tr = 0.0;
         for (int i = 0; i < na; ++i) tr += Acc[(size_t)i * na + i];
         const double alpha = tr / na / na;   // the null vector of the aggregated operator is the vector of ones
         for (int i = 0; i < na; ++i)
             for (int j = 0; j < na; ++j) Acc[(size_t)i * na + j] += alpha;
-    }
-    NLG_TRY(up(Acc, &P.d_Ainv));
-    {
-        double *rk = nullptr, *ck = nullptr;
-        int *bad = nullptr, hbad = 0;
-        NLG_HIP(hipMalloc(&rk, sizeof(double) * (size_t)na));
-        NLG_HIP(hipMalloc(&ck, sizeof(double) * (size_t)na));
-        NLG_HIP(hipMalloc(&bad, sizeof(int)));
-        NLG_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
-        const unsigned gx = (unsigned)((na + NT - 1) / NT);
-        for (int k = 0; k < na; ++k) {
-            hipLaunchKernelGGL(k_gj_prep, dim3(gx), dim3(NT), 0, st, na, k, (const double *)P.d_Ainv, rk, ck, bad);
-            hipLaunchKernelGGL(k_gj_update, dim3(gx, (unsigned)na), dim3(NT), 0, st, na, k, P.d_Ainv, (const double *)rk, (const double *)ck);
-        }
-        NLG_HIP(hipGetLastError());
-        NLG_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
-        NLG_HIP(hipStreamSynchronize(st));
-        hipFree(rk);
-        hipFree(ck);
-        hipFree(bad);
-        NLG_CHECK(hbad == 0, "pprec_setup: aggregate operator is not positive definite");
     }
     std::vector<int> ap((size_t)na + 1, 0), am((size_t)nvert);
     for (int v = 0; v < nvert; ++v) ap[agg[v] + 1]++;
@@ -1146,7 +1224,188 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     NLG_TRY(up(am, &P.d_am));
     NLG_HIP(hipMalloc(&P.d_tq, sizeof(double) * (size_t)E * NC));
     for (double **v : {&P.d_rc, &P.d_x}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(nvert, 1)));
-    for (double **v : {&P.d_ra, &P.d_xa}) NLG_HIP(hipMalloc(v, sizeof(double) * (size_t)std::max(na, 1)));
+    NLG_HIP(hipMalloc(&P.d_xa, sizeof(double) * (size_t)std::max(na, 1)));
+
+    auto gj_inverse = [&](double *dA, int nn) -> int {
+        double *rk = nullptr, *ck = nullptr;
+        int *bad = nullptr, hbad = 0;
+        NLG_HIP(hipMalloc(&rk, sizeof(double) * (size_t)nn));
+        NLG_HIP(hipMalloc(&ck, sizeof(double) * (size_t)nn));
+        NLG_HIP(hipMalloc(&bad, sizeof(int)));
+        NLG_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+        const unsigned gx = (unsigned)((nn + NT - 1) / NT);
+        for (int k = 0; k < nn; ++k) {
+            hipLaunchKernelGGL(k_gj_prep, dim3(gx), dim3(NT), 0, st, nn, k, (const double *)dA, rk, ck, bad);
+            hipLaunchKernelGGL(k_gj_update, dim3(gx, (unsigned)nn), dim3(NT), 0, st, nn, k, dA, (const double *)rk, (const double *)ck);
+        }
+        NLG_HIP(hipGetLastError());
+        NLG_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        hipFree(rk);
+        hipFree(ck);
+        hipFree(bad);
+        NLG_CHECK(hbad == 0, "pprec_setup: aggregate operator is not positive definite");
+        return 0;
+    };
+
+    // large operators (several ranks): Cholesky factorisation and inverse from rocSOLVER — set-up only, a plain dense
+    // library call; the two-launches-per-pivot Gauss-Jordan above streams the matrix once per pivot (18k unknowns: 25 s)
+    auto spd_inverse_dev = [&](double *dA, int nn) -> int {
+        int lib_min = 4096;
+        if (const char *ev = getenv("NLG_LIB_INVERSE_MIN")) lib_min = atoi(ev);
+        if (nn < lib_min) return gj_inverse(dA, nn);
+        rocblas_handle hb = nullptr;
+        NLG_CHECK(rocblas_create_handle(&hb) == rocblas_status_success, "pprec_setup: rocblas_create_handle failed");
+        rocblas_set_stream(hb, st);
+        int *dinfo = nullptr, hinfo[2] = {0, 0};
+        NLG_HIP(hipMalloc(&dinfo, 2 * sizeof(int)));
+        const rocblas_status s1 = rocsolver_dpotrf(hb, rocblas_fill_lower, nn, dA, nn, dinfo);
+        const rocblas_status s2 = s1 == rocblas_status_success ? rocsolver_dpotri(hb, rocblas_fill_lower, nn, dA, nn, dinfo + 1) : s1;
+        NLG_HIP(hipMemcpyAsync(hinfo, dinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        hipFree(dinfo);
+        rocblas_destroy_handle(hb);
+        NLG_CHECK(s1 == rocblas_status_success && s2 == rocblas_status_success, "pprec_setup: rocSOLVER potrf/potri failed (%d, %d)", (int)s1, (int)s2);
+        NLG_CHECK(hinfo[0] == 0 && hinfo[1] == 0, "pprec_setup: aggregate operator is not positive definite (potrf info %d)", hinfo[0]);
+        // column-major lower triangle = row-major upper triangle: mirror it
+        hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)((nn + 255) / 256), (unsigned)nn), dim3(256), 0, st, nn, dA);
+        NLG_HIP(hipGetLastError());
+        return 0;
+    };
+
+    if (!multi) {
+        NLG_TRY(up(Acc, &P.d_Ainv));
+        NLG_TRY(gj_inverse(P.d_Ainv, na));
+        P.na_max = P.ncols = na;
+        NLG_HIP(hipMalloc(&P.d_ra, sizeof(double) * (size_t)std::max(na, 1)));
+        P.ready = true;
+        return 0;
+    }
+
+    // ---- 5. several ranks: ONE aggregate level over all ranks.  The vertex hats are cut at the rank boundaries (the
+    // pressure space is discontinuous, so the cut functions are admissible), hence the diagonal block of a rank is the
+    // halo-free operator assembled above and only the aggregates that touch an element with a shared node couple to
+    // other ranks.  Those columns are probed with the global operator (halo on), one aggregate of one rank at a time;
+    // the rows are gathered, the (12k x 12k at 8 x 10^4 elements) operator is inverted redundantly on every rank
+    // and each rank keeps its own rows of the inverse.  Per application: one all-gather of na_max doubles.
+    // (Rank-local coarse solves — the first version — took 45 pressure iterations on 2 x 512 elements against 14
+    // on one rank: the block-Jacobi coarse solve over-corrects the nearly constant-per-rank modes.)
+    {
+        const int nr = ctx->nranks, me = ctx->rank;
+        NLG_CHECK(st == ctx->stream, "pprec_setup: internal (stream)");
+        auto gather_host = [&](const std::vector<double> &in, std::vector<double> &out) -> int {
+            double *di = nullptr, *d_o = nullptr;
+            const size_t c = in.size();
+            NLG_HIP(hipMalloc(&di, sizeof(double) * c));
+            NLG_HIP(hipMalloc(&d_o, sizeof(double) * c * nr));
+            NLG_HIP(hipMemcpyAsync(di, in.data(), sizeof(double) * c, hipMemcpyHostToDevice, st));
+            NLG_TRY(allgather_f64(ctx, di, d_o, (int64_t)c));
+            out.resize(c * nr);
+            NLG_HIP(hipMemcpyAsync(out.data(), d_o, sizeof(double) * c * nr, hipMemcpyDeviceToHost, st));
+            NLG_HIP(hipStreamSynchronize(st));
+            hipFree(di);
+            hipFree(d_o);
+            return 0;
+        };
+        // aggregates whose support holds an element with a node shared with another rank
+        std::vector<char> velem((size_t)E, 0), aflag((size_t)na, 0);
+        for (int idx : m->halo.h_cidx) velem[idx / np1] = 1;
+        for (int64_t e = 0; e < E; ++e)
+            if (velem[e])
+                for (int c = 0; c < NC; ++c) aflag[agg[vg[(size_t)e * NC + c]]] = 1;
+        std::vector<int> ifa;
+        for (int a = 0; a < na; ++a)
+            if (aflag[a]) ifa.push_back(a);
+        double tr = 0.0;
+        for (int i = 0; i < na; ++i) tr += Acc[(size_t)i * na + i];
+        std::vector<double> info;
+        NLG_TRY(gather_host({(double)na, (double)ifa.size(), tr}, info));
+        std::vector<int> na_all(nr), ni_all(nr);
+        int na_max = 0, ni_max = 0;
+        double tr_all = 0.0, nreal = 0.0;
+        for (int q = 0; q < nr; ++q) {
+            na_all[q] = (int)info[3 * q];
+            ni_all[q] = (int)info[3 * q + 1];
+            tr_all += info[3 * q + 2];
+            nreal += na_all[q];
+            na_max = std::max(na_max, na_all[q]);
+            ni_max = std::max(ni_max, ni_all[q]);
+        }
+        const int64_t ntot = (int64_t)nr * na_max;
+        NLG_CHECK(ntot <= 60000, "pprec_setup: global aggregate level of %lld unknowns is too large for the dense inverse", (long long)ntot);
+        std::vector<double> ifa_pad((size_t)std::max(ni_max, 1), -1.0), ifa_all;
+        for (size_t i = 0; i < ifa.size(); ++i) ifa_pad[i] = ifa[i];
+        NLG_TRY(gather_host(ifa_pad, ifa_all));
+        // this rank's rows: diagonal block from the halo-free assembly, the rest by probing
+        double *d_rows = nullptr, *d_full = nullptr;
+        {
+            std::vector<double> rowsH((size_t)na_max * ntot, 0.0);
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < na; ++j) rowsH[(size_t)i * ntot + (size_t)me * na_max + j] = Acc[(size_t)i * na + j];
+            NLG_TRY(up(rowsH, &d_rows));
+        }
+        NLG_HIP(hipMalloc(&P.d_ra, sizeof(double) * (size_t)na_max));
+        NLG_HIP(hipMemsetAsync(P.d_ra, 0, sizeof(double) * (size_t)na_max, st));
+        NLG_HIP(hipMalloc(&P.d_rag, sizeof(double) * (size_t)ntot));
+        double *pp = sem_scratch2(m, 0), *ep = sem_scratch2(m, 1);
+        NLG_CHECK(pp && ep, "pprec_setup: scratch allocation failed");
+        const unsigned gp = (unsigned)((m->lpn + NT - 1) / NT), ge = (unsigned)((E + 3) / 4);
+        const size_t stride_i = (size_t)std::max(ni_max, 1);
+        for (int r = 0; r < nr; ++r)
+            for (int i = 0; i < ni_all[r]; ++i) {
+                const int a_src = (int)ifa_all[(size_t)r * stride_i + i];
+                const int a = me == r ? a_src : -1;
+                if (dim == 3) {
+                    hipLaunchKernelGGL(k_agg_probe<3>, dim3(gp), dim3(NT), 0, st, E, n2, hat, (const int *)P.d_vg, (const int *)P.d_agg, a, pp);
+                } else {
+                    hipLaunchKernelGGL(k_agg_probe<2>, dim3(gp), dim3(NT), 0, st, E, n2, hat, (const int *)P.d_vg, (const int *)P.d_agg, a, pp);
+                }
+                NLG_TRY(sem_cdabdtp(m, pp, ep));
+                if (me == r) continue;   // own block: already there
+                if (dim == 3) {
+                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr);
+                } else {
+                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr);
+                }
+                hipLaunchKernelGGL(k_q1_gather, dim3((nvert + NT - 1) / NT), dim3(NT), 0, st, (const double *)nullptr, nvert, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, 0.0, P.d_x);
+                hipLaunchKernelGGL(k_agg_restrict, dim3((na + 3) / 4), dim3(NT), 0, st, (const double *)nullptr, na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
+                hipLaunchKernelGGL(k_store_col, dim3((na + 255) / 256), dim3(256), 0, st, na, (const double *)P.d_ra, d_rows, ntot, (int64_t)r * na_max + a_src);
+            }
+        NLG_HIP(hipGetLastError());
+        NLG_HIP(hipMalloc(&d_full, sizeof(double) * (size_t)ntot * ntot));
+        NLG_TRY(allgather_f64(ctx, d_rows, d_full, (int64_t)na_max * ntot));
+        if (getenv("NLG_PPREC_DEBUG")) {
+            std::vector<double> F((size_t)ntot * ntot);
+            NLG_HIP(hipMemcpyAsync(F.data(), d_full, sizeof(double) * F.size(), hipMemcpyDeviceToHost, st));
+            NLG_HIP(hipStreamSynchronize(st));
+            double amax = 0.0, asym = 0.0, rowsum = 0.0, offb = 0.0;
+            for (int64_t i = 0; i < ntot; ++i) {
+                double rs = 0.0;
+                for (int64_t j = 0; j < ntot; ++j) {
+                    amax = std::max(amax, std::fabs(F[i * ntot + j]));
+                    asym = std::max(asym, std::fabs(F[i * ntot + j] - F[j * ntot + i]));
+                    rs += F[i * ntot + j];
+                    if (i / na_max != j / na_max) offb = std::max(offb, std::fabs(F[i * ntot + j]));
+                }
+                rowsum = std::max(rowsum, std::fabs(rs));
+            }
+            fprintf(stderr, "[pprec rank %d] ntot %lld na %d ni %d  max|A| %.3e  asym %.3e  max|row sum| %.3e  max off-block %.3e\n", me,
+                    (long long)ntot, na, (int)ifa.size(), amax, asym, rowsum, offb);
+        }
+        int *d_na_of = nullptr;
+        NLG_TRY(up(na_all, &d_na_of));
+        const double alpha = m->has_outflow ? 0.0 : tr_all / nreal / nreal;
+        hipLaunchKernelGGL(k_glob_fix, dim3((unsigned)((ntot + 255) / 256), (unsigned)ntot), dim3(256), 0, st, ntot, na_max, (const int *)d_na_of, alpha, d_full);
+        NLG_TRY(spd_inverse_dev(d_full, (int)ntot));
+        NLG_HIP(hipMalloc(&P.d_Ainv, sizeof(double) * (size_t)std::max(na, 1) * ntot));
+        NLG_HIP(hipMemcpyAsync(P.d_Ainv, d_full + (size_t)me * na_max * ntot, sizeof(double) * (size_t)na * ntot, hipMemcpyDeviceToDevice, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        hipFree(d_full);
+        hipFree(d_rows);
+        hipFree(d_na_of);
+        P.na_max = na_max;
+        P.ncols = (int)ntot;
+    }
     P.ready = true;
     return 0;
 }
@@ -1172,10 +1431,26 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
     }
     hipLaunchKernelGGL(k_q1_gather, dim3((nv + NT - 1) / NT), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x);
     hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
-    hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_Ainv, P.d_ra, P.d_xa);
+    const double *ra = P.d_ra;
+    if (P.ncols != P.na) {   // several ranks: the aggregate level is global
+        NLG_CHECK(st == m->ctx->stream, "pprec: the global aggregate level runs on the context's stream");
+        NLG_TRY(allgather_f64(m->ctx, P.d_ra, P.d_rag, P.na_max));
+        ra = P.d_rag;
+    }
+    hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.ncols, P.d_Ainv, ra, P.d_xa);
     NLG_HIP(hipGetLastError());
     *xc = P.d_x;   // the Jacobi term; pprec_fine adds xa[agg[v]] while prolonging
     return 0;
+}
+
+// ghost layers of face neighbours on other ranks: the copies of a face on a rank boundary are summed by the halo
+// exchange exactly as the pairs kernel sums the two local copies of an interior face (edge and corner slots of W
+// are never written and travel as zeros)
+static int overlap_halo(nlg_mesh *m, hipStream_t st, bool face_grouped) {
+    if (!m->halo.active) return 0;
+    NLG_CHECK(st == m->ctx->stream, "pprec: the overlap exchange across ranks runs on the context's stream");
+    double *f1[1] = {m->pprec.d_W};
+    return halo_exchange(m, f1, 1, face_grouped);
 }
 
 // Fine part: z = sum_e R_e^T Etilde_e^-1 R_e r (+ R_1 xc when xc is given), launched on `st`.
@@ -1192,6 +1467,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         NLG_CHECK(!rz_part, "pprec: fused sums exist for the 3-D kernels only");
         const unsigned gb = (unsigned)((E + 3) / 4);
         NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        NLG_TRY(overlap_halo(m, st, false));
 #define FX2_CASE(N_)                                                                                                  \
     case N_:                                                                                                          \
         hipLaunchKernelGGL((k_fdm_ext2<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
@@ -1202,6 +1478,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         }
 #undef FX2_CASE
         NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        NLG_TRY(overlap_halo(m, st, false));
         const unsigned gf = (unsigned)((E * m->np2 + NT - 1) / NT);
 #define FF2_CASE(N_)                                                                                                  \
     case N_:                                                                                                          \
@@ -1220,6 +1497,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         NLG_CHECK(P.overlap && m->dim == 3, "pprec: the overlapping variant is not set up for this mesh");
         const unsigned gb = (unsigned)((E + 3) / 4);
         NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
+        NLG_TRY(overlap_halo(m, st, true));
 #define FX_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
         hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
@@ -1230,6 +1508,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         }
 #undef FX_CASE
         NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
+        NLG_TRY(overlap_halo(m, st, true));
 #define FF_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
         hipLaunchKernelGGL((k_sch_finish<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
@@ -1265,7 +1544,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
 
 void pprec_free(nlg_mesh *m) {
     nlg_pprec &P = m->pprec;
-    double *dp[] = {P.d_S, P.d_invden, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_ra, P.d_xa, P.d_tq, P.d_Sx, P.d_lamx, P.d_W, P.d_wq};
+    double *dp[] = {P.d_S, P.d_invden, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_ra, P.d_xa, P.d_rag, P.d_tq, P.d_Sx, P.d_lamx, P.d_W, P.d_wq};
     for (double *p : dp)
         if (p) hipFree(p);
     int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i};

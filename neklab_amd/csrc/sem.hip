@@ -2224,7 +2224,7 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         for (int64_t q = 0; q < m->lpn; ++q) v += h[q];
         m->volvm2 = v;
         m->lpn_global = m->lpn;
-        if (ctx->comm) {   // global volumes and pressure dof count
+        if (ctx->distributed()) {   // global volumes and pressure dof count
             double hv[3] = {m->volvm1, m->volvm2, (double)m->lpn}, *dv = ctx->d_scalars + 4010;
             NLG_HIP(hipMemcpyAsync(dv, hv, sizeof(hv), hipMemcpyHostToDevice, s));
             NLG_TRY(allreduce_sum(ctx, dv, 3));

@@ -534,7 +534,7 @@ int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_o
     ProfScope ps(ctx, P_BLOCKDOT);
     hipLaunchKernelGGL(k_block_dot<KB>, dim3(nblk, v0->ncomp, (k + KB - 1) / KB), dim3(NT), 0, ctx->stream, b->d,
                        b->stride, k, w->d, b->mesh->d_bm1, b->mesh->lvs, nblk, nper, ctx->d_partial);
-    if (ctx->comm) {
+    if (ctx->distributed()) {
         hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out, 0,
                            (double *)nullptr);
         NLG_TRY(allreduce_sum(ctx, d_out, k));

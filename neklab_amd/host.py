@@ -39,6 +39,11 @@ class Context:
         check(self.lib.nlg_ctx_comm_init(self.h, rank, nranks, C.cast(buf, vp)))
         self.rank, self.nranks = rank, nranks
 
+    def comm_init_shm(self, rank: int, nranks: int, name: str, slot_bytes: int = 64 << 20):
+        """Validation transport (several test ranks on one GPU), see include/neklab_gpu.h."""
+        check(self.lib.nlg_ctx_comm_init_shm(self.h, rank, nranks, name.encode(), slot_bytes))
+        self.rank, self.nranks = rank, nranks
+
     @staticmethod
     def unique_id() -> bytes:
         lib = _lib.load()

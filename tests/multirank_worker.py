@@ -1,0 +1,73 @@
+"""One rank of tests/test_gpu_multirank.py: `world` processes share cuda:0 through the shared-memory validation
+transport (nlg_ctx_comm_init_shm) and run the distributed hot path on their element slab of a global box:
+vector-space reductions, the propagator (halo exchange in natural and face-grouped layout, split reductions of the
+PCG solvers, rank-local preconditioner levels), its adjoint, and a short Arnoldi factorisation.
+usage: multirank_worker.py rank world segment outdir case"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neklab_amd import host  # noqa: E402
+from neklab_amd.mesh import box_mesh  # noqa: E402
+
+CASES = {
+    # name: (elements per rank, lx1, periodic, pprecond)
+    "box3d": ((2, 2, 2), 6, (False, False, False), 0),
+    "per3d": ((2, 2, 2), 6, (True, False, True), 0),      # periodic across the rank boundary: two shared interfaces
+    "jac3d": ((2, 2, 1), 5, (False, False, False), 1),
+    "box2d": ((3, 2), 7, (False, False), 0),
+    # with NLG_COARSE_EXACT_MAX=50 in the environment: aggregated (not exact) coarse level, as on production meshes
+    "agg3d": ((4, 4, 3), 5, (False, False, False), 0),
+}
+
+
+def run(rank, world, segment, outdir, case):
+    base, _, mult = case.partition("@")          # "box3d@2" with world 1: the global mesh of the 2-rank run
+    nel, n, periodic, pprecond = CASES[base]
+    nel = tuple(nel[:-1]) + (nel[-1] * int(mult or 1),)
+    dim = len(nel)
+    ctx = host.Context(0)
+    if world > 1:
+        ctx.comm_init_shm(rank, world, segment)
+    gnel = tuple(nel[:-1]) + (nel[-1] * world,)
+    hm = box_mesh(gnel, n, periodic=periodic, deform=0.04, last_range=(rank * nel[-1], (rank + 1) * nel[-1]))
+    gm = host.Mesh(ctx, hm)
+    X = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
+    L = hm.lengths
+    ph = [2 * np.pi * X[d] / L[d] for d in range(dim)]
+    bf = host.nek_dvector(gm)
+    U = [np.sin(ph[1]) * np.cos(ph[-1]), 0.5 * np.sin(ph[0])] + ([0.3 * np.cos(ph[0]) * np.sin(ph[1])] if dim == 3 else [])
+    for i in range(dim):
+        bf.set_field(i, U[i] * hm.mask[i])
+    v, w = host.nek_dvector(gm), host.nek_dvector(gm)
+    v.rand(True, seed=11)
+    w.rand(False, seed=12)
+    scal = [v.dot(w), w.norm(), v.norm()]
+    A = host.exptA_linop(0.03, bf, re=40.0, dt=0.01, vtol=1e-13, ptol=1e-13, maxit_p=2000, pprecond=pprecond)
+    A.init()
+    out, outT = host.nek_dvector(gm), host.nek_dvector(gm)
+    A.matvec(v, out)
+    A.rmatvec(v, outT)
+    scal += [out.norm(), outT.norm(), out.dot(w)]
+    m = 6
+    B = host.KrylovBasis(gm, m + 1)
+    B[0].assign(v)
+    H = np.zeros((m + 1, m), order="F")
+    for k in range(m):
+        host.arnoldi_step(A, B, k, H)
+    fields = {"scal": np.array(scal), "H": H, "stats": np.array([A.stats()["p_iters"], A.stats()["v_iters"]], dtype=float)}
+    for i in range(dim):
+        fields["out%d" % i] = out.get_field(i)
+        fields["outT%d" % i] = outT.get_field(i)
+        fields["v%d" % i] = v.get_field(i)
+    fields["outp"] = out.get_field(3)
+    np.savez(os.path.join(outdir, "%s_w%d_r%d.npz" % (case, world, rank)), **fields)
+    ctx.sync()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5])
+    print("WORKER_OK")

@@ -1,0 +1,84 @@
+"""The distributed hot path with 2 and 3 ranks on ONE GPU, against the single-rank run of the same global mesh.
+
+RCCL refuses two ranks on one device, so the ranks talk through the library's shared-memory validation transport
+(nlg_ctx_comm_init_shm, csrc/shm_transport.hip); everything else is the product code: halo index lists (natural and
+face-grouped), pack / unpack kernels, split reductions of the PCG solvers and of the block dot, rank-local
+preconditioner levels.  Reference behaviour: element-partitioned Nek5000 fields with gslib's gs_op and glsc3's
+MPI_Allreduce (src/vectors/real_vectors.f90:100, :217-224) give partition-independent results.
+"""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "multirank_worker.py")
+
+
+def case_env(case):
+    env = dict(os.environ)
+    if case.startswith("agg"):
+        env["NLG_COARSE_EXACT_MAX"] = "50"
+    return env
+
+
+def launch(world, outdir, case):
+    seg = "/nlg_%s" % uuid.uuid4().hex[:16]
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), seg, str(outdir), case], cwd=ROOT,
+                              env=case_env(case), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=420)
+            outs.append(o)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            os.unlink("/dev/shm" + seg)
+        except OSError:
+            pass
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "WORKER_OK" in o, "rank %d of %d:\n%s" % (r, world, o[-3000:])
+    return [np.load(os.path.join(outdir, "%s_w%d_r%d.npz" % (case, world, r))) for r in range(world)]
+
+
+@pytest.mark.parametrize("case,world", [("box3d", 2), ("per3d", 2), ("box3d", 3), ("jac3d", 2), ("box2d", 2),
+                                        ("agg3d", 2)])
+def test_partition_independent(tmp_path, case, world):
+    parts = launch(world, tmp_path, case)
+    # the single-rank run of the same global mesh (`world` times the elements in the last direction)
+    gcase = "%s@%d" % (case, world)
+    r = subprocess.run([sys.executable, WORKER, "0", "1", "", str(tmp_path), gcase], cwd=ROOT, capture_output=True,
+                       text=True, timeout=420, env=case_env(case))
+    assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    ref = np.load(os.path.join(tmp_path, "%s_w1_r0.npz" % gcase))
+    # reductions: identical on every rank, equal to the single-rank values
+    for p in parts:
+        np.testing.assert_array_equal(p["scal"], parts[0]["scal"])
+        np.testing.assert_array_equal(p["H"], parts[0]["H"])
+    np.testing.assert_allclose(parts[0]["scal"], ref["scal"], rtol=1e-9, atol=1e-12)
+    # the two-level pressure preconditioner is global (one aggregate level over all ranks, overlap across the rank
+    # boundaries): the iteration counts must stay those of the single-rank run
+    assert parts[0]["stats"][0] <= 1.25 * ref["stats"][0] + 5, (parts[0]["stats"], ref["stats"])
+    # fields: the slabs concatenated in rank order are the global fields
+    for key in ref.files:
+        if key in ("scal", "H", "stats"):
+            continue
+        got = np.concatenate([p[key].reshape(-1) for p in parts])
+        want = ref[key].reshape(-1)
+        assert got.shape == want.shape, key
+        tol = 1e-13 if key.startswith("v") else 2e-9      # start vector: same bits up to the global normalisation
+        scale = np.max(np.abs(want)) + 1e-300
+        assert np.max(np.abs(got - want)) <= tol * scale, (key, np.max(np.abs(got - want)) / scale)
+    # the Arnoldi factorisation: Hessenberg matrix and hence the Ritz values
+    np.testing.assert_allclose(parts[0]["H"], ref["H"], rtol=0, atol=2e-9 * np.max(np.abs(ref["H"])))
+    ev_p = np.sort_complex(np.linalg.eigvals(parts[0]["H"][:-1]))
+    ev_r = np.sort_complex(np.linalg.eigvals(ref["H"][:-1]))
+    assert np.max(np.abs(ev_p - ev_r)) <= 1e-8 * np.max(np.abs(ev_r))
