@@ -170,6 +170,7 @@ struct nlg_pprec {
     double thrx = 0.0;
     int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;
     double *d_Ainv = nullptr;                    // dense inverse on the aggregates: this rank's rows, [na][ncols]
+    float *d_Ainv32 = nullptr;                   // several ranks: the rows in single precision instead of d_Ainv
     int na_max = 0, ncols = 0;                   // several ranks: ncols = nranks * na_max columns (global aggregate level)
     double *d_rag = nullptr;                     // [ncols] aggregate residuals of all ranks (all-gather of d_ra)
     double *d_rc = nullptr, *d_x = nullptr, *d_ra = nullptr, *d_xa = nullptr;

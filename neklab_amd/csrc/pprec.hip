@@ -595,18 +595,27 @@ __global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na,
     if (lane == 0) ra[a] = s;
 }
 
-// xa = Ainv ra (dense, row-major), one wave per row
-__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, int ncols, const double *__restrict__ Ainv,
+// xa = Ainv ra (dense, row-major), one wave per row.  T = float for the global aggregate level of several ranks: the
+// rows of the inverse are the largest per-iteration read there (2.4k x 19.6k at 8 x 10^4 elements), a preconditioner
+// needs no more than single precision, and the symmetric matrix is rounded entry by entry, so it stays symmetric
+// across the ranks that hold its rows; sums in double.
+template <typename T>
+__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, int ncols, const T *__restrict__ Ainv,
                                                    const double *__restrict__ ra, double *__restrict__ xa) {
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     if (row >= na) return;
     double s = 0.0;
-    for (int j = lane; j < ncols; j += 64) s += Ainv[(size_t)row * ncols + j] * ra[j];
+    for (int j = lane; j < ncols; j += 64) s += (double)Ainv[(size_t)row * ncols + j] * ra[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) xa[row] = s;
+}
+
+__global__ void k_to_float(int64_t n, const double *__restrict__ a, float *__restrict__ b) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (float)a[i];
 }
 
 // ---- dense SPD inverse on the device (set-up): in-place Gauss-Jordan without pivoting, two launches per pivot ----
@@ -1397,8 +1406,11 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         const double alpha = m->has_outflow ? 0.0 : tr_all / nreal / nreal;
         hipLaunchKernelGGL(k_glob_fix, dim3((unsigned)((ntot + 255) / 256), (unsigned)ntot), dim3(256), 0, st, ntot, na_max, (const int *)d_na_of, alpha, d_full);
         NLG_TRY(spd_inverse_dev(d_full, (int)ntot));
-        NLG_HIP(hipMalloc(&P.d_Ainv, sizeof(double) * (size_t)std::max(na, 1) * ntot));
-        NLG_HIP(hipMemcpyAsync(P.d_Ainv, d_full + (size_t)me * na_max * ntot, sizeof(double) * (size_t)na * ntot, hipMemcpyDeviceToDevice, st));
+        const int64_t nrow_el = (int64_t)std::max(na, 1) * ntot;
+        NLG_HIP(hipMalloc(&P.d_Ainv32, sizeof(float) * (size_t)nrow_el));
+        hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nrow_el + 255) / 256)), dim3(256), 0, st, (int64_t)na * ntot,
+                           (const double *)(d_full + (size_t)me * na_max * ntot), P.d_Ainv32);
+        NLG_HIP(hipGetLastError());
         NLG_HIP(hipStreamSynchronize(st));
         hipFree(d_full);
         hipFree(d_rows);
@@ -1437,7 +1449,10 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
         NLG_TRY(allgather_f64(m->ctx, P.d_ra, P.d_rag, P.na_max));
         ra = P.d_rag;
     }
-    hipLaunchKernelGGL(k_dense_gemv, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.ncols, P.d_Ainv, ra, P.d_xa);
+    if (P.d_Ainv32)
+        hipLaunchKernelGGL(k_dense_gemv<float>, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.ncols, (const float *)P.d_Ainv32, ra, P.d_xa);
+    else
+        hipLaunchKernelGGL(k_dense_gemv<double>, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.ncols, (const double *)P.d_Ainv, ra, P.d_xa);
     NLG_HIP(hipGetLastError());
     *xc = P.d_x;   // the Jacobi term; pprec_fine adds xa[agg[v]] while prolonging
     return 0;
@@ -1550,6 +1565,7 @@ void pprec_free(nlg_mesh *m) {
     int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i};
     for (int *p : ip)
         if (p) hipFree(p);
+    if (P.d_Ainv32) hipFree(P.d_Ainv32);
     P = nlg_pprec();
 }
 
