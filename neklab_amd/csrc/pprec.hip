@@ -857,7 +857,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
 
     // ---- 1b. overlapping variant: extended 1-D operators from the line left neighbour | element | right neighbour
     // (3-D: exchange array in the face-grouped layout; 2-D: natural layout)
-    if (((dim == 3 && m->gs.d_indices_fg) || dim == 2) && m->gs.npairs > 0 && n <= 8) {
+    if (((dim == 3 && m->gs.d_indices_fg && n <= 12 && n != 11) || (dim == 2 && n <= 8)) && m->gs.npairs > 0) {
         // normal edge length of the face neighbours, through the gather-scatter: every element puts its own
         // normal length on the interior points of its faces, the sum minus the own value is the neighbour's
         std::vector<double> hw((size_t)m->lvn, 0.0);
@@ -1518,8 +1518,8 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
         break;
         switch (m->n) {
-            FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8)
-            default: set_error("pprec: overlapping variant built for lx1 = 4..8, got %d", m->n); return 1;
+            FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(12)
+            default: set_error("pprec: overlapping variant built for lx1 = 4..10 and 12, got %d", m->n); return 1;
         }
 #undef FX_CASE
         NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
@@ -1529,7 +1529,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         hipLaunchKernelGGL((k_sch_finish<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
         break;
         switch (m->n) {
-            FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8)
+            FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10) FF_CASE(12)
             default: break;
         }
 #undef FF_CASE
