@@ -24,7 +24,50 @@ CASES = {
 }
 
 
+def run_cylinder(rank, world, segment, outdir, case):
+    """The reference's cylinder mesh (unstructured, periodic in y, outflow), contiguous element blocks per rank."""
+    import dataclasses
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from refdata import load_cylinder
+    from neklab_amd.mesh import partition_elements
+    hm, ux, uy, _, re, lxd, _ = load_cylinder(with_bcs=True)
+    mine = partition_elements(hm.x.shape[0], world)[rank]
+    loc = dataclasses.replace(hm, nel=(len(mine), 1), x=hm.x[mine], y=hm.y[mine], glo_num=hm.glo_num[mine],
+                              mask=[m[mine] for m in hm.mask], tmask=hm.tmask[mine], elem_gid=hm.elem_gid[mine])
+    ctx = host.Context(0)
+    if world > 1:
+        ctx.comm_init_shm(rank, world, segment)
+    gm = host.Mesh(ctx, loc, lxd=lxd)
+    bf = host.nek_dvector(gm)
+    bf.set_field(host.VX, ux[mine])
+    bf.set_field(host.VY, uy[mine])
+    v = host.nek_dvector(gm)
+    v.rand(True, seed=3)
+    A = host.exptA_linop(0.05, bf, re=re, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    A.init()
+    out, outT = host.nek_dvector(gm), host.nek_dvector(gm)
+    A.matvec(v, out)
+    A.rmatvec(v, outT)
+    m = 4
+    B = host.KrylovBasis(gm, m + 1)
+    B[0].assign(v)
+    H = np.zeros((m + 1, m), order="F")
+    for k in range(m):
+        host.arnoldi_step(A, B, k, H)
+    fields = {"scal": np.array([v.norm(), out.norm(), outT.norm(), out.dot(v), float(A.info()["nsteps"])]), "H": H,
+              "stats": np.array([A.stats()["p_iters"], A.stats()["v_iters"]], dtype=float)}
+    for i in range(2):
+        fields["out%d" % i] = out.get_field(i)
+        fields["outT%d" % i] = outT.get_field(i)
+        fields["v%d" % i] = v.get_field(i)
+    fields["outp"] = out.get_field(3)
+    np.savez(os.path.join(outdir, "%s_w%d_r%d.npz" % (case, world, rank)), **fields)
+    ctx.sync()
+
+
 def run(rank, world, segment, outdir, case):
+    if case.startswith("cyl"):
+        return run_cylinder(rank, world, segment, outdir, case)
     base, _, mult = case.partition("@")          # "box3d@2" with world 1: the global mesh of the 2-rank run
     nel, n, periodic, pprecond = CASES[base]
     nel = tuple(nel[:-1]) + (nel[-1] * int(mult or 1),)

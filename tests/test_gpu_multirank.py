@@ -50,11 +50,11 @@ def launch(world, outdir, case):
 
 
 @pytest.mark.parametrize("case,world", [("box3d", 2), ("per3d", 2), ("box3d", 3), ("jac3d", 2), ("box2d", 2),
-                                        ("agg3d", 2)])
+                                        ("agg3d", 2), ("cyl", 2), ("cyl", 3)])
 def test_partition_independent(tmp_path, case, world):
     parts = launch(world, tmp_path, case)
     # the single-rank run of the same global mesh (`world` times the elements in the last direction)
-    gcase = "%s@%d" % (case, world)
+    gcase = "%s@%d" % (case, world)       # (the cylinder case ignores the multiplier: the mesh is the global one)
     r = subprocess.run([sys.executable, WORKER, "0", "1", "", str(tmp_path), gcase], cwd=ROOT, capture_output=True,
                        text=True, timeout=420, env=case_env(case))
     assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
