@@ -65,7 +65,44 @@ def run_cylinder(rank, world, segment, outdir, case):
     ctx.sync()
 
 
+def run_heat(rank, world, segment, outdir, case):
+    """Boussinesq coupling (cfg.ifheat) and the nonlinear map on a slab partition: the scalar solve, the buoyancy and the
+    scalar convection use the same halo / reductions as the fluid."""
+    _, _, mult = case.partition("@")
+    nel, n = (2, 2, 2 * int(mult or 1)), 6
+    ctx = host.Context(0)
+    if world > 1:
+        ctx.comm_init_shm(rank, world, segment)
+    gnel = (nel[0], nel[1], nel[2] * world)
+    hm = box_mesh(gnel, n, lengths=(2.0, 1.0, 1.0 * gnel[2] / 2), periodic=(True, False, True), deform=0.03,
+                  last_range=(rank * nel[2], (rank + 1) * nel[2]))
+    gm = host.Mesh(ctx, hm)
+    gb = host.nek_dvector(gm, 1)
+    gb.set_field(0, hm.mask[0] * (4 * hm.y * (1 - hm.y)))
+    gb.set_field(host.THETA, 1.0 - hm.y + 0.1 * np.sin(np.pi * hm.x) * np.sin(np.pi * hm.y))
+    kw = dict(re=5.0, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=600, maxit_p=4000, dt=0.01, ifheat=1, conductivity=0.3,
+              rhocp=1.5, buoy=(0.0, 50.0, 0.0))
+    A = host.exptA_linop(0.05, gb, **kw)
+    A.init()
+    v, out, nl = host.nek_dvector(gm, 1), host.nek_dvector(gm, 1), host.nek_dvector(gm, 1)
+    v.rand(True, seed=5)
+    A.matvec(v, out)
+    host.check(A.lib.nlg_linop_nonlinear_map(A.h, v.h, nl.h))
+    fields = {"scal": np.array([v.norm(), out.norm(), nl.norm(), out.dot(nl)]), "H": np.zeros((2, 1)),
+              "stats": np.array([A.stats()["p_iters"], A.stats()["v_iters"]], dtype=float)}
+    for i in range(3):
+        fields["out%d" % i] = out.get_field(i)
+        fields["outT%d" % i] = nl.get_field(i)
+        fields["v%d" % i] = v.get_field(i)
+    fields["outp"] = out.get_field(host.THETA)
+    fields["outq"] = nl.get_field(host.THETA)
+    np.savez(os.path.join(outdir, "%s_w%d_r%d.npz" % (case, world, rank)), **fields)
+    ctx.sync()
+
+
 def run(rank, world, segment, outdir, case):
+    if case.startswith("heat"):
+        return run_heat(rank, world, segment, outdir, case)
     if case.startswith("cyl"):
         return run_cylinder(rank, world, segment, outdir, case)
     base, _, mult = case.partition("@")          # "box3d@2" with world 1: the global mesh of the 2-rank run
