@@ -13,6 +13,8 @@
 // returns immediately once the flag is set, so the result is identical to stopping at convergence.
 #include <cmath>
 #include <functional>
+#include <map>
+#include <string>
 
 #include "internal.h"
 
@@ -553,6 +555,17 @@ struct nlg_linop {
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
     std::vector<int> pit_hist, vit_hist;   // iteration counts of the previous matvec, by time-step index (the pattern repeats)
+    // hipGraphs of PCG iterations, by solver / argument signature.  OPT-IN (NLG_GRAPH=1|2): measured on the reference's
+    // cylinder case (1996 elements, ~330 kernels of ~4 us per time step) graph replay changes nothing — 1437 us per time
+    // step with direct launches, 1510 / 1436 / 1456 us with graphs of 1 / 2 / 4 iterations: the host is already ahead
+    // of the device, the cost is the device-side start-up of each dependent tiny kernel, which a graph does not remove.
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        int uses = 0;
+        bool failed = false;
+    };
+    std::map<std::string, GraphSlot> graphs;
+    int graph_mode = -1;       // NLG_GRAPH: 0 off (default), 1 meshes below NLG_GRAPH_MAX points, 2 always; -1 = not read yet
 };
 
 namespace {
@@ -604,6 +617,8 @@ struct CGProblem {
     bool fused_pupdate = false;        // `apply` itself performs p <- z + beta p (gated by the done flag) before w = A p
     const double *rz_part = nullptr;   // [2][rz_n]: sum r.z , sum z   (written by `precond`)
     int rz_n = 0;
+    std::string tag;                   // non-empty: the iteration may be replayed from a hipGraph; names the solver and
+                                       // every argument of `apply` / `precond` that is not a member of this struct
 };
 
 // Generic device-scalar PCG. `apply` computes w = A p (must itself be stream-ordered and may be gated
@@ -658,28 +673,86 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     if (!P.fused_pupdate)
         launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
     hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
+    auto body = [&]() -> int {
+        NLG_TRY(apply(s));
+        if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
+        if (!P.pw_part)
+            launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
+        NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
+        launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
+                  pc, P.ipw, P.nw, partial);
+        if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
+        if (P.precond) {
+            NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
+            if (!P.rz_part)
+                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+        }
+        NLG_TRY(reduce_post(rd_rz, 3, 1, 2));
+        if (!P.fused_pupdate)
+            launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
+        return 0;
+    };
+    // One iteration as a hipGraph: every argument is fixed for the life of the signature (the scalars live on the
+    // device), so the graph captured at the second solve with a signature is replayed by all later ones.
+    hipGraphExec_t exec = nullptr;
+    int giters = 1;   // iterations per graph
+    if (const char *ev = getenv("NLG_GRAPH_ITERS")) giters = std::max(1, atoi(ev));
+    if (op->graph_mode < 0) {
+        const char *ev = getenv("NLG_GRAPH");
+        op->graph_mode = ev ? atoi(ev) : 0;
+    }
+    {
+        int64_t gmax = 1500000;
+        if (const char *ev = getenv("NLG_GRAPH_MAX")) gmax = atoll(ev);
+        const bool want = !P.tag.empty() && !ctx->prof_on && !ctx->distributed() &&
+                          (op->graph_mode == 2 || (op->graph_mode == 1 && op->mesh->lvn <= gmax));
+        if (want) {
+            char kb[512];
+            snprintf(kb, sizeof(kb), "%s|%d|%d|%lld|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p|%p|%a|%d|%d|%p|%a|%d|%p|%d|%d|%d|%p|%d", P.tag.c_str(), giters, nf,
+                     (long long)P.n, (void *)P.x[0], (void *)(nf > 1 ? P.x[1] : nullptr), (void *)(nf > 2 ? P.x[2] : nullptr), (void *)P.r[0],
+                     (void *)(nf > 1 ? P.r[1] : nullptr), (void *)(nf > 2 ? P.r[2] : nullptr), (void *)P.z[0], (void *)(nf > 1 ? P.z[1] : nullptr),
+                     (void *)(nf > 2 ? P.z[2] : nullptr), (void *)P.p[0], (void *)(nf > 1 ? P.p[1] : nullptr), (void *)(nf > 2 ? P.p[2] : nullptr),
+                     (void *)P.w[0], (void *)(nf > 1 ? P.w[1] : nullptr), (void *)(nf > 2 ? P.w[2] : nullptr),
+                     (void *)(P.pc ? P.pc[0] : nullptr), (void *)(P.pc && nf > 1 ? P.pc[1] : nullptr), (void *)(P.pc && nf > 2 ? P.pc[2] : nullptr),
+                     (const void *)P.ipw, (const void *)P.nw, P.tol2, P.use_tol, P.maxit, (void *)P.s, P.inv_n, P.npe, (const void *)P.pw_part,
+                     P.pw_n, (int)P.pw_sum, (int)P.fused_pupdate, (const void *)P.rz_part, P.rz_n);
+            nlg_linop::GraphSlot &slot = op->graphs[kb];
+            ++slot.uses;
+            if (!slot.exec && !slot.failed && slot.uses >= 2) {
+                // everything the iteration allocates lazily exists after the first solve
+                hipGraph_t gr = nullptr;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    int rc = 0;
+                    for (int q = 0; q < giters && rc == 0; ++q) rc = body();
+                    const hipError_t e1 = hipStreamEndCapture(st, &gr);
+                    if (rc == 0 && e1 == hipSuccess && gr && hipGraphInstantiate(&slot.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+                    } else {
+                        slot.exec = nullptr;
+                        slot.failed = true;   // direct launches from now on
+                        (void)hipGetLastError();
+                    }
+                    if (gr) hipGraphDestroy(gr);
+                } else {
+                    slot.failed = true;
+                    (void)hipGetLastError();
+                }
+            }
+            exec = slot.exec;
+        }
+    }
     int launched = 0;
     int iters = 0;
     while (true) {
         int todo = launched == 0 ? P.chunk : P.chunk_next;
         if (launched + todo > P.maxit) todo = P.maxit - launched;
-        for (int it = 0; it < todo; ++it) {
-            NLG_TRY(apply(s));
-            if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
-            if (!P.pw_part)
-                launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
-            NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
-            launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
-                      pc, P.ipw, P.nw, partial);
-            if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
-            if (P.precond) {
-                NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
-                if (!P.rz_part)
-                    launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+        for (int it = 0; it < todo;) {
+            if (exec && it + giters <= todo) {
+                NLG_HIP(hipGraphLaunch(exec, st));
+                it += giters;
+            } else {
+                NLG_TRY(body());
+                ++it;
             }
-            NLG_TRY(reduce_post(rd_rz, 3, 1, 2));
-            if (!P.fused_pupdate)
-                launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
         }
         launched += todo;
         NLG_HIP(hipGetLastError());
@@ -741,6 +814,11 @@ int helm_solve(nlg_linop *op, int order, double h2) {
         NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE));
         return 0;
     };
+    {
+        char tb[96];
+        snprintf(tb, sizeof(tb), "helm|%a|%a|%d", nu, h2, pw_part ? 1 : 0);
+        P.tag = tb;
+    }
     int iters = 0;
     NLG_TRY(run_pcg(op, P, apply, &iters));
     op->st_viters += iters;
@@ -818,6 +896,11 @@ int heat_step(nlg_linop *op, int k, double b0) {
         NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE));
         return 0;
     };
+    {
+        char tb[96];
+        snprintf(tb, sizeof(tb), "heat|%a|%a", h1, h2);
+        P.tag = tb;
+    }
     int iters = 0;
     NLG_TRY(run_pcg(op, P, apply, &iters));
     op->st_titers += iters;
@@ -908,6 +991,11 @@ int pres_solve(nlg_linop *op, double scale) {
         NLG_TRY(dots(op->pr_r, nold, op->prX, alpha));                       // alpha = X^T b
         hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_r, (const double *)op->prB, m->lps,
                            nold, (const double *)alpha, -1.0);               // b <- b - B alpha
+    }
+    {
+        char tb[96];
+        snprintf(tb, sizeof(tb), "pres|%d|%d", c.pprecond, P.precond ? 1 : 0);
+        P.tag = tb;
     }
     int iters = 0;
     NLG_TRY(run_pcg(op, P, apply, &iters));
@@ -1263,6 +1351,9 @@ int nlg_linop_create(nlg_mesh *mesh, const nlg_exptA_config *cfg, const nlg_vec 
 int nlg_linop_destroy(nlg_linop *op) {
     if (!op) return 0;
     hipDeviceSynchronize();
+    for (auto &kv : op->graphs)
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+    op->graphs.clear();
     auto fr = [](double *p) {
         if (p) hipFree(p);
     };
