@@ -68,9 +68,14 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
         return nshared * (16.0 * dim + 4.0)
     if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
         return 8.0 * (k * ncomp + ncomp + 1) * lvs
-    if cls == "block_axpy":   # k basis vectors + w in/out.  CGS2 launches it twice: first pass over the main fields only,
-        # second pass over main + the lorder-1 history blocks (consistent restart history) -> mean per launch
-        return 8.0 * (k + 2) * main_len * (1 + lorder) / 2.0
+    fused = 24 <= k <= 64     # CGS2: first subtraction + second projection in one sweep (k_block_axpy_dot)
+    if cls == "axpy_dot":     # k basis vectors + w in/out + bm1 over the inner-product dofs
+        return 8.0 * ((k + 2) * ncomp + 1) * lvs if fused else None
+    if cls == "block_axpy":   # k basis vectors + w in/out.  CGS2 launches it twice: first pass over the main fields only
+        # (fused sweep: only the pressure part is left to it), second pass over main + the lorder-1 history blocks
+        # (consistent restart history) -> mean per launch
+        first = lps if fused else main_len
+        return 8.0 * (k + 2) * (first + main_len * lorder) / 2.0
     return None
 
 
@@ -146,7 +151,7 @@ def main():
     ctx.sync()
     setup_s = time.time() - t0
     H = np.zeros((m + 2, m + 1), order="F")
-    names = ["axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops", "pprec"]
+    names = ["axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops", "pprec", "axpy_dot"]
 
     def step():
         host.arnoldi_step(A, B, m - 1, H)

@@ -56,7 +56,7 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 }  // namespace nlg
 
 // kernel classes that can be timed with HIP events on the launch stream (bench.py roofline leg)
-enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_PPREC, P_COUNT };
+enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_PPREC, P_AXPYDOT, P_COUNT };
 
 struct nlg_prof_slot {
     std::vector<hipEvent_t> ev;   // pairs (begin, end)

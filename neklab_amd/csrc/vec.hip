@@ -178,6 +178,50 @@ __global__ __launch_bounds__(NT) void k_block_dot(const double *V, int64_t vstri
     }
 }
 
+// CGS2, first subtraction and second projection in ONE sweep over the basis (k <= KMAX):
+//   w <- w - V h   on the velocity (+ scalar) part of the main block,   partial[j] = V_j^T (bm1 o w_new).
+// The second projection needs the finished w at a point and the k basis values at the same point — which the thread
+// that has just computed w there still holds in registers.  One point per lane, the k values and the k running sums
+// in registers (2 x KMAX doubles: one wave per SIMD, 64 independent loads in flight per wave), one block per CU.
+// Saves one of the four reads of the basis that CGS2 otherwise makes.
+template <int KMAX>
+__global__ __launch_bounds__(NT) void k_block_axpy_dot(const double *__restrict__ V, int64_t vstride, int k,
+                                                       const double *__restrict__ h, double *__restrict__ w,
+                                                       const double *__restrict__ bm1, int64_t lvs, int64_t nv,
+                                                       double *__restrict__ partial) {
+    __shared__ double sh[KMAX];
+    __shared__ double sm[4][KMAX];
+    for (int j = threadIdx.x; j < KMAX; j += NT) sh[j] = j < k ? h[j] : 0.0;
+    __syncthreads();
+    double acc[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) acc[j] = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < nv; i += (int64_t)gridDim.x * NT) {
+        double v[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) v[j] = j < k ? V[(int64_t)j * vstride + i] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) s += sh[j] * v[j];
+        const double wn = w[i] - s;
+        w[i] = wn;
+        const double x = wn * bm1[i % lvs];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) acc[j] += v[j] * x;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const double t = wave_sum(acc[j]);
+        if (lane == 0) sm[wid][j] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < k) {
+        const int j = threadIdx.x;
+        partial[(int64_t)j * gridDim.x + blockIdx.x] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+    }
+}
+
 // w -= sum_j h_j V_j on the main block; history slots of w receive the same correction
 // (reference axpby quirk) or the combination of the basis history (consistent mode).
 // `hh` (may be null): a second coefficient set used for the entries at or beyond blk2 (the history blocks of a sweep
@@ -577,8 +621,39 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
             // first pass on the main block only; the second pass applies h2 to the main block and h + h2 (accumulated
             // in h by the second block_dot) to the history blocks: the result is the one of two full sweeps up to
             // rounding, at two thirds of the traffic
-            NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0, nullptr, true));
-            NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));
+            // (measured, CGS2 + norm + scale at 10^4 elements: k = 64: 6.29 -> 4.94 ms, 32: 3.28 -> 2.79, 16: 1.78 -> 1.88,
+            // 8: 1.04 -> 1.46 — the fully unrolled KMAX = 64 kernel does all 128 FMAs whatever k — hence the lower bound)
+            static const int fuse_max = getenv("NLG_CGS2_FUSE_MAX") ? atoi(getenv("NLG_CGS2_FUSE_MAX")) : 64;
+            if (k >= 24 && k <= fuse_max && k <= 64) {
+                // first subtraction and second projection in one sweep over the basis (k_block_axpy_dot)
+                const nlg_vec *v0 = b->views[0];
+                const int64_t nv = (int64_t)v0->ncomp * b->mesh->lvs;   // velocity (+ scalar) part; the pressure follows
+                const int G = 256;                                     // one block per CU (one wave per SIMD)
+                NLG_TRY(reduce_ws_reserve(ctx, k));
+                {
+                    ProfScope ps(ctx, P_AXPYDOT);
+                    hipLaunchKernelGGL(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, (const double *)b->d, b->stride, k,
+                                       (const double *)h, w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
+                }
+                {
+                    ProfScope ps(ctx, P_BLOCKAXPY);
+                    const int64_t np2 = (w->main_len - nv) / 2;        // pressure part of the main block: subtraction only
+                    if (np2 > 0)
+                        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(np2)), dim3(NT), sizeof(double) * 2 * k, ctx->stream,
+                                           (const double *)(b->d + nv), b->stride, k, (const double *)h, w->d + nv, np2, 0, np2, 0, -1.0,
+                                           (const double *)nullptr);
+                }
+                if (ctx->distributed()) {
+                    hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2, 0, (double *)nullptr);
+                    NLG_TRY(allreduce_sum(ctx, h2, k));
+                    hipLaunchKernelGGL(k_vadd, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, h, h2, k);
+                } else {
+                    hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2, 1, h);
+                }
+            } else {
+                NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0, nullptr, true));
+                NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));
+            }
             NLG_TRY(basis_block_axpy_dev(b, k, h2, w, -1.0, h, false));
         } else {
             NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0));
