@@ -145,3 +145,49 @@ def test_scalar_fields_in_the_basis(gpu_ctx):
     hh, beta = B.cgs2(k, w)
     assert beta > 0 and abs(w.norm() - 1.0) < 1e-13
     assert np.max(np.abs(B.block_dot(k, w))) < 1e-13
+
+
+@pytest.mark.parametrize("k", [23, 24, 40, 64, 65])
+def test_cgs2_fused_sweep_matches_separate_kernels(gpu_ctx, k):
+    """CGS2 (LightKrylov's double Gram-Schmidt) through `nlg_basis_cgs2` -- which for 24 <= k <= 64 fuses the
+    first subtraction with the second projection (k_block_axpy_dot) -- against the same four passes made with the
+    separate block_dot / block_axpy entry points: coefficients, the orthogonalised vector (velocity, pressure and the
+    restart-history blocks) and the norm.  k = 23 and 65 take the unfused path and pin the comparison itself."""
+    hm = box_mesh((3, 3, 2), 6, deform=0.03)
+    gm = host.Mesh(gpu_ctx, hm)
+    B = host.KrylovBasis(gm, k + 1)
+    hist = host.nek_dvector(gm)
+    for j in range(k):                                     # orthonormal columns with restart history
+        v = B[j]
+        v.rand(False, seed=300 + j)
+        for irst in (1, 2):
+            hist.rand(False, seed=1000 + 10 * j + irst)
+            v.save_rst(hist, irst)
+        B.cgs2(j, v)
+    w1, w2 = host.nek_dvector(gm), host.nek_dvector(gm)
+    w1.rand(False, seed=7)
+    for irst in (1, 2):
+        hist.rand(False, seed=5000 + irst)
+        w1.save_rst(hist, irst)
+    w2.assign(w1)
+    # reference: four separate passes; the history receives the sum of both coefficient sets
+    h1 = B.block_dot(k, w2)
+    B.block_axpy(k, h1, w2)
+    h2 = B.block_dot(k, w2)
+    B.block_axpy(k, h2, w2)
+    nrm = w2.norm()
+    w2.scal(1.0 / nrm)
+    h, beta = B.cgs2(k, w1)
+    assert np.max(np.abs(h - (h1 + h2))) < 1e-12 * np.max(np.abs(h1))
+    assert abs(beta - nrm) < 1e-12 * nrm
+    for f in range(4):
+        a, b = w1.get_field(f), w2.get_field(f)
+        assert np.max(np.abs(a - b)) < 1e-12 * max(np.max(np.abs(b)), 1e-300), f
+    ra, rb = host.nek_dvector(gm), host.nek_dvector(gm)
+    for irst in (1, 2):
+        w1.get_rst(ra, irst)
+        w2.get_rst(rb, irst)
+        for f in range(4):
+            a, b = ra.get_field(f), rb.get_field(f)
+            assert np.max(np.abs(a - b)) < 1e-11 * max(np.max(np.abs(b)), 1e-300), (irst, f)
+    assert np.max(np.abs(B.block_dot(k, w1))) < 1e-12
