@@ -68,9 +68,11 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
         return nshared * (16.0 * dim + 4.0)
     if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
         return 8.0 * (k * ncomp + ncomp + 1) * lvs
-    fused = 24 <= k <= 64     # CGS2: first subtraction + second projection in one sweep (k_block_axpy_dot)
-    if cls == "axpy_dot":     # k basis vectors + w in/out + bm1 over the inner-product dofs
-        return 8.0 * ((k + 2) * ncomp + 1) * lvs if fused else None
+    fused = k >= 24           # CGS2: first subtraction + second projection in one sweep over the last min(k, 64) vectors
+    if cls == "axpy_dot":     # kf basis vectors + w in/out + bm1 over the inner-product dofs
+        return 8.0 * ((min(k, 64) + 2) * ncomp + 1) * lvs if fused else None
+    if cls == "block_axpy" and k > 64:
+        return None           # three launches of different sizes per CGS2: not a single-kernel class any more
     if cls == "block_axpy":   # k basis vectors + w in/out.  CGS2 launches it twice: first pass over the main fields only
         # (fused sweep: only the pressure part is left to it), second pass over main + the lorder-1 history blocks
         # (consistent restart history) -> mean per launch

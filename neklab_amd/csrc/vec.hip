@@ -624,32 +624,37 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
             // (measured, CGS2 + norm + scale at 10^4 elements: k = 64: 6.29 -> 4.94 ms, 32: 3.28 -> 2.79, 16: 1.78 -> 1.88,
             // 8: 1.04 -> 1.46 — the fully unrolled KMAX = 64 kernel does all 128 FMAs whatever k — hence the lower bound)
             static const int fuse_max = getenv("NLG_CGS2_FUSE_MAX") ? atoi(getenv("NLG_CGS2_FUSE_MAX")) : 64;
-            if (k >= 24 && k <= fuse_max && k <= 64) {
-                // first subtraction and second projection in one sweep over the basis (k_block_axpy_dot)
+            if (k >= 24 && fuse_max >= 24) {
+                // first subtraction and second projection in one sweep over the LAST kf <= 64 basis vectors
+                // (k_block_axpy_dot); the k0 = k - kf vectors before them are subtracted first and projected after
                 const nlg_vec *v0 = b->views[0];
+                const int kf = std::min(std::min(k, fuse_max), 64), k0 = k - kf;
                 const int64_t nv = (int64_t)v0->ncomp * b->mesh->lvs;   // velocity (+ scalar) part; the pressure follows
                 const int G = 256;                                     // one block per CU (one wave per SIMD)
                 NLG_TRY(reduce_ws_reserve(ctx, k));
+                if (k0 > 0) NLG_TRY(basis_block_axpy_dev(b, k0, h, w, -1.0, nullptr, true));
+                const double *Vf = b->d + (int64_t)k0 * b->stride;
                 {
                     ProfScope ps(ctx, P_AXPYDOT);
-                    hipLaunchKernelGGL(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, (const double *)b->d, b->stride, k,
-                                       (const double *)h, w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
+                    hipLaunchKernelGGL(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, Vf, b->stride, kf,
+                                       (const double *)(h + k0), w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
                 }
                 {
                     ProfScope ps(ctx, P_BLOCKAXPY);
                     const int64_t np2 = (w->main_len - nv) / 2;        // pressure part of the main block: subtraction only
                     if (np2 > 0)
-                        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(np2)), dim3(NT), sizeof(double) * 2 * k, ctx->stream,
-                                           (const double *)(b->d + nv), b->stride, k, (const double *)h, w->d + nv, np2, 0, np2, 0, -1.0,
+                        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(np2)), dim3(NT), sizeof(double) * 2 * kf, ctx->stream,
+                                           Vf + nv, b->stride, kf, (const double *)(h + k0), w->d + nv, np2, 0, np2, 0, -1.0,
                                            (const double *)nullptr);
                 }
                 if (ctx->distributed()) {
-                    hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2, 0, (double *)nullptr);
-                    NLG_TRY(allreduce_sum(ctx, h2, k));
-                    hipLaunchKernelGGL(k_vadd, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, h, h2, k);
+                    hipLaunchKernelGGL(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 0, (double *)nullptr);
+                    NLG_TRY(allreduce_sum(ctx, h2 + k0, kf));
+                    hipLaunchKernelGGL(k_vadd, dim3((kf + 255) / 256), dim3(256), 0, ctx->stream, h + k0, h2 + k0, kf);
                 } else {
-                    hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2, 1, h);
+                    hipLaunchKernelGGL(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 1, h + k0);
                 }
+                if (k0 > 0) NLG_TRY(basis_block_dot_dev(b, k0, w, h2, h));
             } else {
                 NLG_TRY(basis_block_axpy_dev(b, k, h, w, -1.0, nullptr, true));
                 NLG_TRY(basis_block_dot_dev(b, k, w, h2, h));

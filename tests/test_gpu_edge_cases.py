@@ -147,12 +147,13 @@ def test_scalar_fields_in_the_basis(gpu_ctx):
     assert np.max(np.abs(B.block_dot(k, w))) < 1e-13
 
 
-@pytest.mark.parametrize("k", [23, 24, 40, 64, 65])
+@pytest.mark.parametrize("k", [23, 24, 40, 64, 65, 100])
 def test_cgs2_fused_sweep_matches_separate_kernels(gpu_ctx, k):
     """CGS2 (LightKrylov's double Gram-Schmidt) through `nlg_basis_cgs2` -- which for 24 <= k <= 64 fuses the
     first subtraction with the second projection (k_block_axpy_dot) -- against the same four passes made with the
     separate block_dot / block_axpy entry points: coefficients, the orthogonalised vector (velocity, pressure and the
-    restart-history blocks) and the norm.  k = 23 and 65 take the unfused path and pin the comparison itself."""
+    restart-history blocks) and the norm.  k = 23 takes the unfused path and pins the comparison itself; above 64 the sweep
+    is fused over the last 64 vectors only."""
     hm = box_mesh((3, 3, 2), 6, deform=0.03)
     gm = host.Mesh(gpu_ctx, hm)
     B = host.KrylovBasis(gm, k + 1)
