@@ -166,6 +166,7 @@ struct nlg_pprec {
     // overlapping variant (3-D, lx1 <= 8): extended 1-D eigen-decompositions [E][3][n*n], eigenvalues [E][3][n], the
     // velocity-shaped exchange array (face-grouped layout) and the zero-denominator threshold
     bool overlap = false;
+    int *d_exttab = nullptr;                     // [n^3] packed per-point constants of the extended grid (k_fdm_ext)
     double *d_Sx = nullptr, *d_lamx = nullptr, *d_W = nullptr, *d_wq = nullptr;   // d_wq: count^-1/2 weights [E][n2^3]
     double thrx = 0.0;
     int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;

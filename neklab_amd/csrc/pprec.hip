@@ -203,7 +203,7 @@ template <int N, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                 const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                 const double *__restrict__ wq, double *__restrict__ W,
-                                                double *__restrict__ z) {
+                                                double *__restrict__ z, const int *__restrict__ tab) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
     __shared__ double sL[WPB][3][N];
     __shared__ double sA[WPB][NP], sB[WPB][NP];
@@ -219,15 +219,25 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
     for (int q = lane; q < 3 * N; q += 64) sL[wv][q / N][q % N] = lam[ee * (3 * N) + q];
     const double *re = r + ee * NP2;
     double *We = W + ee * NP;
-    for (int q = lane; q < NP; q += 64) {
-        const int a = q % N, b = (q / N) % N, c = q / (N * N);
-        const int nb = (a == 0 || a == N - 1) + (b == 0 || b == N - 1) + (c == 0 || c == N - 1);
+    // packed per-point constants (pprec_setup): bits 0-1 boundary directions, 2-12 exchange slot, 13-22 pressure point,
+    // 23-28 ghost-neighbour flags; kept in registers for the store phase
+    constexpr int NQL = (NP + 63) / 64;
+    int te[NQL];
+#pragma unroll
+    for (int u = 0; u < NQL; ++u) {
+        const int q = lane + 64 * u;
+        te[u] = q < NP ? tab[q] : 3;
+    }
+#pragma unroll
+    for (int u = 0; u < NQL; ++u) {
+        const int q = lane + 64 * u;
+        if (q >= NP) break;
+        const int nb = te[u] & 3;
         double v = 0.0;
         if (nb <= 1) {
-            const int a2 = min(max(a, 1), N - 2) - 1, b2 = min(max(b, 1), N - 2) - 1, c2 = min(max(c, 1), N - 2) - 1;
-            const int q2 = a2 + N2 * (b2 + N2 * c2);
+            const int q2 = (te[u] >> 13) & 1023;
             const double own = re[q2] * wq[ee * NP2 + q2];
-            v = nb == 0 ? own : We[ext_slot(N, a, b, c)] - own;
+            v = nb == 0 ? own : We[(te[u] >> 2) & 2047] - own;
         }
         sA[wv][q] = v;
     }
@@ -250,20 +260,23 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
     fdm_stage<N, 3, false, 0>(sB[wv], sA[wv], Sg + 0 * N * N, lane);
     __syncthreads();
     if (act) {
-        for (int q = lane; q < NP; q += 64) {
-            const int a = q % N, b = (q / N) % N, c = q / (N * N);
-            const int nb = (a == 0 || a == N - 1) + (b == 0 || b == N - 1) + (c == 0 || c == N - 1);
+#pragma unroll
+        for (int u = 0; u < NQL; ++u) {
+            const int q = lane + 64 * u;
+            if (q >= NP) break;
+            const int nb = te[u] & 3;
             if (nb == 1) {
-                We[ext_slot(N, a, b, c)] = sA[wv][q];   // ghost value: belongs to the neighbour's adjacent layer
+                We[(te[u] >> 2) & 2047] = sA[wv][q];   // ghost value: belongs to the neighbour's adjacent layer
             } else if (nb == 0) {
+                const int fl = te[u] >> 23;
                 double v = sA[wv][q];
-                if (a == 1) v -= sA[wv][q - 1];
-                if (a == N - 2) v -= sA[wv][q + 1];
-                if (b == 1) v -= sA[wv][q - N];
-                if (b == N - 2) v -= sA[wv][q + N];
-                if (c == 1) v -= sA[wv][q - N * N];
-                if (c == N - 2) v -= sA[wv][q + N * N];
-                z[e * NP2 + (a - 1) + N2 * ((b - 1) + N2 * (c - 1))] = v;
+                if (fl & 1) v -= sA[wv][q - 1];
+                if (fl & 2) v -= sA[wv][q + 1];
+                if (fl & 4) v -= sA[wv][q - N];
+                if (fl & 8) v -= sA[wv][q + N];
+                if (fl & 16) v -= sA[wv][q - N * N];
+                if (fl & 32) v -= sA[wv][q + N * N];
+                z[e * NP2 + ((te[u] >> 13) & 1023)] = v;
             }
         }
     }
@@ -965,6 +978,23 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         NLG_TRY(up(hwq, &P.d_wq));
         P.thrx = 1e-12 * dmax;
         NLG_TRY(up(hSx, &P.d_Sx));
+        if (dim == 3) {
+            // per-point constants of the extended n^3 grid, the same for every element: number of boundary directions,
+            // slot in the face-grouped exchange array, index of the (clamped) pressure point, and which neighbours of
+            // an interior point are ghost layers.  Computed per point in the kernel they were ~2/3 of its instructions.
+            std::vector<int> tab((size_t)n * n * n);
+            for (int c = 0; c < n; ++c)
+                for (int b = 0; b < n; ++b)
+                    for (int a = 0; a < n; ++a) {
+                        const int nb = (a == 0 || a == n - 1) + (b == 0 || b == n - 1) + (c == 0 || c == n - 1);
+                        const int a2 = std::min(std::max(a, 1), n - 2) - 1, b2 = std::min(std::max(b, 1), n - 2) - 1,
+                                  c2 = std::min(std::max(c, 1), n - 2) - 1;
+                        const int q2 = a2 + n2 * (b2 + n2 * c2);
+                        const int fl = (a == 1) | ((a == n - 2) << 1) | ((b == 1) << 2) | ((b == n - 2) << 3) | ((c == 1) << 4) | ((c == n - 2) << 5);
+                        tab[(size_t)a + n * (b + n * c)] = nb | (fg_slot(n, a, b, c) << 2) | (q2 << 13) | (fl << 23);
+                    }
+            NLG_TRY(up(tab, &P.d_exttab));
+        }
         NLG_TRY(up(hlx, &P.d_lamx));
         NLG_HIP(hipMalloc(&P.d_W, sizeof(double) * (size_t)m->lvs));
         NLG_HIP(hipMemsetAsync(P.d_W, 0, sizeof(double) * (size_t)m->lvs, st));
@@ -1515,7 +1545,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         NLG_TRY(overlap_halo(m, st, true));
 #define FX_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
+        hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab); \
         break;
         switch (m->n) {
             FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(12)
@@ -1562,7 +1592,7 @@ void pprec_free(nlg_mesh *m) {
     double *dp[] = {P.d_S, P.d_invden, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_ra, P.d_xa, P.d_rag, P.d_tq, P.d_Sx, P.d_lamx, P.d_W, P.d_wq};
     for (double *p : dp)
         if (p) hipFree(p);
-    int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i};
+    int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i, P.d_exttab};
     for (int *p : ip)
         if (p) hipFree(p);
     if (P.d_Ainv32) hipFree(P.d_Ainv32);
