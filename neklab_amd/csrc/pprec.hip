@@ -64,6 +64,40 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
     }
 }
 
+// The same transform in place: a lane reads its whole column into registers before it writes the outputs, and the
+// columns of one stage are disjoint, so one LDS array serves as input and output (half the LDS per element -> twice
+// the resident elements per CU for a kernel that mostly waits).
+template <int N2, bool FWD, int AX>
+__device__ __forceinline__ void fdm_stage_inplace3(double *buf, const double *__restrict__ S, int lane) {
+    constexpr int NCOL = N2 * N2;
+    for (int col = lane; col < NCOL; col += 64) {
+        int base, stride;
+        if (AX == 0) {
+            base = col * N2;
+            stride = 1;
+        } else if (AX == 1) {
+            base = (col % N2) + N2 * N2 * (col / N2);
+            stride = N2;
+        } else {
+            base = col;
+            stride = N2 * N2;
+        }
+        double v[N2];
+#pragma unroll
+        for (int l = 0; l < N2; ++l) v[l] = buf[base + stride * l];
+        double o_[N2];
+#pragma unroll
+        for (int o = 0; o < N2; ++o) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < N2; ++l) a += (FWD ? S[l * N2 + o] : S[o * N2 + l]) * v[l];
+            o_[o] = a;
+        }
+#pragma unroll
+        for (int o = 0; o < N2; ++o) buf[base + stride * o] = o_[o];
+    }
+}
+
 // z_e = (Sz x Sy x Sx) [ invden o ((Sz x Sy x Sx)^T r_e) ] + xc[e]      (S stored row-major [point][mode])
 // One wave per element, four elements per block: the six 1-D transforms of an element are tiny (N2^3 points), so
 // the kernel is bound by launch/barrier latency, not by bytes; each lane owns whole columns and keeps them in
@@ -206,7 +240,7 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
                                                 double *__restrict__ z, const int *__restrict__ tab) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
     __shared__ double sL[WPB][3][N];
-    __shared__ double sA[WPB][NP], sB[WPB][NP];
+    __shared__ double sA[WPB][NP];   // the six transforms run in place (fdm_stage_inplace3)
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * WPB + wv;
@@ -242,22 +276,22 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
         sA[wv][q] = v;
     }
     __syncthreads();
-    fdm_stage<N, 3, true, 0>(sA[wv], sB[wv], Sg + 0 * N * N, lane);
+    fdm_stage_inplace3<N, true, 0>(sA[wv], Sg + 0 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, true, 1>(sB[wv], sA[wv], Sg + 1 * N * N, lane);
+    fdm_stage_inplace3<N, true, 1>(sA[wv], Sg + 1 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, true, 2>(sA[wv], sB[wv], Sg + 2 * N * N, lane);
+    fdm_stage_inplace3<N, true, 2>(sA[wv], Sg + 2 * N * N, lane);
     __syncthreads();
     for (int q = lane; q < NP; q += 64) {
         const double den = sL[wv][0][q % N] + sL[wv][1][(q / N) % N] + sL[wv][2][q / (N * N)];
-        sB[wv][q] = den > thr ? sB[wv][q] / den : 0.0;
+        sA[wv][q] = den > thr ? sA[wv][q] / den : 0.0;
     }
     __syncthreads();
-    fdm_stage<N, 3, false, 2>(sB[wv], sA[wv], Sg + 2 * N * N, lane);
+    fdm_stage_inplace3<N, false, 2>(sA[wv], Sg + 2 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, false, 1>(sA[wv], sB[wv], Sg + 1 * N * N, lane);
+    fdm_stage_inplace3<N, false, 1>(sA[wv], Sg + 1 * N * N, lane);
     __syncthreads();
-    fdm_stage<N, 3, false, 0>(sB[wv], sA[wv], Sg + 0 * N * N, lane);
+    fdm_stage_inplace3<N, false, 0>(sA[wv], Sg + 0 * N * N, lane);
     __syncthreads();
     if (act) {
 #pragma unroll
