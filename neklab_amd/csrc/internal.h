@@ -278,7 +278,16 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w);
 
 // ---- pprec.hip ----
 int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d);
-int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap = false);
+// PCG update fused into the first kernel of the preconditioner (null alpha: none): x += alpha p, r -= alpha (w - wmean)
+// written back, rr_part[block] = sum r^2 nw -- the residual is in registers there anyway
+struct nlg_pcg_upd {
+    const double *alpha = nullptr, *wmean = nullptr;
+    double *x = nullptr;
+    const double *p = nullptr, *w = nullptr, *nw = nullptr;
+    double *rr_part = nullptr;   // [(E + 3) / 4]
+};
+int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap = false,
+                 const nlg_pcg_upd *upd = nullptr);
 int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
                double *rz_part = nullptr, bool overlap = false);
 void pprec_free(nlg_mesh *m);

@@ -617,6 +617,8 @@ struct CGProblem {
     bool fused_pupdate = false;        // `apply` itself performs p <- z + beta p (gated by the done flag) before w = A p
     const double *rz_part = nullptr;   // [2][rz_n]: sum r.z , sum z   (written by `precond`)
     int rz_n = 0;
+    const double *rr_part = nullptr;   // [rr_n]: sum r^2 nw, written by `precond`, which then also performs the update
+    int rr_n = 0;                      // x += alpha p, r -= alpha (w - wmean) of the iteration (no k_cg_update launch)
     std::string tag;                   // non-empty: the iteration may be replayed from a hipGraph; names the solver and
                                        // every argument of `apply` / `precond` that is not a member of this struct
 };
@@ -662,6 +664,11 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
             launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, xc, P.npe, partial);
         }
     }
+    Red rd_rz_loop = rd_rz;   // inside the loop the r^2 sums may come from the preconditioner's first kernel
+    if (P.rr_part) {
+        rd_rz_loop.p[1] = P.rr_part;
+        rd_rz_loop.n[1] = P.rr_n;
+    }
     Red rd_pw = rd_std;
     if (P.pw_part) {
         rd_pw.p[0] = P.pw_part;
@@ -679,15 +686,16 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         if (!P.pw_part)
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
         NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
-        launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
-                  pc, P.ipw, P.nw, partial);
+        if (!P.rr_part)
+            launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
+                      pc, P.ipw, P.nw, partial);
         if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
         if (P.precond) {
             NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
             if (!P.rz_part)
                 launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
         }
-        NLG_TRY(reduce_post(rd_rz, 3, 1, 2));
+        NLG_TRY(reduce_post(rd_rz_loop, 3, 1, 2));
         if (!P.fused_pupdate)
             launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
         return 0;
@@ -715,7 +723,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
                      (void *)P.w[0], (void *)(nf > 1 ? P.w[1] : nullptr), (void *)(nf > 2 ? P.w[2] : nullptr),
                      (void *)(P.pc ? P.pc[0] : nullptr), (void *)(P.pc && nf > 1 ? P.pc[1] : nullptr), (void *)(P.pc && nf > 2 ? P.pc[2] : nullptr),
                      (const void *)P.ipw, (const void *)P.nw, P.tol2, P.use_tol, P.maxit, (void *)P.s, P.inv_n, P.npe, (const void *)P.pw_part,
-                     P.pw_n, (int)P.pw_sum, (int)P.fused_pupdate, (const void *)P.rz_part, P.rz_n);
+                     P.pw_n, (int)P.pw_sum, (int)P.fused_pupdate, (const void *)P.rz_part, P.rz_n + 100000 * (P.rr_part ? 1 : 0));
             nlg_linop::GraphSlot &slot = op->graphs[kb];
             ++slot.uses;
             if (!slot.exec && !slot.failed && slot.uses >= 2) {
@@ -945,12 +953,23 @@ int pres_solve(nlg_linop *op, double scale) {
         P.pc = nopc;
         P.npe = m->np2;
         double *rzp = m->dim == 3 ? op->d_part + 2 * m->E : nullptr;
-        P.precond = [m, rzp, overlap](const double *flag, const double *rr, double *zz, const double **xc) -> int {
+        // the PCG update of an iteration rides in the preconditioner's first kernel (which reads r anyway)
+        nlg_pcg_upd upd;
+        upd.alpha = op->d_s + S_N + S_ALPHA;
+        upd.wmean = op->d_s + S_N + S_WMEAN;
+        upd.x = op->pr_x;
+        upd.p = op->pr_p;
+        upd.w = op->pr_w;
+        upd.nw = op->nwp;
+        upd.rr_part = op->d_part + 2 * m->E + 2 * ((m->E + 3) / 4);
+        P.rr_part = upd.rr_part;
+        P.rr_n = (int)((m->E + 3) / 4);
+        P.precond = [m, rzp, overlap, upd](const double *flag, const double *rr, double *zz, const double **xc) -> int {
             // one stream: a fork/join through events costs more than it hides (measured: 98 vs 84 us per apply)
             nlg_ctx *c = m->ctx;
             ProfScope ps(c, P_PPREC);
             const double *coarse = nullptr;
-            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse, overlap));
+            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse, overlap, flag ? &upd : nullptr));   // flag == null: the initial residual
             NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz, rzp, overlap));   // z = local solves + prolonged coarse part
             *xc = nullptr;
             return 0;

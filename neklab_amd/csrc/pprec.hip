@@ -487,19 +487,31 @@ __global__ __launch_bounds__(NT) void k_sch_finish2(const double *__restrict__ f
 // t[e][c] = sum_q phi_c(q) r_e(q): the element-local part of R_1^T r, one wave per element
 template <int DIM>
 __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restrict__ flag, int64_t E, int n2, Hat hat,
-                                                          const double *__restrict__ r, double *__restrict__ t,
-                                                          double *__restrict__ W, const double *__restrict__ wq) {
+                                                          double *__restrict__ r, double *__restrict__ t,
+                                                          double *__restrict__ W, const double *__restrict__ wq,
+                                                          nlg_pcg_upd u) {
+    __shared__ double srr[4];
     if (flag && flag[0] != 0.0) return;
     constexpr int NC = 1 << DIM;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 4 + wid;
-    if (e >= E) return;
+    const bool act = e < E;
     const int np2 = DIM == 3 ? n2 * n2 * n2 : n2 * n2;
+    const bool upd = u.alpha != nullptr;
+    const double alpha = upd ? u.alpha[0] : 0.0, wmean = upd ? u.wmean[0] : 0.0;
+    double rr = 0.0;
     double a[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) a[c] = 0.0;
-    for (int q = lane; q < np2; q += 64) {
-        const double v = r[e * np2 + q];
+    for (int q = lane; act && q < np2; q += 64) {
+        double v = r[e * np2 + q];
+        if (upd) {   // the PCG update of this point: the new residual is what gets restricted
+            const int64_t i = e * np2 + q;
+            u.x[i] += alpha * u.p[i];
+            v -= alpha * (u.w[i] - wmean);
+            r[i] = v;
+            rr += v * v * u.nw[i];
+        }
         const double ha = hat.h1[q % n2], hb = hat.h1[(q / n2) % n2];
         const double hc = DIM == 3 ? hat.h1[q / (n2 * n2)] : 0.0;
         if (DIM == 2 && W) {
@@ -535,9 +547,16 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restri
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a[c] += __shfl_down(a[c], o, 64);
     }
-    if (lane == 0) {
+    if (lane == 0 && act) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) t[e * NC + c] = a[c];
+    }
+    if (upd) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rr += __shfl_down(rr, o, 64);
+        if (lane == 0) srr[wid] = rr;
+        __syncthreads();
+        if (threadIdx.x == 0) u.rr_part[blockIdx.x] = (srr[0] + srr[1]) + (srr[2] + srr[3]);
     }
 }
 
@@ -1121,9 +1140,9 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
                 rc = sem_cdabdtp(m, pp, ep);
                 if (rc) break;
                 if (dim == 3) {
-                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr);
+                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 } else {
-                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr);
+                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 }
                 if (hipMemcpyAsync(t8.data(), d_t8, sizeof(double) * t8.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipStreamSynchronize(st) != hipSuccess) {
@@ -1436,9 +1455,9 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
                 NLG_TRY(sem_cdabdtp(m, pp, ep));
                 if (me == r) continue;   // own block: already there
                 if (dim == 3) {
-                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr);
+                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 } else {
-                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr);
+                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 }
                 hipLaunchKernelGGL(k_q1_gather, dim3((nvert + NT - 1) / NT), dim3(NT), 0, st, (const double *)nullptr, nvert, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, 0.0, P.d_x);
                 hipLaunchKernelGGL(k_agg_restrict, dim3((na + 3) / 4), dim3(NT), 0, st, (const double *)nullptr, na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
@@ -1488,7 +1507,10 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
 
 // Coarse part of M^-1 r on `st`: xc[v] = omega dinv[v] (R_1^T r)[v] and P.d_xa = aggregate-level solve; pprec_fine
 // adds the two while prolonging.
-int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap) {
+int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap,
+                 const nlg_pcg_upd *upd) {
+    const nlg_pcg_upd uu = upd ? *upd : nlg_pcg_upd{};
+    double *rw = const_cast<double *>(r);   // written only when the PCG update rides along
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
     const int64_t E = m->E;
@@ -1498,12 +1520,12 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
     for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
     if (m->dim == 3) {
         NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
-        hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq,
-                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq);
+        hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq,
+                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq, uu);
     } else {
         NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
-        hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, r, P.d_tq,
-                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq);
+        hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq,
+                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq, uu);
     }
     hipLaunchKernelGGL(k_q1_gather, dim3((nv + NT - 1) / NT), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x);
     hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
