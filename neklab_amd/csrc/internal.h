@@ -303,6 +303,7 @@ int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);
 int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
                double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr);   // zf: fused u <- zf + beta u
+int sem_opdiv_blocks(const nlg_mesh *m);
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false, const double *gate = nullptr);

@@ -952,7 +952,8 @@ int pres_solve(nlg_linop *op, double scale) {
         const bool overlap = c.pprecond == 0 && m->pprec.overlap;
         P.pc = nopc;
         P.npe = m->np2;
-        double *rzp = m->dim == 3 ? op->d_part + 2 * m->E : nullptr;
+        // r.z / z sums from the last kernel of the preconditioner: 3-D always, 2-D with the overlapping variant
+        double *rzp = (m->dim == 3 || overlap) ? op->d_part + 2 * m->E : nullptr;
         // the PCG update of an iteration rides in the preconditioner's first kernel (which reads r anyway)
         nlg_pcg_upd upd;
         upd.alpha = op->d_s + S_N + S_ALPHA;
@@ -979,16 +980,14 @@ int pres_solve(nlg_linop *op, double scale) {
         const int pred = (op->istep < (int)op->pit_hist.size() && op->pit_hist[op->istep] > 0) ? op->pit_hist[op->istep] : op->last_piters;
         P.chunk = std::max(2, std::min(pred, 96));
     }
-    const bool fuse = m->dim == 3;   // the fused first-stage sums are rank-local; the all-reduce follows the second stage
-    double *pw_part = nullptr;
-    if (fuse) {
-        pw_part = op->d_part;
-        P.pw_part = pw_part;
-        P.pw_n = (int)m->E;
-        if (P.precond) {
-            P.rz_part = op->d_part + 2 * m->E;
-            P.rz_n = (int)((m->E + 3) / 4);
-        }
+    // fused first-stage sums (rank-local; the all-reduce follows the second stage): p.w and sum w from the divergence kernel,
+    // r.z and sum z from the preconditioner's last kernel
+    double *pw_part = op->d_part;
+    P.pw_part = pw_part;
+    P.pw_n = sem_opdiv_blocks(m);
+    if (P.precond && (m->dim == 3 || (c.pprecond == 0 && m->pprec.overlap))) {
+        P.rz_part = op->d_part + 2 * m->E;
+        P.rz_n = m->dim == 3 ? (int)((m->E + 3) / 4) : (int)((m->E * m->np2 + NT - 1) / NT);
     }
     // gated: launches past convergence (the host only looks at the flag once per chunk) return at once
     auto apply = [&](double *sflag) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w, pw_part, sflag + S_DONE); };

@@ -456,11 +456,13 @@ __global__ __launch_bounds__(NT) void k_sch_finish2(const double *__restrict__ f
                                                     const double *__restrict__ r, const double *__restrict__ wq,
                                                     const double *__restrict__ xc, const double *__restrict__ xa,
                                                     const int *__restrict__ agg, const int *__restrict__ vg, Hat hat,
-                                                    double *__restrict__ z) {
+                                                    double *__restrict__ z, double *__restrict__ part) {
     constexpr int N2 = N - 2, NP = N * N, NP2 = N2 * N2;
+    __shared__ double srz[2][NT / 64];
     if (flag && flag[0] != 0.0) return;
     const int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x;
-    if (i >= E * NP2) return;
+    double srzv = 0.0, szv = 0.0;
+    if (i < E * NP2) {
     const int64_t e = i / NP2;
     const int q = (int)(i % NP2), a = q % N2, b = q / N2;
     const double *We = W + e * NP;
@@ -482,6 +484,31 @@ __global__ __launch_bounds__(NT) void k_sch_finish2(const double *__restrict__ f
         v += c0 + hb * (c1 - c0);
     }
     z[i] = v;
+    srzv = r[i] * v;
+    szv = v;
+    }
+    if (part) {   // first-stage sums of the PCG: part[b] = sum r z, part[nb + b] = sum z
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            srzv += __shfl_down(srzv, o, 64);
+            szv += __shfl_down(szv, o, 64);
+        }
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (lane == 0) {
+            srz[0][wid] = srzv;
+            srz[1][wid] = szv;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < NT / 64; ++w) {
+                a += srz[0][w];
+                b += srz[1][w];
+            }
+            part[blockIdx.x] = a;
+            part[gridDim.x + blockIdx.x] = b;
+        }
+    }
 }
 
 // t[e][c] = sum_q phi_c(q) r_e(q): the element-local part of R_1^T r, one wave per element
@@ -1565,7 +1592,6 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
     const int *vg = P.d_vg;
     if (overlap && m->dim == 2) {
         NLG_CHECK(P.overlap, "pprec: the overlapping variant is not set up for this mesh");
-        NLG_CHECK(!rz_part, "pprec: fused sums exist for the 3-D kernels only");
         const unsigned gb = (unsigned)((E + 3) / 4);
         NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
         NLG_TRY(overlap_halo(m, st, false));
@@ -1583,7 +1609,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         const unsigned gf = (unsigned)((E * m->np2 + NT - 1) / NT);
 #define FF2_CASE(N_)                                                                                                  \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_sch_finish2<N_>), dim3(gf), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z); \
+        hipLaunchKernelGGL((k_sch_finish2<N_>), dim3(gf), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
         break;
         switch (m->n) {
             FF2_CASE(4) FF2_CASE(5) FF2_CASE(6) FF2_CASE(7) FF2_CASE(8)

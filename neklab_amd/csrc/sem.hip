@@ -1095,11 +1095,14 @@ __global__ __launch_bounds__(NT) void k_opgradt2(int64_t E, const double *__rest
 template <int N>
 __global__ __launch_bounds__(NT) void k_opdiv2(int64_t E, const double *__restrict__ Img,
                                                const double *__restrict__ Dmg, CF9 g, CF3 u, CF3 wt,
-                                               double *__restrict__ out, double scale) {
+                                               double *__restrict__ out, double scale, const double *__restrict__ pdot,
+                                               double *__restrict__ part, const double *__restrict__ gate) {
     constexpr int N2 = N - 2;
     constexpr int NP2 = N2 * N2, NP1 = N * N, SB = N2 * N;
     constexpr int EPB = NT / NP1 > 0 ? NT / NP1 : 1;
     __shared__ double sI[N2 * N], sD[N2 * N];
+    __shared__ double spw[2][NT / 64];
+    if (gate && gate[0] != 0.0) return;   // the surrounding PCG has converged
     __shared__ double sU[EPB][NP1];
     __shared__ double sB[EPB][2][SB];
     const int tid = threadIdx.x;
@@ -1139,7 +1142,37 @@ __global__ __launch_bounds__(NT) void k_opdiv2(int64_t E, const double *__restri
             acc += g.p[0 * 2 + i][gq] * t0 + g.p[1 * 2 + i][gq] * t1;
         }
     }
-    if (act && lt < NP2) out[e * NP2 + lt] = scale * acc;
+    double s1 = 0.0, s2 = 0.0;
+    if (act && lt < NP2) {
+        const double o = scale * acc;
+        out[e * NP2 + lt] = o;
+        if (part) {
+            s1 = pdot[e * NP2 + lt] * o;
+            s2 = o;
+        }
+    }
+    if (part) {   // first-stage sums of the surrounding PCG, as in the 3-D kernel: part[b] = sum pdot out, part[nb + b] = sum out
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_down(s1, o, 64);
+            s2 += __shfl_down(s2, o, 64);
+        }
+        const int lane = tid & 63, wid = tid >> 6;
+        if (lane == 0) {
+            spw[0][wid] = s1;
+            spw[1][wid] = s2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < NT / 64; ++w) {
+                a += spw[0][w];
+                b += spw[1][w];
+            }
+            part[blockIdx.x] = a;
+            part[gridDim.x + blockIdx.x] = b;
+        }
+    }
 }
 
 // ---- pointwise kernels of the convective term on the fine mesh ------------------------------------
@@ -1712,9 +1745,15 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
     return 0;
 }
 
+// number of first-stage sums sem_opdiv writes per reduction (pw_part holds 2 x this)
+int sem_opdiv_blocks(const nlg_mesh *m) {
+    if (m->dim == 3) return (int)m->E;
+    const int epb = NT / (m->n * m->n) > 0 ? NT / (m->n * m->n) : 1;
+    return (int)((m->E + epb - 1) / epb);
+}
+
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts, bool face_grouped,
               const double *pdot, double *pw_part, const double *gate) {
-    NLG_CHECK(!pw_part || m->dim == 3, "sem_opdiv: fused sums exist for the 3-D kernel only");
     ProfScope ps(m->ctx, P_OPDIV);
     CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
     CF3 wt = {{wts ? wts[0] : nullptr, wts ? wts[1] : nullptr, (wts && m->dim == 3) ? wts[2] : nullptr}};
@@ -1741,7 +1780,7 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
     {                                                                                                      \
         constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                       \
         hipLaunchKernelGGL((k_opdiv2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
-                           m->d_I12, m->d_D12, g, cu, wt, out, scale);                                     \
+                           m->d_I12, m->d_D12, g, cu, wt, out, scale, pdot, pw_part, gate);                \
     }
         NLG_FOR_N(DV2)
 #undef DV2
