@@ -133,6 +133,8 @@ __global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p,
 }
 
 // x += alpha p ; r -= alpha (w - wmean) ; z = pc r ; partial (r,z)_ipw, (r,r)_nw, sum(z)
+// Two points per lane (16-byte accesses; every field length is a multiple of 32): eight streams per component are
+// what this kernel is, so the width of an access is its efficiency.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3 x, F3 r, F3 z, CF3 p, CF3 w, CF3 pc,
                                                   const double *ipw, const double *nw, double *partial) {
@@ -140,14 +142,44 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
     if (s[S_DONE] != 0.0) return;
     const double alpha = s[S_ALPHA], wmean = s[S_WMEAN];
     double a = 0.0, b = 0.0, c3 = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-        const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
+    const int64_t n2 = n >> 1;
+    const double2 *ipw2 = reinterpret_cast<const double2 *>(ipw), *nw2 = reinterpret_cast<const double2 *>(nw);
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        const double2 wi = ipw ? ipw2[i] : make_double2(1.0, 1.0), wn = nw2[i];
 #pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            double2 *x2 = reinterpret_cast<double2 *>(x.p[c]), *r2 = reinterpret_cast<double2 *>(r.p[c]);
+            const double2 pv = reinterpret_cast<const double2 *>(p.p[c])[i], wv = reinterpret_cast<const double2 *>(w.p[c])[i];
+            double2 xv = x2[i], rv = r2[i];
+            xv.x += alpha * pv.x;
+            xv.y += alpha * pv.y;
+            x2[i] = xv;
+            rv.x -= alpha * (wv.x - wmean);
+            rv.y -= alpha * (wv.y - wmean);
+            double2 pcv = make_double2(1.0, 1.0);
+            if (pc.p[c]) pcv = reinterpret_cast<const double2 *>(pc.p[c])[i];
+            if (pcv.x == 0.0) rv.x = 0.0;   // Dirichlet dof (the Helmholtz preconditioner carries the mask): w is not masked
+            if (pcv.y == 0.0) rv.y = 0.0;
+            r2[i] = rv;
+            b += rv.x * rv.x * wn.x + rv.y * rv.y * wn.y;
+            if (pc.p[c]) {
+                double2 zv;
+                zv.x = pcv.x * rv.x;
+                zv.y = pcv.y * rv.y;
+                reinterpret_cast<double2 *>(z.p[c])[i] = zv;
+                a += rv.x * zv.x * wi.x + rv.y * zv.y * wi.y;
+                c3 += zv.x + zv.y;
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd length: the last point
+        const int64_t i = n - 1;
+        const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
         for (int c = 0; c < NF; ++c) {
             x.p[c][i] += alpha * p.p[c][i];
             double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
             const double pcv = pc.p[c] ? pc.p[c][i] : 1.0;
-            if (pcv == 0.0) rv = 0.0;   // Dirichlet dof (the Helmholtz preconditioner carries the mask): w is not masked
+            if (pcv == 0.0) rv = 0.0;
             r.p[c][i] = rv;
             b += rv * rv * wn;
             if (pc.p[c]) {
