@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: exptA matvec + Arnoldi orthogonalisation on the MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  Started without a
+launcher (WORLD_SIZE unset) and with N > 1 it starts the N rank processes itself (`python -m torch.distributed.run`,
+before anything in this process touches the GPU) and relays rank 0's line.
+
+Scaling (`--scaling`): "strong" (default, BASELINE.json configs[2] "1 GPU vs 8 GPU element-partitioned") -- ONE global
+problem of E = 10 000 elements split into N contiguous element blocks; "weak" -- every GPU holds an E-element block of an
+N-times larger box.  In both, `value` is matvecs per second of the GLOBAL operator.
 
 A "step" is one Arnoldi iteration at full basis size on BASELINE.json's headline configuration
 (configs[2]: 3-D, E = 10 000 = 25x20x20 spectral elements, N = 7 i.e. lx1 = 8, Krylov dimension m = 64):
@@ -35,6 +41,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: the global --nel box is split into N contiguous element blocks; weak: every rank holds "
+                         "a --nel block of an N times larger box")
     ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
                     help="shm: REHEARSAL of the N>1 path with all ranks on GPU 0 through the library's shared-memory "
                          "validation transport (RCCL refuses two ranks per device); its numbers are not bench results")
@@ -81,10 +90,29 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
     return None
 
 
+def spawn_ranks(args):
+    """No launcher around us and --gpus N > 1: start the N ranks as fresh children (one process per GPU) and relay
+    their output; this parent never touches the GPU (nothing GPU-related has been imported at this point)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
@@ -113,12 +141,25 @@ def main():
 
     # ---- synthetic inputs: deformed box, wall-masked, C0 noise on a smooth shear flow
     t0 = time.time()
-    # weak scaling: the global box is `world` copies of the per-GPU block stacked in the last direction; every
-    # rank generates only its own contiguous element block (Nek5000's block distribution) with the labels and
-    # element ids of the global mesh.  Shared faces are exchanged by the library's gather-scatter halo (RCCL
-    # send/recv); every reduction is a RCCL all-reduce.
-    gnel = tuple(nel[:-1]) + (nel[-1] * world,)
-    hm = box_mesh(gnel, n, deform=0.05, last_range=(rank * nel[-1], (rank + 1) * nel[-1]))
+    # Every rank generates only its own contiguous element block (Nek5000's block distribution: whole layers of the
+    # last direction) with the labels and element ids of the global mesh.  Shared faces are exchanged by the library's
+    # gather-scatter halo (RCCL send/recv); every reduction is a RCCL all-reduce.
+    # strong: the global box is --nel, its layers are dealt out as evenly as they divide (20 layers on 8 ranks: 3,3,3,3,
+    # 2,2,2,2); weak: the global box is `world` copies of --nel stacked in the last direction.
+    if args.scaling == "strong":
+        gnel = nel
+        if nel[-1] < world:
+            raise SystemExit("bench.py: strong scaling splits the %d element layers of the last direction; %d ranks "
+                             "are too many" % (nel[-1], world))
+        base, rem = divmod(nel[-1], world)
+        k0 = rank * base + min(rank, rem)
+        k1 = k0 + base + (1 if rank < rem else 0)
+    else:
+        gnel = tuple(nel[:-1]) + (nel[-1] * world,)
+        k0, k1 = rank * nel[-1], (rank + 1) * nel[-1]
+    E_global = int(np.prod(gnel))
+    hm = box_mesh(gnel, n, deform=0.05, last_range=(k0, k1))
+    E = hm.E                                   # local element count from here on
     gm = host.Mesh(ctx, hm)
     bf = host.nek_dvector(gm)
     L = hm.lengths
@@ -277,24 +318,23 @@ def main():
     if rank == 0:
         out = {
             "metric": "linop matvecs/sec + Arnoldi iter time, E=10k N=7, 1/2/4/8 GPU",
-            # weak scaling: a matvec of the N-times larger global operator is N matvecs of the per-GPU block the metric
-            # is quoted on (same time steps, N times the elements), so the whole-job figure counts it N times
-            "value": world * args.steps / elapsed,
+            # matvecs per second of the GLOBAL operator (strong: the same E-element problem at every N)
+            "value": args.steps / elapsed,
             "unit": "matvecs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if args.transport == "rccl" else "synthetic; REHEARSAL on one GPU (shm transport), not a result",
             "config": {"workload": "3-D deformed box E=%d (%s) lx1=%d (N=%d), Krylov dim m=%d, exptA: Re=%g bdf3/ext3 "
                                    "nsteps=%d(+2 history steps), tol 1e-9/1e-7, one Arnoldi iteration per step at k=m"
-                                   % (E, "x".join(map(str, nel)), n, n - 1, m, args.re, args.nsteps),
-                       "elements_per_gpu": E, "time_steps_per_matvec": steps_per_mv,
+                                   % (E_global, "x".join(map(str, gnel)), n, n - 1, m, args.re, args.nsteps),
+                       "elements_per_gpu": E_global / world, "time_steps_per_matvec": steps_per_mv,
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
                        "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
-                       "global_elements": E * world,
-                       "global_operator_matvecs_per_s": args.steps / elapsed,
-                       "value_definition": "matvecs of the %d-element per-GPU block per second, summed over the GPUs: one "
-                                           "matvec of the global (N x %d elements) operator counts N" % (E, E),
+                       "global_elements": E_global,
+                       "element_matvecs_per_s": E_global * args.steps / elapsed,
+                       "value_definition": "exptA matvecs (+ CGS2 at k = m) of the global %d-element operator per second"
+                                           % E_global,
                        "operator_applies_per_s_per_field_per_gpu": None if u12_per_s is None else round(u12_per_s, 1),
                        "arnoldi_orthogonalisation_ms_at_k=m": None if u3_ms is None else round(u3_ms, 3),
                        "arnoldi_orthogonalisation_ms_vs_k": u3_vs_k,

@@ -123,6 +123,12 @@ int nlg_vec_copy(nlg_vec *dst, const nlg_vec *src);
 int nlg_vec_zero(nlg_vec *self);
 /* nek_drand   real_vectors.f90:52-123   (interface :69-72); seed replaces the compiler RNG */
 int nlg_vec_rand(nlg_vec *self, int ifnorm, uint64_t seed);
+/* The two halves of nek_drand, exported so that each can be compared with the oracle on its own: the mth_rand noise
+ * (neklab_vectors.f90:305-314) added to every active field, real_vectors.f90:62-98 -- and the part that makes the
+ * field admissible: opdssum * vmult, dsavg, bcdirvc / bcdirsc, optional normalisation, nrst = 0 (:100-122).
+ * nlg_vec_rand = noise + finish. */
+int nlg_vec_rand_noise(nlg_vec *self, uint64_t seed);
+int nlg_vec_rand_finish(nlg_vec *self, int ifnorm);
 /* nek_dscal   real_vectors.f90:125-160  (interface :74-77) */
 int nlg_vec_scal(nlg_vec *self, double alpha);
 /* nek_daxpby  real_vectors.f90:162-206  (interface :79-84): self = alpha*vec + beta*self */
@@ -133,6 +139,14 @@ int nlg_vec_dot(const nlg_vec *self, const nlg_vec *vec, double *out);
 int nlg_vec_norm(const nlg_vec *self, double *out);
 /* nek_dsize   real_vectors.f90:235-247  (interface :91-93) */
 int nlg_vec_size(const nlg_vec *self, int64_t *out);
+/* the same as a plain function value (-1: NULL handle): the reference declares nek_dsize `pure`
+ * (neklab_vectors.f90:91-93), and a pure Fortran function can only call interfaces that are themselves pure */
+int64_t nlg_vec_size_value(const nlg_vec *self);
+/* outpost_dnek  src/neklab_utils.f90:305-333 (Nek5000 `outpost(vx, vy, vz, pr, t, prefix)`): one vector -> one Nek5000
+ * field file at `path` ("#std" header, fp64): GLL coordinates when with_coords != 0 (Nek5000 writes them into the first
+ * file of a series only), velocity, the pressure mapped to the velocity mesh (Nek5000's `mappr` for a Pn-Pn-2 run), the
+ * first scalar if the vector carries one.  Single rank. */
+int nlg_vec_outpost(const nlg_vec *self, const char *path, int with_coords, double time, int istep);
 /* dsave_rst / dget_rst / dhas_rst_fields / dclear_rst_fields  real_vectors.f90:249-346 (irst 1-based) */
 int nlg_vec_save_rst(nlg_vec *self, const nlg_vec *vec_rst, int irst);
 int nlg_vec_get_rst(const nlg_vec *self, nlg_vec *vec_rst, int irst);

@@ -76,6 +76,10 @@ SIGNATURES = {
     "nlg_vec_copy": (C.c_int, [vp, vp]),
     "nlg_vec_zero": (C.c_int, [vp]),
     "nlg_vec_rand": (C.c_int, [vp, C.c_int, C.c_uint64]),
+    "nlg_vec_rand_noise": (C.c_int, [vp, C.c_uint64]),
+    "nlg_vec_size_value": (C.c_int64, [vp]),
+    "nlg_vec_outpost": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_double, C.c_int]),
+    "nlg_vec_rand_finish": (C.c_int, [vp, C.c_int]),
     "nlg_vec_scal": (C.c_int, [vp, C.c_double]),
     "nlg_vec_axpby": (C.c_int, [C.c_double, vp, C.c_double, vp]),
     "nlg_vec_dot": (C.c_int, [vp, vp, c_double_p]),

@@ -48,6 +48,9 @@ int scalars_to_host(nlg_ctx *ctx, int first, int count, double *out) {
 
 int reduce_ws_reserve(nlg_ctx *ctx, int nvec) {
     if (nvec <= ctx->max_red_vec) return 0;
+    // the first reservation already covers a Krylov dimension of 256 (2 MB): later bases then never reallocate the
+    // workspace under kernels or captured graphs that hold its address (hipFree synchronises the device in any case)
+    if (nvec < 264) nvec = 264;
     if (ctx->d_partial) NLG_HIP(hipFree(ctx->d_partial));
     ctx->d_partial = nullptr;
     NLG_HIP(hipMalloc(&ctx->d_partial, sizeof(double) * (size_t)nvec * kMaxBlocksReduce));

@@ -748,7 +748,9 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
                           (op->graph_mode == 2 || (op->graph_mode == 1 && op->mesh->lvn <= gmax));
         if (want) {
             char kb[512];
-            snprintf(kb, sizeof(kb), "%s|%d|%d|%lld|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p|%p|%a|%d|%d|%p|%a|%d|%p|%d|%d|%d|%p|%d", P.tag.c_str(), giters, nf,
+            // (the reduction workspace is part of the signature: reduce_ws_reserve may reallocate it when a larger basis
+            //  arrives later, and the captured kernels hold the old pointer)
+            snprintf(kb, sizeof(kb), "%s|%p|%d|%d|%lld|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p|%p|%a|%d|%d|%p|%a|%d|%p|%d|%d|%d|%p|%d", P.tag.c_str(), (void *)ctx->d_partial, giters, nf,
                      (long long)P.n, (void *)P.x[0], (void *)(nf > 1 ? P.x[1] : nullptr), (void *)(nf > 2 ? P.x[2] : nullptr), (void *)P.r[0],
                      (void *)(nf > 1 ? P.r[1] : nullptr), (void *)(nf > 2 ? P.r[2] : nullptr), (void *)P.z[0], (void *)(nf > 1 ? P.z[1] : nullptr),
                      (void *)(nf > 2 ? P.z[2] : nullptr), (void *)P.p[0], (void *)(nf > 1 ? P.p[1] : nullptr), (void *)(nf > 2 ? P.p[2] : nullptr),

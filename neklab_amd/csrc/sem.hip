@@ -1512,11 +1512,17 @@ __global__ void k_rand_add(int dim, int n, int64_t E, const int64_t *lglel, CF3 
         double fc[3];
         for (int c = 0; c < 3; ++c)
             fc[c] = (double)(splitmix64((base + (uint64_t)c) ^ sk) >> 11) * (1.0 / 9007199254740992.0) * 1.0e4;
+        // mth_rand, neklab_vectors.f90:305-314.  The two nested 1e3 * sin() amplify a rounding difference in the
+        // argument a million-fold, so the expression is evaluated operation by operation (no fused multiply-add), left
+        // to right as written: the value then depends on sin / cos alone and agrees with the oracle's to ~1e-9.
         const double x = X.p[0][q], y = X.p[1][q];
-        double r = fc[0] * ((double)ieg + x * sin(y)) + fc[1] * ix * iy + fc[2] * ix;
-        if (dim == 3) r = fc[0] * ((double)ieg + X.p[2][q] * sin(r)) + fc[1] * iz * ix + fc[2] * iz;
-        r = 1.0e3 * sin(r);
-        r = 1.0e3 * sin(r);
+        double r = __dadd_rn(__dadd_rn(__dmul_rn(fc[0], __dadd_rn((double)ieg, __dmul_rn(x, sin(y)))), __dmul_rn(__dmul_rn(fc[1], (double)ix), (double)iy)),
+                             __dmul_rn(fc[2], (double)ix));
+        if (dim == 3)
+            r = __dadd_rn(__dadd_rn(__dmul_rn(fc[0], __dadd_rn((double)ieg, __dmul_rn(X.p[2][q], sin(r)))), __dmul_rn(__dmul_rn(fc[1], (double)iz), (double)ix)),
+                          __dmul_rn(fc[2], (double)iz));
+        r = __dmul_rn(1.0e3, sin(r));
+        r = __dmul_rn(1.0e3, sin(r));
         field[q] += cos(r);
     }
 }
@@ -2387,6 +2393,12 @@ int nlg_mesh_get(const nlg_mesh *m, const char *name, double *out, int64_t count
 
 // ---- rand (needs the gather-scatter, hence lives here) ---------------------------------------------
 int nlg_vec_rand(nlg_vec *self, int ifnorm, uint64_t seed) {
+    NLG_TRY(nlg_vec_rand_noise(self, seed));
+    return nlg_vec_rand_finish(self, ifnorm);
+}
+
+// first half of nek_drand (real_vectors.f90:62-98): the mth_rand noise added point by point to every active field
+int nlg_vec_rand_noise(nlg_vec *self, uint64_t seed) {
     NLG_CHECK(self, "nlg_vec_rand: NULL vector");
     nlg_mesh *m = self->mesh;
     hipStream_t s = m->ctx->stream;
@@ -2395,6 +2407,15 @@ int nlg_vec_rand(nlg_vec *self, int ifnorm, uint64_t seed) {
         double *fld = f < m->dim ? self->vel(f) : self->theta(f - m->dim);
         hipLaunchKernelGGL(k_rand_add, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->dim, m->n, m->E, m->d_lglel, X, fld, f, seed);
     }
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+// second half (real_vectors.f90:100-122): continuity, Dirichlet masks, optional normalisation, history cleared
+int nlg_vec_rand_finish(nlg_vec *self, int ifnorm) {
+    NLG_CHECK(self, "nlg_vec_rand: NULL vector");
+    nlg_mesh *m = self->mesh;
+    hipStream_t s = m->ctx->stream;
     // opdssum, opcolv(vmult), dsavg, bcdirvc   (real_vectors.f90:100-105)
     double *v[3] = {self->vel(0), self->vel(1), m->dim == 3 ? self->vel(2) : nullptr};
     F3 fv = {{v[0], v[1], v[2]}};
@@ -2430,6 +2451,128 @@ int nlg_vec_rand(nlg_vec *self, int ifnorm, uint64_t seed) {
     self->nrst = 0;
     return 0;
 }
+
+// ---- outpost_dnek (src/neklab_utils.f90:305-333): one vector -> one Nek5000 "#std" field file -----------------
+// Layout as written by Nek5000's mfo_outfld for a Pn-Pn-2 run: 132-byte header, endian tag, element map, then the groups
+// X (optional), U, P (pressure interpolated GL -> GLL inside every element and averaged across elements: `mappr`),
+// T (first scalar), element by element, component by component; 3-D files end with float32 min / max records.
+// Host-side I/O on one rank; the only device work is the pressure map.
+int nlg_vec_outpost(const nlg_vec *v, const char *path, int with_coords, double time, int istep) {
+    NLG_CHECK(v && path, "nlg_vec_outpost: NULL argument");
+    nlg_mesh *m = v->mesh;
+    NLG_CHECK(!m->ctx->distributed(), "nlg_vec_outpost: single-rank writer (every rank would write its own file)");
+    hipStream_t st = m->ctx->stream;
+    const int dim = m->dim, n = m->n, n2 = m->n2, np1 = m->np1;
+    const int64_t E = m->E;
+    // GL(n2) -> GLL(n) Lagrange interpolation, row-major n x n2
+    std::vector<double> I21((size_t)n * n2, 1.0);
+    const auto &z1 = m->ops.z1, &z2 = m->ops.z2;
+    for (int a = 0; a < n; ++a)
+        for (int k = 0; k < n2; ++k) {
+            double p = 1.0;
+            for (int l = 0; l < n2; ++l)
+                if (l != k) p *= (z1[a] - z2[l]) / (z2[k] - z2[l]);
+            I21[(size_t)a * n2 + k] = p;
+        }
+    double *dM = nullptr;
+    NLG_HIP(hipMalloc(&dM, sizeof(double) * I21.size()));
+    NLG_HIP(hipMemcpyAsync(dM, I21.data(), sizeof(double) * I21.size(), hipMemcpyHostToDevice, st));
+    double *p1 = sem_scratch1(m, 0);
+    NLG_CHECK(p1, "nlg_vec_outpost: scratch allocation failed");
+    NLG_TRY(sem_tensor(m, v->pr(), p1, n2, n, dM, dM, dM, nullptr));
+    double *f1[1] = {p1};
+    NLG_TRY(sem_gs(m, f1, 1));
+    {
+        F3 fw = {{p1, nullptr, nullptr}};
+        CF3 vm = {{m->d_vmult, nullptr, nullptr}};
+        hipLaunchKernelGGL(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, fw, vm, m->lvn);
+    }
+    std::vector<std::vector<double>> grp;   // each [E][nc][np1]
+    std::vector<int> ncs;
+    std::string code;
+    auto fetch = [&](const double *const *src, int nc) -> int {
+        std::vector<double> h((size_t)E * np1), out((size_t)E * nc * np1);
+        for (int c = 0; c < nc; ++c) {
+            NLG_HIP(hipMemcpyAsync(h.data(), src[c], sizeof(double) * (size_t)E * np1, hipMemcpyDeviceToHost, st));
+            NLG_HIP(hipStreamSynchronize(st));
+            for (int64_t e = 0; e < E; ++e) memcpy(&out[((size_t)e * nc + c) * np1], &h[(size_t)e * np1], sizeof(double) * np1);
+        }
+        grp.push_back(std::move(out));
+        ncs.push_back(nc);
+        return 0;
+    };
+    if (with_coords) {
+        const double *x[3] = {m->d_x[0], m->d_x[1], m->d_x[2]};
+        NLG_TRY(fetch(x, dim));
+        code += "X";
+    }
+    {
+        const double *u[3] = {v->vel(0), v->vel(1), dim == 3 ? v->vel(2) : nullptr};
+        NLG_TRY(fetch(u, dim));
+        code += "U";
+        const double *pp[1] = {p1};
+        NLG_TRY(fetch(pp, 1));
+        code += "P";
+        if (v->nscal > 0) {
+            const double *tt[1] = {v->theta(0)};
+            NLG_TRY(fetch(tt, 1));
+            code += "T";
+        }
+    }
+    hipFree(dM);
+    // time in Fortran's e20.13 form 0.dddddddddddddE+xx
+    char mant[64];
+    {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%.12E", time);        // d.ddddddddddddE+xx
+        std::string b(buf);
+        const size_t ep = b.find('E');
+        std::string digits;
+        for (char ch : b.substr(0, ep))
+            if (ch >= '0' && ch <= '9') digits += ch;
+        int ex = atoi(b.c_str() + ep + 1);
+        if (time != 0.0) ex += 1;
+        else ex = 0;
+        snprintf(mant, sizeof(mant), "%s0.%sE%+03d", time < 0 ? "-" : "", digits.c_str(), ex);
+    }
+    char hdr[256];
+    snprintf(hdr, sizeof(hdr), "#std %1d %2d %2d %2d %10lld %10lld %20s %9d %6d %6d %-10s%15s %s", 8, n, n, dim == 3 ? n : 1, (long long)E,
+             (long long)E, mant, istep, 0, 1, code.c_str(), "1.0000000E+00", "F");
+    std::string h132(hdr);
+    h132.resize(132, ' ');
+    FILE *f = fopen(path, "wb");
+    NLG_CHECK(f, "nlg_vec_outpost: cannot open %s", path);
+    fwrite(h132.data(), 1, 132, f);
+    const float tag = 6.54321f;
+    fwrite(&tag, 4, 1, f);
+    std::vector<int32_t> elmap((size_t)E);
+    for (int64_t e = 0; e < E; ++e) elmap[e] = (int32_t)(m->h_lglel.empty() ? e + 1 : m->h_lglel[e] + 1);
+    fwrite(elmap.data(), 4, (size_t)E, f);
+    for (auto &g : grp) fwrite(g.data(), 8, g.size(), f);
+    if (dim == 3)
+        for (size_t q = 0; q < grp.size(); ++q) {
+            const int nc = ncs[q];
+            std::vector<float> mm((size_t)E * nc * 2);
+            for (int64_t e = 0; e < E; ++e)
+                for (int c = 0; c < nc; ++c) {
+                    const double *a = &grp[q][((size_t)e * nc + c) * np1];
+                    double lo = a[0], hi = a[0];
+                    for (int i = 1; i < np1; ++i) {
+                        lo = a[i] < lo ? a[i] : lo;
+                        hi = a[i] > hi ? a[i] : hi;
+                    }
+                    mm[((size_t)e * nc + c) * 2] = (float)lo;
+                    mm[((size_t)e * nc + c) * 2 + 1] = (float)hi;
+                }
+            fwrite(mm.data(), 4, mm.size(), f);
+        }
+    const bool bad = ferror(f) != 0;
+    fclose(f);
+    NLG_CHECK(!bad, "nlg_vec_outpost: write error on %s", path);
+    return 0;
+}
+
+int64_t nlg_vec_size_value(const nlg_vec *self) { return self ? (int64_t)self->ncomp * self->mesh->lvn + self->mesh->lpn : -1; }
 
 // ---- operator-level entry points ------------------------------------------------------------------
 static int vel_ptrs(const nlg_vec *v, double **p) {

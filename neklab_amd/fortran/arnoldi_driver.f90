@@ -6,12 +6,12 @@
 !!         base flow, start vector).  Output: the Hessenberg matrix on stdout, one entry per line.
 program arnoldi_driver
    use iso_c_binding
-   use LightKrylov, only: dp, abstract_vector_rdp, abstract_exptA_linop_rdp
-   use neklab_gpu
+   use LightKrylov, only: abstract_vector_rdp, abstract_exptA_linop_rdp
+   use neklab_gpu                            ! round-1 module name: re-exports `neklab`
    implicit none
    integer :: ldim, lx1, nelv, lvn, lpn, k, kdim, i, j, u
    integer(c_int64_t), allocatable :: glo(:)
-   real(dp), allocatable :: x(:), y(:), z(:), m1(:), m2(:), m3(:), bx(:), by(:), bz(:), vx(:), vy(:), vz(:), pr(:)
+   real(dp), allocatable :: x(:), y(:), z(:), m1(:), m2(:), m3(:), bx(:), by(:), bz(:), vx(:), vy(:), vz(:), pr(:), t(:)
    real(dp) :: tau, re, dt, beta
    real(dp), allocatable :: H(:, :)
    type(nek_dvector), allocatable :: bf, Xb(:)
@@ -24,8 +24,8 @@ program arnoldi_driver
    lvn = nelv*lx1**ldim
    lpn = nelv*(lx1 - 2)**ldim
    allocate (x(lvn), y(lvn), z(lvn), m1(lvn), m2(lvn), m3(lvn), bx(lvn), by(lvn), bz(lvn), vx(lvn), vy(lvn), vz(lvn))
-   allocate (glo(lvn), pr(lpn))
-   z = 0; m3 = 0; bz = 0; vz = 0; pr = 0
+   allocate (glo(lvn), pr(lpn), t(1))
+   z = 0; m3 = 0; bz = 0; vz = 0; pr = 0; t = 0
    read (u) x, y
    if (ldim == 3) read (u) z
    read (u) glo
@@ -40,16 +40,15 @@ program arnoldi_driver
    call neklab_gpu_init(0)
    call neklab_gpu_set_mesh(ldim, lx1, nelv, x, y, z, glo, m1, m2, m3, .false.)
 
-   allocate (bf); call nek2vec_host(bf, bx, by, bz, pr, lvn, lpn, ldim == 3)
+   allocate (bf); call nek2vec(bf, bx, by, bz, pr, t)
    allocate (exptA)
    exptA%tau = tau
    exptA%baseflow = bf                       ! deep copy through defined assignment
-   exptA%cfg%torder = 0                      ! -> defaults, then overrides
-   call set_cfg(exptA)
+   call set_cfg(exptA)                       ! this driver fills in the solver configuration itself
    call exptA%init()
 
    allocate (Xb(kdim + 1))
-   call nek2vec_host(Xb(1), vx, vy, vz, pr, lvn, lpn, ldim == 3)
+   call nek2vec(Xb(1), vx, vy, vz, pr, t)
    allocate (H(kdim + 1, kdim)); H = 0.0_dp
    beta = Xb(1)%norm(); call Xb(1)%scal(1.0_dp/beta)
    do k = 1, kdim
@@ -77,6 +76,7 @@ contains
       A%cfg%torder = 3; A%cfg%maxit_v = 400; A%cfg%maxit_p = 4000
       A%cfg%fixed_iters_v = 0; A%cfg%fixed_iters_p = 0; A%cfg%pprecond = 0; A%cfg%pproj = 1
       A%cfg%ifheat = 0; A%cfg%conductivity = 1.0_dp; A%cfg%rhocp = 1.0_dp; A%cfg%buoy = 0.0_dp
+      A%cfg_set = .true.
    end subroutine
 
    !> one Arnoldi step written against the abstract API only (CGS2 with k separate dots and axpbys)

@@ -1,0 +1,243 @@
+!> Drop-in for the reference's module of the same name: `nek_dvector` with every type-bound procedure forwarded through
+!! ISO_C_BINDING to libneklab_gpu.so (include/neklab_gpu.h).
+!!
+!! Mapping (file:line under /root/reference):
+!!   type nek_dvector                     src/vectors/neklab_vectors.f90:26-50
+!!   constructor nek_dvector(vx, vy, ..)  src/vectors/neklab_vectors.f90:53-61
+!!   zero/rand/scal/axpby/dot/get_size    src/vectors/real_vectors.f90:37-247
+!!   save_rst/get_rst/has_rst_fields/clear_rst_fields               :249-346
+!!
+!! Object semantics.  The reference's vectors are plain static arrays: intrinsic assignment, sourced allocation and
+!! structure constructors deep-copy them (SURVEY.md 7.3 item 5).  Here the fields live in HBM behind an opaque handle, so
+!!   * `=` is a defined assignment (clone / copy) and the type has a finaliser (destroy);
+!!   * every object remembers the address it was created at (`owner`).  A bitwise copy made behind the type's back
+!!     (allocate(.., source=), a structure-constructor component, an array assignment) has the same handle but another
+!!     address: it is recognised on its first use as an inout argument and given its own clone, and a finaliser only
+!!     destroys the handle its object owns -- never a double free, never two vectors writing the same memory;
+!!   * handles are created on first use, so `allocate(X(k))`, `intent(out)` dummies and `mold=` allocations cost nothing.
+!! A non-zero return code from the C ABI becomes `error stop` with nlg_last_error(), which is what stop_error does in the
+!! reference (src/neklab_nek_setup.f90:406-417); a wrong dynamic type calls type_error as the reference does.
+module neklab_vectors
+   use iso_c_binding
+   use LightKrylov, only: dp, abstract_vector_rdp, type_error
+   use neklab_gpu_capi
+   implicit none
+   private
+   character(len=*), parameter, private :: this_module = 'neklab_vectors'
+
+   public :: nek_dvector_handle, nek_dvector_ensure
+
+   type, extends(abstract_vector_rdp), public :: nek_dvector
+      type(c_ptr) :: h = c_null_ptr
+      integer(c_intptr_t) :: owner = 0
+   contains
+      private
+      procedure, pass(self), public :: zero => nek_dzero
+      procedure, pass(self), public :: rand => nek_drand
+      procedure, pass(self), public :: scal => nek_dscal
+      procedure, pass(self), public :: axpby => nek_daxpby
+      procedure, pass(self), public :: dot => nek_ddot
+      procedure, pass(self), public :: get_size => nek_dsize
+      procedure, pass(self), public :: save_rst => dsave_rst
+      procedure, pass(self), public :: get_rst => dget_rst
+      procedure, pass(self), public :: has_rst_fields => dhas_rst_fields
+      procedure, pass(self), public :: clear_rst_fields => dclear_rst_fields
+      procedure, pass(lhs) :: assign_dvector
+      generic, public :: assignment(=) => assign_dvector
+      final :: finalize_dvector, finalize_dvector_rank1
+   end type nek_dvector
+
+   ! --> Constructor (reference: construct_nek_dvector, neklab_vectors.f90:53-61; not pure: it allocates device memory)
+   interface nek_dvector
+      module procedure construct_nek_dvector
+   end interface
+
+contains
+
+   !> make sure `self` has a handle of its own (see the header): create on first use, clone if `self` is a bitwise copy
+   subroutine nek_dvector_ensure(self)
+      class(nek_dvector), intent(inout) :: self
+      type(c_ptr) :: hnew
+      if (.not. c_associated(self%h)) then
+         call nlg_check(c_vec_create(nlg_mesh, int(nek_nscal, c_int), int(nek_lorder, c_int), self%h), 'nek_dvector allocate')
+         self%owner = loc(self)
+      else if (self%owner /= loc(self)) then
+         call nlg_check(c_vec_clone(self%h, hnew), 'nek_dvector copy-on-detect')
+         self%h = hnew
+         self%owner = loc(self)
+      end if
+   end subroutine
+
+   !> handle for a read-only use (a bitwise copy may read through the original's handle)
+   function nek_dvector_handle(self) result(h)
+      class(nek_dvector), intent(in) :: self
+      type(c_ptr) :: h
+      if (.not. c_associated(self%h)) then
+         write (*, '(A)') 'ERROR in '//this_module//': use of a nek_dvector that holds no data yet'
+         error stop 1
+      end if
+      h = self%h
+   end function
+
+   function construct_nek_dvector(vx, vy, vz, pr, theta) result(out)
+      real(dp), intent(in) :: vx(*), vy(*)
+      real(dp), optional, intent(in) :: vz(*), pr(*), theta(*)
+      type(nek_dvector) :: out
+      call nek_dvector_ensure(out)
+      call nlg_check(c_vec_zero(out%h), 'construct_nek_dvector')
+      call nlg_check(c_vec_set_field(out%h, 0_c_int, 0_c_int, vx, nek_lvn), 'construct_nek_dvector')
+      call nlg_check(c_vec_set_field(out%h, 1_c_int, 0_c_int, vy, nek_lvn), 'construct_nek_dvector')
+      if (present(vz) .and. nek_ldim == 3) call nlg_check(c_vec_set_field(out%h, 2_c_int, 0_c_int, vz, nek_lvn), 'construct_nek_dvector')
+      if (present(pr)) call nlg_check(c_vec_set_field(out%h, 3_c_int, 0_c_int, pr, nek_lpn), 'construct_nek_dvector')
+      if (present(theta) .and. nek_nscal > 0) call nlg_check(c_vec_set_field(out%h, 4_c_int, 0_c_int, theta, nek_lvn), 'construct_nek_dvector')
+   end function
+
+   !-----------------------------------------
+   !-----     TYPE-BOUND PROCEDURES     -----
+   !-----------------------------------------
+   subroutine nek_dzero(self)
+      class(nek_dvector), intent(inout) :: self
+      if (c_associated(self%h) .and. self%owner /= loc(self)) then      ! a bitwise copy about to be overwritten: no clone needed
+         self%h = c_null_ptr
+      end if
+      call nek_dvector_ensure(self)
+      call nlg_check(c_vec_zero(self%h), 'nek_dzero')
+   end subroutine
+
+   subroutine nek_drand(self, ifnorm)
+      class(nek_dvector), intent(inout) :: self
+      logical, optional, intent(in) :: ifnorm
+      integer(c_int) :: nrm
+      integer(c_int64_t), save :: seed = 0
+      nrm = 0
+      if (present(ifnorm)) nrm = merge(1, 0, ifnorm)
+      call nek_dvector_ensure(self)
+      seed = seed + 1     ! successive calls draw different fields, like random_number in the reference
+      call nlg_check(c_vec_rand(self%h, nrm, seed), 'nek_drand')
+   end subroutine
+
+   subroutine nek_dscal(self, alpha)
+      class(nek_dvector), intent(inout) :: self
+      real(dp), intent(in) :: alpha
+      call nek_dvector_ensure(self)
+      call nlg_check(c_vec_scal(self%h, alpha), 'nek_dscal')
+   end subroutine
+
+   subroutine nek_daxpby(alpha, vec, beta, self)
+      class(nek_dvector), intent(inout) :: self
+      real(dp), intent(in) :: alpha
+      class(abstract_vector_rdp), intent(in) :: vec
+      real(dp), intent(in) :: beta
+      call nek_dvector_ensure(self)
+      select type (vec)
+      type is (nek_dvector)
+         call nlg_check(c_vec_axpby(alpha, nek_dvector_handle(vec), beta, self%h), 'nek_daxpby')
+      class default
+         call type_error('vec', 'nek_dvector', 'IN', this_module, 'nek_daxpby')      ! real_vectors.f90:202-204
+      end select
+   end subroutine
+
+   function nek_ddot(self, vec) result(alpha)
+      class(nek_dvector), intent(in) :: self
+      class(abstract_vector_rdp), intent(in) :: vec
+      real(dp) :: alpha
+      alpha = 0.0_dp
+      select type (vec)
+      type is (nek_dvector)
+         call nlg_check(c_vec_dot(nek_dvector_handle(self), nek_dvector_handle(vec), alpha), 'nek_ddot')
+      class default
+         call type_error('vec', 'nek_dvector', 'IN', this_module, 'nek_ddot')        ! real_vectors.f90:229-231
+      end select
+   end function
+
+   pure function nek_dsize(self) result(n)
+      class(nek_dvector), intent(in) :: self
+      integer :: n
+      if (c_associated(self%h)) then
+         n = int(c_vec_size_value(self%h))
+      else      ! not materialised yet: the size is a property of the mesh and the case (real_vectors.f90:235-247)
+         n = int((nek_ldim + nek_nscal)*nek_lvn + nek_lpn)
+      end if
+   end function
+
+   subroutine dsave_rst(self, vec_rst, irst)
+      class(nek_dvector), intent(inout) :: self
+      class(abstract_vector_rdp), intent(in) :: vec_rst
+      integer, intent(in) :: irst
+      call nek_dvector_ensure(self)
+      select type (vec_rst)
+      type is (nek_dvector)
+         call nlg_check(c_vec_save_rst(self%h, nek_dvector_handle(vec_rst), int(irst, c_int)), 'dsave_rst')
+      class default
+         call type_error('vec_rst', 'nek_dvector', 'IN', this_module, 'dsave_rst')     ! real_vectors.f90:286-288
+      end select
+   end subroutine
+
+   subroutine dget_rst(self, vec_rst, irst)
+      class(nek_dvector), intent(in) :: self
+      class(abstract_vector_rdp), intent(inout) :: vec_rst
+      integer, intent(in) :: irst
+      select type (vec_rst)
+      type is (nek_dvector)
+         call nek_dvector_ensure(vec_rst)
+         call nlg_check(c_vec_get_rst(nek_dvector_handle(self), vec_rst%h, int(irst, c_int)), 'dget_rst')
+      class default
+         call type_error('vec_rst', 'nek_dvector', 'OUT', this_module, 'dget_rst')     ! real_vectors.f90:329-331
+      end select
+   end subroutine
+
+   function dhas_rst_fields(self) result(has_rst_fields)
+      class(nek_dvector), intent(in) :: self
+      logical :: has_rst_fields
+      integer(c_int) :: flag
+      has_rst_fields = .false.
+      if (.not. c_associated(self%h)) return
+      call nlg_check(c_vec_has_rst(self%h, flag), 'dhas_rst_fields')
+      has_rst_fields = flag /= 0
+   end function
+
+   subroutine dclear_rst_fields(self)
+      class(nek_dvector), intent(inout) :: self
+      call nek_dvector_ensure(self)
+      call nlg_check(c_vec_clear_rst(self%h), 'dclear_rst_fields')
+   end subroutine
+
+   !> intrinsic-assignment semantics of the reference's by-value vectors: deep copy
+   subroutine assign_dvector(lhs, rhs)
+      class(nek_dvector), intent(inout) :: lhs
+      class(nek_dvector), intent(in) :: rhs
+      integer(c_int) :: rc
+      if (loc(lhs) == loc(rhs)) return
+      if (c_associated(lhs%h) .and. lhs%owner /= loc(lhs)) lhs%h = c_null_ptr      ! lhs was a bitwise copy: drop the alias
+      if (.not. c_associated(rhs%h)) then      ! rhs holds nothing: lhs becomes empty too
+         if (c_associated(lhs%h)) rc = c_vec_destroy(lhs%h)
+         lhs%h = c_null_ptr; lhs%owner = 0
+         return
+      end if
+      if (c_associated(lhs%h)) then
+         if (c_associated(lhs%h, rhs%h)) return
+         call nlg_check(c_vec_copy(lhs%h, rhs%h), 'nek_dvector assignment')
+      else
+         call nlg_check(c_vec_clone(rhs%h, lhs%h), 'nek_dvector assignment')
+         lhs%owner = loc(lhs)
+      end if
+   end subroutine
+
+   subroutine finalize_dvector(self)
+      type(nek_dvector), intent(inout) :: self
+      integer(c_int) :: rc
+      if (c_associated(self%h) .and. self%owner == loc(self)) rc = c_vec_destroy(self%h)
+      self%h = c_null_ptr; self%owner = 0
+   end subroutine
+
+   subroutine finalize_dvector_rank1(self)
+      type(nek_dvector), intent(inout) :: self(:)
+      integer :: i
+      integer(c_int) :: rc
+      do i = 1, size(self)
+         if (c_associated(self(i)%h) .and. self(i)%owner == loc(self(i))) rc = c_vec_destroy(self(i)%h)
+         self(i)%h = c_null_ptr; self(i)%owner = 0
+      end do
+   end subroutine
+
+end module neklab_vectors

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from neklab_amd.mesh import box_mesh  # noqa: E402
-from oracle.krylov import eigs  # noqa: E402
+from oracle.krylov import arnoldi_step, eigs  # noqa: E402
 from oracle.lns import ExptA, LNSConfig  # noqa: E402
 from oracle.sem import SEM  # noqa: E402
 from oracle.vectors import NekDVector  # noqa: E402
@@ -23,6 +23,9 @@ from oracle.vectors import NekDVector  # noqa: E402
 CASES = {
     "2d": dict(nel=(3, 2), n=6, lengths=(3.0, 2.0), periodic=(True, False), deform=0.04),
     "3d": dict(nel=(2, 2, 2), n=5, lengths=(2.0, 2.0, 2.0), periodic=(False, False, True), deform=0.04),
+    # the instantiation the headline benchmark runs (lx1 = 8, 3-D: k_axhelm3r<8,4>, face-grouped k_opdiv3 / k_opgradt3<8,3>,
+    # k_fdm_ext<8,1>, k_conv3<8,12>, ...): propagator and Arnoldi only, the operators are covered by the cases above
+    "3d_n8": dict(nel=(3, 3, 2), n=8, lengths=(3.0, 3.0, 2.0), periodic=(True, False, False), deform=0.04, ops=False),
 }
 
 
@@ -45,6 +48,8 @@ def generate(case):
     dim = sem.dim
     rng = np.random.default_rng(20260101)
     out = {}
+    if not CASES[case].get("ops", True):
+        return generate_propagator(sem, out)
     u = [rng.standard_normal(sem.shape1) for _ in range(dim)]
     w = [rng.standard_normal(sem.shape1) for _ in range(dim)]
     p = rng.standard_normal(sem.shape2)
@@ -87,6 +92,10 @@ def generate(case):
     out["axpby_pr"] = a.pr
     out["axpby_theta"] = a.theta[0]
     out["axpby_rst1_v"] = np.stack(a.v_rst[0])
+    return generate_propagator(sem, out, case)
+
+
+def generate_propagator(sem, out, case=""):
     # exptA matvec, direct and adjoint, plus chained matvec using the restart history
     U = base_flow(sem)
     out["baseflow"] = np.stack(U)
@@ -102,6 +111,13 @@ def generate(case):
     out["mv2_out_v"] = np.stack(y2.v)
     z = A.rmatvec(x)
     out["rmv_out_v"] = np.stack(z.v)
+    if case == "":
+        # three Arnoldi steps (matvec + CGS2): Hessenberg matrix and the last basis vector
+        V, H = [x, None, None, None], np.zeros((4, 3))
+        for k in range(3):
+            arnoldi_step(A.matvec, V, H, k)
+        out["arnoldi_H"] = H
+        out["arnoldi_v3"] = np.stack(V[3].v)
     # eigs: a converged leading pair (2-D only; tau = 1 separates the spectrum, 15 matvecs)
     if case == "2d":
         cfg = lns_cfg()
@@ -118,7 +134,7 @@ def generate(case):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    for case in CASES:
+    for case in (sys.argv[1:] or CASES):     # no argument: every case
         data = generate(case)
         path = os.path.join(here, "golden_%s.npz" % case)
         np.savez_compressed(path, **data)

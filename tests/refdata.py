@@ -8,7 +8,7 @@ from neklab_amd.mesh import BoxMesh
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_cylinder(with_bcs=False):
+def load_cylinder(with_bcs=False, dirichlet_tags=("v", "W")):
     """with_bcs=False: connectivity from coincident coordinates only, no masks (operator-level checks).
     with_bcs=True : the boundary conditions of 1cyl.re2 applied: 'v' / 'W' faces Dirichlet-masked, 'O' natural,
     'P' faces (y = -16 <-> y = +16) identified in the global numbering."""
@@ -28,12 +28,12 @@ def load_cylinder(with_bcs=False):
     if with_bcs:
         pos = {int(g): k for k, g in enumerate(d["elmap"])}    # global element id -> position in the field file
         for ge, fc, tag in zip(d["bc_elem"], d["bc_face"], d["bc_tag"]):
-            if str(tag) in ("v", "W"):
+            if str(tag) in dirichlet_tags:
                 nodes = face_nodes(n, 2, int(fc))
                 for m in mask:
                     m[pos[int(ge)], nodes] = 0.0
     hm = BoxMesh(dim=2, n=n, nel=(E, 1), x=x, y=y, z=None, glo_num=glo.reshape(E, n * n).astype(np.int64),
-                 mask=mask, tmask=ones.copy(), has_outflow=True, elem_gid=np.arange(E, dtype=np.int64))
+                 mask=mask, tmask=ones.copy(), has_outflow="O" not in dirichlet_tags, elem_gid=np.arange(E, dtype=np.int64))
     rr = np.hypot(x, y)
     interior = (x > -16 + 1e-6) & (x < 50 - 1e-6) & (np.abs(y) < 16 - 1e-6) & (rr > 0.5 + 1e-6)
     return hm, d["ux"].copy(), d["uy"].copy(), d["p"].copy(), float(d["re"]), int(d["lxd"]), interior

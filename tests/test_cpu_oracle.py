@@ -286,3 +286,19 @@ def test_c_port_matches_numpy_restatement():
     y = u[2].copy()
     cp.axpby(0.3, u[0], 0.5, y)
     assert err(y, 0.5 * u[2] + 0.3 * u[0]) < 1e-15
+
+
+def test_matvec_matches_golden_3d_n8():
+    """The lx1 = 8, 3-D fixture the GPU box checks the benchmark's kernel instantiations against (first matvec only here:
+    the whole fixture takes half a minute of oracle time, tests/golden/make_golden.py 3d_n8)."""
+    from oracle.lns import ExptA, LNSConfig
+    from oracle.vectors import NekDVector
+    g = golden("3d_n8")
+    hm, sem = mg.build("3d_n8")
+    A = ExptA(sem, list(g["baseflow"]), LNSConfig(**mg.lns_cfg()))
+    x = NekDVector(sem)
+    for i in range(3):
+        x.v[i][...] = g["mv_in_v"][i]
+    y = A.matvec(x)
+    assert max(np.abs(y.v[i] - g["mv_out_v"][i]).max() for i in range(3)) < 1e-13 * np.abs(g["mv_out_v"]).max()
+    assert max(np.abs(y.v_rst[1][i] - g["mv_out_rst2_v"][i]).max() for i in range(3)) < 1e-13 * np.abs(g["mv_out_v"]).max()

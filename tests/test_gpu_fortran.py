@@ -60,3 +60,89 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
     assert np.max(np.abs(H - Href)) < 1e-9 * np.max(np.abs(Href))
     assert abs(alias - 1.0) < 1e-12          # wrk = X(1); wrk%scal(2) must not touch X(1)
     assert size == x0.get_size()
+
+
+@pytest.mark.parametrize("device_eigs", [0, 1])
+def test_fortran_stability_driver_is_the_reference_call_sequence(gpu_ctx, device_eigs):
+    """neklab_amd/fortran/stability_driver.f90 = the userchk of 1cyl.usr:13-24 + linear_stability_analysis_fixed_point
+    (neklab_analysis.f90:77-93) with the reference's module names: `use neklab`, nek2vec / vec2nek, the positional
+    constructor exptA_linop(tau, bf), init(), eigs, log(mu)/tau, save_eigenspectrum, outpost_dnek.  device_eigs = 0 runs
+    LightKrylov's loop structure (stand-in) through the type-bound procedures, 1 the device block path (nlg_eigs)."""
+    subprocess.run(["make", "-s", "-C", FDIR], check=True)
+    exe = os.path.join(FDIR, "_build", "stability_driver")
+    hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), periodic=(True, False), deform=0.04)
+    kdim, nev, tau, re, vtol, ptol = 24, 2, 1.0, 10.0, 1e-11, 1e-10
+    bfv = [hm.mask[0] * (1.0 + np.sin(hm.x) * np.cos(hm.y)), hm.mask[1] * np.sin(2 * hm.x) * np.cos(hm.y)]
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "case.bin"), "wb") as f:
+        np.array([2, 6, hm.E, kdim, nev, device_eigs], dtype=np.int32).tofile(f)
+        np.array([tau, re, vtol, ptol], dtype=np.float64).tofile(f)
+        for a in (hm.x, hm.y):
+            a.astype(np.float64).tofile(f)
+        hm.glo_num.astype(np.int64).tofile(f)
+        for a in (hm.mask[0], hm.mask[1], bfv[0], bfv[1]):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    r = subprocess.run([exe], cwd=tmp, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.split()}
+    # the same analysis through the Python mirror of the C ABI
+    gm = host.Mesh(gpu_ctx, hm)
+    gb = host.nek_dvector(gm)
+    for i in range(2):
+        gb.set_field(i, bfv[i])
+    A = host.exptA_linop(tau, gb, re=re, torder=3, vtol=vtol, ptol=ptol, maxit_v=400, maxit_p=4000)
+    A.init()
+    x0 = host.nek_dvector(gm)
+    x0.rand(True, seed=1)                      # the shim's first rand() draws seed 1
+    X = [host.nek_dvector(gm) for _ in range(nev)]
+    mu, res, info = host.eigs(A, X, kdim=kdim, x0=x0, write_intermediate=False)
+    lam = np.log(mu.astype(complex)) / tau
+    spec = np.load(os.path.join(tmp, "dir_eigenspectrum.npy"))
+    assert spec.shape == (nev, 3)
+    flam = spec[:, 0] + 1j * spec[:, 1]
+    assert np.all(spec[:, 2] < 1e-6)
+    for a in flam:                             # same continuous-time eigenvalues (pair order / conjugate aside)
+        assert min(abs(a - b) for b in np.concatenate([lam, np.conj(lam)])) < 1e-7 * max(1.0, abs(a)), (flam, lam)
+    rows = [ln.split() for ln in open(os.path.join(tmp, "eigs_output.txt")) if not ln.startswith("#")]
+    conv = [r_ for r_ in rows if r_[5] == "T"]
+    assert len(conv) >= nev and abs(float(conv[0][3]) - abs(mu[0])) < 1e-7
+    assert int(out["NSTEPS"][0]) == A.info()["nsteps"] and int(out["SIZE"][0]) == gb.get_size()
+    assert abs(float(out["BFNORM"][0]) - gb.norm()) < 1e-12 * gb.norm()
+    assert abs(float(out["OPBFNORM"][0]) - gb.norm()) < 1e-12 * gb.norm()
+    c = [float(v) for v in out["COPIES"]]
+    assert abs(c[0] - gb.norm()) < 1e-12 * c[0] and abs(c[1] - 2 * c[0]) < 1e-12 * c[0] and abs(c[2] - 3 * c[0]) < 1e-12 * c[0]
+    # eigenvector field files: dir<session>0.f00001 carries the coordinates, both carry velocity and pressure
+    from neklab_amd import nekio
+    f1 = nekio.read_fld(os.path.join(tmp, "dirneklab0.f00001"))
+    f2 = nekio.read_fld(os.path.join(tmp, "dirneklab0.f00002"))
+    assert "x" in f1 and "x" not in f2 and "ux" in f2 and "p" in f2
+    assert np.max(np.abs(f1["x"] - hm.x)) < 1e-14
+    v = np.concatenate([f1["ux"].ravel(), f1["uy"].ravel()])
+    # a Ritz vector of the converged pair: inside the span of the Python path's pair
+    Bm = np.stack([np.concatenate([X[q].get_field(0), X[q].get_field(1)]) for q in range(nev)], axis=1)
+    coef, *_ = np.linalg.lstsq(Bm, v, rcond=None)
+    assert np.max(np.abs(v - Bm @ coef)) < 1e-5 * np.max(np.abs(v))
+
+
+def test_outpost_matches_python_writer(gpu_ctx, tmp_path):
+    """nlg_vec_outpost (the C-ABI writer behind the shim's outpost_dnek) against host.outpost_dnek / nekio.write_fld,
+    which reproduces the reference's own field file byte for byte (tests/test_cpu_nekio.py)."""
+    for nel, n in (((3, 2), 6), ((2, 2, 2), 5)):
+        hm = box_mesh(nel, n, deform=0.04)
+        gm = host.Mesh(gpu_ctx, hm)
+        v = host.nek_dvector(gm)
+        v.rand(True, seed=2)
+        v.set_field(host.PR, np.random.default_rng(1).standard_normal(gm.lpn))
+        for with_coords in (1, 0):
+            pa = str(tmp_path / ("c%d_%d.f00001" % (hm.dim, with_coords)))
+            host.check(gm.lib.nlg_vec_outpost(v.h, pa.encode(), with_coords, 0.0, 1 if with_coords else 2))
+            pb = host.outpost_dnek(v, "ref", "x%d%d" % (hm.dim, with_coords), str(tmp_path), first_index=1 if with_coords else 2)[0]
+            a, b = open(pa, "rb").read(), open(pb, "rb").read()
+            if with_coords:                    # host.outpost_dnek writes coordinates into the first file of a call only
+                assert a == b
+            else:
+                from neklab_amd import nekio
+                fa, fb = nekio.read_fld(pa), nekio.read_fld(pb)
+                assert "x" not in fa
+                for key in ("ux", "uy", "p"):
+                    assert np.array_equal(fa[key], fb[key])

@@ -1,0 +1,77 @@
+"""nek_drand (real_vectors.f90:52-123) on the GPU against the oracle, half by half.
+
+* the mth_rand noise (neklab_vectors.f90:305-314) with the counter-based uniform numbers that stand in for the compiler's
+  random_number: the two nested 1e3 * sin() of the hash amplify a rounding difference of the argument a million-fold, so
+  the kernel evaluates it without fused multiply-adds, in the order written; what is left is the difference between the
+  device's and numpy's sin / cos (an ulp or two), amplified: tolerance 1e-7 absolute on values in [-1, 1];
+* continuity (opdssum * vmult, dsavg), Dirichlet masks, normalisation, nrst = 0: exact arithmetic on injected noise,
+  tolerance 1e-14.
+"""
+import numpy as np
+import pytest
+
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+from oracle.sem import SEM
+from oracle.vectors import NekDVector
+
+pytestmark = pytest.mark.gpu
+
+CASES = [((4, 3), 6, (True, False)), ((3, 2, 2), 5, (False, False, True)), ((3, 3, 2), 8, (True, False, False))]
+
+
+@pytest.mark.parametrize("nel,n,periodic", CASES)
+def test_rand_noise_matches_oracle_hash(gpu_ctx, nel, n, periodic):
+    hm = box_mesh(nel, n, periodic=periodic, deform=0.04)
+    hm.elem_gid = hm.elem_gid + 37                       # global element ids of some other rank's block
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    dim = hm.dim
+    for nscal, seed in ((0, 11), (1, 2 ** 40 + 5)):
+        gv, ov = host.nek_dvector(gm, nscal), NekDVector(sem, nscal)
+        host.check(gm.lib.nlg_vec_rand_noise(gv.h, seed))
+        worst = 0.0
+        for f in range(dim + nscal):
+            raw = ov.raw_noise(seed, hm.elem_gid, f)
+            got = gv.get_field(f if f < dim else host.THETA + f - dim)
+            assert np.all(np.abs(got) <= 1.0)
+            worst = max(worst, np.max(np.abs(got - raw.ravel())))
+        assert worst < 1e-7, worst
+        # "adds to the current contents" (real_vectors.f90:80-98): a second call doubles the field
+        before = gv.get_field(0)
+        host.check(gm.lib.nlg_vec_rand_noise(gv.h, seed))
+        assert np.max(np.abs(gv.get_field(0) - 2.0 * before)) < 1e-15
+
+
+@pytest.mark.parametrize("nel,n,periodic", CASES)
+@pytest.mark.parametrize("ifnorm", [False, True])
+def test_rand_finish_matches_oracle_on_injected_noise(gpu_ctx, nel, n, periodic, ifnorm):
+    hm = box_mesh(nel, n, periodic=periodic, deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    dim, nscal = hm.dim, 1
+    rng = np.random.default_rng(17)
+    raw = [rng.standard_normal(sem.shape1) for _ in range(dim + nscal)]
+    ov, gv = NekDVector(sem, nscal), host.nek_dvector(gm, nscal)
+    ov.rand(ifnorm=ifnorm, raw=raw)
+    for f in range(dim + nscal):
+        gv.set_field(f if f < dim else host.THETA + f - dim, raw[f])
+    gv.save_rst(gv, 1)                                   # rand clears the history (real_vectors.f90:121)
+    assert gv.nrst == 1
+    host.check(gm.lib.nlg_vec_rand_finish(gv.h, int(ifnorm)))
+    assert gv.nrst == 0
+    for f in range(dim + nscal):
+        want = (ov.v[f] if f < dim else ov.theta[f - dim]).ravel()
+        got = gv.get_field(f if f < dim else host.THETA + f - dim)
+        assert np.max(np.abs(got - want)) < 1e-14 * max(np.abs(want).max(), 1.0), f
+    if ifnorm:
+        assert abs(gv.norm() - 1.0) < 1e-14
+
+
+def test_rand_is_noise_then_finish(gpu_ctx):
+    hm = box_mesh((3, 2, 2), 6, deform=0.03)
+    gm = host.Mesh(gpu_ctx, hm)
+    a, b = host.nek_dvector(gm), host.nek_dvector(gm)
+    a.rand(True, seed=9)
+    host.check(gm.lib.nlg_vec_rand_noise(b.h, 9))
+    host.check(gm.lib.nlg_vec_rand_finish(b.h, 1))
+    for i in range(3):
+        assert np.array_equal(a.get_field(i), b.get_field(i))
