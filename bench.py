@@ -250,19 +250,26 @@ def main():
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None, "traffic": None, "launches": cnt.value, "avg_ms": avg_ms,
                 "algorithmic_bytes_per_launch": abytes,
-                "share_of_step": {k: round(v[1] / max(sum(x[1] for x in prof.values()), 1e-30), 4) for k, v in prof.items()}}
+                "share_of_step": {k: round(v[1] / max(sum(x[1] for x in prof.values()), 1e-30), 4) for k, v in prof.items()},
+                # absolute: event-timed milliseconds per step and launches per step of every class (warm-up steps)
+                "class_ms_per_step": {k: round(v[1] / max(args.warmup, 1), 3) for k, v in prof.items()},
+                "class_launches_per_step": {k: round(v[0] / max(args.warmup, 1), 1) for k, v in prof.items()}}
     if abytes is not None and avg_ms > 0:
         roofline["achieved"] = abytes / (avg_ms * 1e-3) / 1e9
         roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
-    # HBM bytes per launch from the PMC counters: they cannot be sampled from inside this process, so the figure
-    # is the one recorded by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command on THIS
-    # configuration (profiles/r01_pmc/, corrected as MI355X_MICROARCH.md prescribes); null for any other config.
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic_per_launch.json")))
-        if tr["config"] == {"E": E, "lx1": n, "dim": dim} and dominant in tr:
-            roofline["traffic"] = tr[dominant]["traffic_bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM bytes per launch from the PMC counters: they cannot be sampled from inside this process, so the figure is the
+    # one produced by scripts/pmc_traffic.py from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of THIS command on
+    # THIS configuration (newest profiles/r*_pmc/traffic_per_launch.json whose config matches); null for any other config.
+    import glob
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "traffic_per_launch.json")), reverse=True):
+        try:
+            tr = json.load(open(tf))
+            if tr["config"] == {"E": E, "lx1": n, "dim": dim} and dominant in tr:
+                roofline["traffic"] = tr[dominant]["traffic_bytes"]
+                roofline["traffic_source"] = os.path.relpath(tf, ROOT)
+                break
+        except (OSError, ValueError, KeyError):
+            pass
 
     steps_per_mv = (st2["steps"] - st1["steps"]) / max(args.steps, 1)
     p_iters = (st2["p_iters"] - st1["p_iters"]) / max(st2["steps"] - st1["steps"], 1)

@@ -180,6 +180,14 @@ int nlg_basis_block_axpy(const nlg_basis *b, int k, const double *h, nlg_vec *w)
 /* classical Gram-Schmidt with one re-orthogonalisation pass, then norm and scale:
  * h[0:k] accumulated coefficients, *beta = ||w|| before normalisation */
 int nlg_basis_cgs2(const nlg_basis *b, int k, nlg_vec *w, double *h, double *beta);
+/* Block variant for s <= 4 NEW vectors held in the consecutive columns k .. k+s-1 (block Arnoldi, BASELINE.json config 5;
+ * the reference advances several perturbations together through Nek5000's lpert / npert, src/neklab_nek_setup.f90:39-247,
+ * src/neklab_otd.f90:37-49): classical Gram-Schmidt with one re-orthogonalisation pass against the columns 0 .. k-1 --
+ * every pass reads the basis ONCE for all s vectors -- then a Cholesky QR (applied twice) among the s columns.
+ * coef is column-major with leading dimension k+s, one column per new vector: rows 0 .. k-1 the projection coefficients
+ * (both passes summed), rows k .. k+s-1 the upper-triangular factor R with  W_old = V(:,0:k) coef(0:k,:) + W_new R.
+ * Restart history and pressure follow as in axpby / scal (consistent history update only). */
+int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef);
 /* out = sum_j c[j] V(:,j)  over ALL fields (eigenvector reconstruction, LightKrylov eigs tail) */
 int nlg_basis_combine(const nlg_basis *b, int k, const double *c, nlg_vec *out);
 
@@ -288,6 +296,10 @@ int nlg_op_cfl(nlg_mesh *mesh, const nlg_vec *base, double dt, double *cfl);
 /* one Arnoldi step on device: basis column k -> column k+1, H(0:k+1, k) written to H (column-major,
  * leading dimension ldh). transpose != 0 uses rmatvec. */
 int nlg_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, double *H, int ldh, int transpose);
+
+/* one BLOCK Arnoldi step: the s columns k .. k+s-1 of the basis -> columns k+s .. k+2s-1 (s matvecs, then
+ * nlg_basis_block_cgs2 against the k+s columns before them); H(0:k+2s, k:k+s) written (column-major, ldh >= k+2s). */
+int nlg_block_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, int s, double *H, int ldh, int transpose);
 
 typedef struct nlg_eigs_opts {
     int kdim;               /* kdim=  (1cyl.usr:11: 128)                                          */

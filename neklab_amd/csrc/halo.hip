@@ -260,18 +260,27 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
         NLG_TRY(up(to_fg(send_idx), &h.d_send_idx_fg));
         NLG_TRY(up(to_fg(cidx), &h.d_cidx_fg));
     }
+    if (!m->h_slot_xp.empty()) {
+        auto to_xp = [&](std::vector<int> v) {
+            for (int &i : v) i = (i / np1) * np1 + m->h_slot_xp[i % np1];
+            return v;
+        };
+        NLG_TRY(up(to_xp(send_idx), &h.d_send_idx_xp));
+        NLG_TRY(up(to_xp(cidx), &h.d_cidx_xp));
+    }
     NLG_HIP(hipMalloc(&h.d_send, sizeof(double) * (size_t)tot * 3));
     NLG_HIP(hipMalloc(&h.d_recv, sizeof(double) * (size_t)tot * 3));
     h.active = true;
     return 0;
 }
 
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped) {
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout) {
     nlg_halo &h = m->halo;
     if (!h.active) return 0;
-    NLG_CHECK(!face_grouped || h.d_send_idx_fg, "halo_exchange: no face-grouped index lists");
-    const int *send_idx = face_grouped ? h.d_send_idx_fg : h.d_send_idx;
-    const int *cidx = face_grouped ? h.d_cidx_fg : h.d_cidx;
+    NLG_CHECK(layout != LAYOUT_FG || h.d_send_idx_fg, "halo_exchange: no face-grouped index lists");
+    NLG_CHECK(layout != LAYOUT_XP || h.d_send_idx_xp, "halo_exchange: no x-planes-first index lists");
+    const int *send_idx = layout == LAYOUT_FG ? h.d_send_idx_fg : (layout == LAYOUT_XP ? h.d_send_idx_xp : h.d_send_idx);
+    const int *cidx = layout == LAYOUT_FG ? h.d_cidx_fg : (layout == LAYOUT_XP ? h.d_cidx_xp : h.d_cidx);
     nlg_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
@@ -306,7 +315,7 @@ int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped)
 
 void halo_free(nlg_mesh *m) {
     nlg_halo &h = m->halo;
-    int *ip[] = {h.d_send_idx, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.d_send_idx_fg, h.d_cidx_fg};
+    int *ip[] = {h.d_send_idx, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.d_send_idx_fg, h.d_cidx_fg, h.d_send_idx_xp, h.d_cidx_xp};
     for (int *p : ip)
         if (p) hipFree(p);
     if (h.d_send) hipFree(h.d_send);

@@ -124,6 +124,20 @@ __host__ __device__ inline int fg_slot(int N, int a, int j, int k) {
     return fbase + 6 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
 }
 
+// "x-planes first" slot of point (a, j, k): the two x-faces of an element first -- per k the row (j = 0..N-1) of the a = 0
+// face followed by the row of the a = N-1 face, 2N doubles = one 128-byte line at N = 8 -- then the rest with a' = a - 1
+// fastest.  A k-slab of an element is then two dense runs (2N and (N-2) N doubles) for a kernel whose lanes are (a, j)
+// columns -- as many cache lines as the natural layout, whose slab is one run of N N -- while the copies of a shared
+// x-face, one 8-byte word per 64-byte row in the natural layout, become runs of N; y-faces are runs of N-2, z-faces stay
+// dense.  Used for the vectors of the velocity PCG (3-D), whose gather-scatter moved 3.2 times its algorithmic bytes in
+// the natural layout.  (Measured first with the two faces as separate N x N planes: the half-line rows cost the operator
+// kernel 11 %, more than the gather-scatter gained.)
+__host__ __device__ inline int xp_slot(int N, int a, int j, int k) {
+    if (a == 0) return 2 * N * k + j;
+    if (a == N - 1) return 2 * N * k + N + j;
+    return 2 * N * N + (a - 1) + (N - 2) * (j + N * k);
+}
+
 struct nlg_gs {
     // groups of local dofs that share a global label (only groups of size >= 2 are stored)
     int64_t ngroups = 0;
@@ -137,7 +151,11 @@ struct nlg_gs {
     // are contiguous runs instead of stride-n points
     int *d_offsets_fg = nullptr;
     int *d_indices_fg = nullptr;
+    // ... and in the x-planes-first layout of the velocity PCG (3-D)
+    int *d_offsets_xp = nullptr;
+    int *d_indices_xp = nullptr;
 };
+enum { LAYOUT_NAT = 0, LAYOUT_FG = 1, LAYOUT_XP = 2 };
 
 struct nlg_halo {
     bool active = false;
@@ -148,6 +166,7 @@ struct nlg_halo {
     int *d_roff = nullptr, *d_rpos = nullptr;   // per distinct shared label: positions in the recv buffer
     int *d_coff = nullptr, *d_cidx = nullptr;   // per distinct shared label: all local copies
     int *d_send_idx_fg = nullptr, *d_cidx_fg = nullptr;   // d_send_idx / d_cidx for the face-grouped element layout
+    int *d_send_idx_xp = nullptr, *d_cidx_xp = nullptr;   // ... and for the x-planes-first layout
     double *d_send = nullptr, *d_recv = nullptr;
     std::vector<int> h_cidx;         // host copy of d_cidx: every local dof that another rank shares
 };
@@ -208,6 +227,9 @@ struct nlg_mesh {
     int64_t *d_lglel = nullptr;
     std::vector<int64_t> h_lglel;
     std::vector<int> h_slot;   // natural point -> face-grouped slot inside an element (3-D)
+    std::vector<int> h_slot_xp;   // natural point -> x-planes-first slot (3-D)
+    int *d_slot_xp = nullptr;
+    double *d_vmult_xp = nullptr;
     nlg_gs gs;
     double volvm1 = 0, volvm2 = 0;
     int64_t lpn_global = 0;   // global pressure dof count (ortho)
@@ -239,6 +261,7 @@ struct nlg_basis {
     double *d = nullptr;
     std::vector<nlg_vec *> views;
     double *d_h = nullptr;     // [2 * nvec + 8] device coefficients
+    double *d_hb = nullptr;    // block orthogonalisation: [2 * nvec * 4 + 64] coefficients of up to 4 vectors (lazy)
 };
 
 namespace nlg {
@@ -294,15 +317,17 @@ void pprec_free(nlg_mesh *m);
 
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf, bool face_grouped = false);
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout = 0);   // LAYOUT_*
 void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
-int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr);   // in place QQ^T; gate: device flag, non-zero = skip
+int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr, int layout = 0);   // in place QQ^T; gate: device flag, non-zero = skip; layout: LAYOUT_NAT or LAYOUT_XP
+int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf);     // natural -> x-planes-first (out of place)
+int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf);
 int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);
 int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
-               double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr);   // zf: fused u <- zf + beta u
+               double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr, bool xp = false);   // zf: fused u <- zf + beta u; xp: u, zf, w in the x-planes-first layout (3-D, lx1 <= 8)
 int sem_opdiv_blocks(const nlg_mesh *m);
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)

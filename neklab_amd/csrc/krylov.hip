@@ -160,6 +160,24 @@ int nlg_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, double *H, int ldh,
     return 0;
 }
 
+int nlg_block_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, int s, double *H, int ldh, int transpose) {
+    NLG_CHECK(op && basis && H, "nlg_block_arnoldi_step: NULL argument");
+    NLG_CHECK(s >= 1 && s <= 4, "nlg_block_arnoldi_step: block size %d unsupported (1..4)", s);
+    NLG_CHECK(k >= 0 && k + 2 * s <= basis->nvec, "nlg_block_arnoldi_step: k=%d, s=%d need basis columns up to %d (nvec=%d)", k, s,
+              k + 2 * s - 1, basis->nvec);
+    NLG_CHECK(ldh >= k + 2 * s, "nlg_block_arnoldi_step: ldh=%d too small for k=%d, s=%d", ldh, k, s);
+    for (int v = 0; v < s; ++v) {
+        nlg_vec *vin = basis->views[k + v], *w = basis->views[k + s + v];
+        NLG_TRY(transpose ? nlg_linop_rmatvec(op, vin, w) : nlg_linop_matvec(op, vin, w));
+    }
+    const int kk = k + s;
+    std::vector<double> coef((size_t)(kk + s) * s);
+    NLG_TRY(nlg_basis_block_cgs2(basis, kk, s, coef.data()));
+    for (int v = 0; v < s; ++v)
+        for (int i = 0; i < kk + s; ++i) H[(size_t)(k + v) * ldh + i] = coef[(size_t)v * (kk + s) + i];
+    return 0;
+}
+
 int nlg_eigs_opts_default(nlg_eigs_opts *o) {
     NLG_CHECK(o, "nlg_eigs_opts_default: NULL");
     o->kdim = 0;

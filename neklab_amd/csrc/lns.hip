@@ -561,6 +561,10 @@ struct nlg_linop {
     double *rhs[3] = {}, *x[3] = {}, *z[3] = {}, *pv[3] = {}, *w[3] = {}, *gp[3] = {};
     double *pr_r = nullptr, *pr_x = nullptr, *pr_z = nullptr, *pr_p = nullptr, *pr_w = nullptr;
     double *pcv[4][3] = {};    // mask_i / diag(H) per BDF order
+    // velocity PCG in the x-planes-first layout (3-D, lx1 <= 8: internal.h xp_slot): the preconditioners and the residual
+    // weight permuted once; 0 = natural layout (2-D, lx1 > 8, NLG_XP=0)
+    int use_xp = -1;
+    double *pcv_xp[4][3] = {}, *nwv_xp = nullptr;
     double *pce = nullptr;     // 1 / diag(E)
     double *prX = nullptr, *prB = nullptr, *d_pc = nullptr;   // pressure residual projection: PROJ_L solution / image pairs, coefficients
     int nproj = 0;
@@ -816,16 +820,20 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     const int dim = m->dim;
     const auto &c = op->cfg;
     CGProblem P;
+    // x-planes-first layout for every vector of the iteration: the right-hand side is permuted on the way in (into gp,
+    // free at this point), the solution on the way out (into rhs, which the caller reads as the increment)
+    const bool xp = op->use_xp > 0;
+    if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim));
     P.nf = dim;
     P.n = m->lvn;
     P.x = op->x;
-    P.r = op->rhs;
+    P.r = xp ? op->gp : op->rhs;
     P.z = op->z;
     P.p = op->pv;
     P.w = op->w;
-    P.pc = op->pcv[order];
-    P.ipw = m->d_vmult;
-    P.nw = op->nwv;
+    P.pc = xp ? op->pcv_xp[order] : op->pcv[order];
+    P.ipw = xp ? m->d_vmult_xp : m->d_vmult;
+    P.nw = xp ? op->nwv_xp : op->nwv;
     P.tol2 = c.vtol * c.vtol;
     P.use_tol = c.fixed_iters_v > 0 ? 0 : 1;
     P.maxit = c.fixed_iters_v > 0 ? c.fixed_iters_v : c.maxit_v;
@@ -850,19 +858,20 @@ int helm_solve(nlg_linop *op, int order, double h2) {
     }
     auto apply = [&](double *) -> int {
         if (pw_part)
-            NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE));
+            NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, xp));
         else
             NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part));
-        NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE));
+        NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE, xp ? LAYOUT_XP : LAYOUT_NAT));
         return 0;
     };
     {
         char tb[96];
-        snprintf(tb, sizeof(tb), "helm|%a|%a|%d", nu, h2, pw_part ? 1 : 0);
+        snprintf(tb, sizeof(tb), "helm|%a|%a|%d|%d", nu, h2, pw_part ? 1 : 0, xp ? 1 : 0);
         P.tag = tb;
     }
     int iters = 0;
     NLG_TRY(run_pcg(op, P, apply, &iters));
+    if (xp) NLG_TRY(sem_from_xp(m, op->x, op->rhs, dim));   // the increment, natural layout
     op->st_viters += iters;
     op->last_viters = iters;
     if ((int)op->vit_hist.size() <= op->istep) op->vit_hist.resize(op->istep + 1, 0);
@@ -1155,7 +1164,7 @@ int advance(nlg_linop *op) {
     {
         CF3 none = {{nullptr, nullptr, nullptr}};
         launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(unew, dim), cf3(op->ubuf[0], dim),
-                  cf3(op->x, dim), 1.0, none, 0.0);
+                  cf3(op->use_xp > 0 ? op->rhs : op->x, dim), 1.0, none, 0.0);
     }
     // pressure correction
     NLG_TRY(sem_opdiv(m, unew, op->pr_r, -(b0 / dt)));
@@ -1422,6 +1431,7 @@ int nlg_linop_destroy(nlg_linop *op) {
         fr(op->w[c]);
         fr(op->gp[c]);
         for (int k = 0; k < 4; ++k) fr(op->pcv[k][c]);
+        for (int k = 0; k < 4; ++k) fr(op->pcv_xp[k][c]);
     }
     for (int q = 0; q < 9; ++q) fr(op->GU[q]);
     fr(op->p);
@@ -1452,6 +1462,7 @@ int nlg_linop_destroy(nlg_linop *op) {
     if (op->proj_off2) hipFree(op->proj_off2);
     if (op->proj_idx2) hipFree(op->proj_idx2);
     fr(op->nwv);
+    fr(op->nwv_xp);
     fr(op->nwp);
     fr(op->d_s);
     fr(op->d_part);
@@ -1532,6 +1543,17 @@ int nlg_linop_init(nlg_linop *op) {
             hipLaunchKernelGGL(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pcv[k][c], (const double *)dg,
                                (const double *)m->d_mask[c]);
     }
+    if (op->use_xp < 0) {
+        const char *ev = getenv("NLG_XP");
+        op->use_xp = (dim == 3 && m->n <= 8 && m->d_slot_xp && (m->gs.d_indices_xp || m->gs.ngroups == 0) && !(ev && atoi(ev) == 0)) ? 1 : 0;
+    }
+    if (op->use_xp > 0) {
+        for (int k = 1; k <= op->cfg.torder; ++k) {
+            for (int c = 0; c < dim; ++c)
+                if (!op->pcv_xp[k][c]) NLG_TRY(lalloc(op, &op->pcv_xp[k][c], m->lvs));
+            NLG_TRY(sem_to_xp(m, op->pcv[k], op->pcv_xp[k], dim));
+        }
+    }
     if (op->cfg.ifheat) {
         if (!op->trhs) {
             for (int q = 0; q < 3; ++q) {
@@ -1563,6 +1585,11 @@ int nlg_linop_init(nlg_linop *op) {
                        (const double *)m->d_vmult, 1.0 / m->volvm1);
     hipLaunchKernelGGL(k_scale1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->nwp, (const double *)m->d_bm2inv,
                        1.0 / m->volvm2);
+    if (op->use_xp > 0) {
+        if (!op->nwv_xp) NLG_TRY(lalloc(op, &op->nwv_xp, m->lvs));
+        double *a[1] = {op->nwv}, *b[1] = {op->nwv_xp};
+        NLG_TRY(sem_to_xp(m, a, b, 1));
+    }
     NLG_HIP(hipGetLastError());
     NLG_HIP(hipStreamSynchronize(st));
     op->inited = true;

@@ -533,7 +533,8 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 // u and of w in registers; per k-slab the r/s contractions go through three N x N LDS slabs (rows padded to N+1), the
 // t contraction stays in registers.  A wave only ever touches its own slabs and LDS operations of one wave execute in
 // order, so the kernel needs no barrier at all; ~2.5 KB of LDS per wave, occupancy set by registers alone.
-template <int N, int WPB>
+// XP: u, zf and w live in the x-planes-first layout (xp_slot); the metric factors stay natural.
+template <int N, int WPB, bool XP>
 __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const double *__restrict__ Dg,
                                                        const double *__restrict__ G0, const double *__restrict__ G1,
                                                        const double *__restrict__ G2, const double *__restrict__ G3,
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     __shared__ double sU[WPB][N * NQ], sR[WPB][N * NQ], sS[WPB][N * NQ];
     __shared__ double sred[WPB];
     if (done_p && done_p[0] != 0.0) return;   // the surrounding PCG has converged: nothing consumes w any more
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: element, field and every base pointer stay scalar
     for (int p = tid; p < NS; p += 64 * WPB) sD[p] = Dg[p];
     __syncthreads();   // the only block-wide barrier: the derivative matrix
     const int64_t gslot = (int64_t)blockIdx.x * WPB + wv;
@@ -556,19 +558,24 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     const bool act = e < E && lane < NS;
     const int ij = lane < NS ? lane : 0;
     const int i = ij % N, j = ij / N;
-    const int64_t base = (e < E ? e : 0) * NP + ij;
-    const double *uc = c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]);
-    double *wc = c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2]);
-    const double *zc = c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2]);
+    const int64_t eoff = (e < E ? e : 0) * NP;
+    const int base = ij;   // offset inside the element, natural layout (metric factors)
+    // field offsets inside the element: vb + k * vs
+    const int vb = XP ? (i == 0 ? j : (i == N - 1 ? N + j : 2 * NS + (i - 1) + (N - 2) * j)) : ij;
+    const int vs = XP ? ((i == 0 || i == N - 1) ? 2 * N : (N - 2) * N) : NS;
+    const double *uc = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2])) + eoff;
+    double *wc = (c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2])) + eoff;
+    const double *zc = (c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2])) + eoff;
+    G0 += eoff, G1 += eoff, G2 += eoff, G3 += eoff, G4 += eoff, G5 += eoff, bm1 += eoff;
     const bool upd = beta_p != nullptr && done_p[0] == 0.0;
     const double beta = upd ? beta_p[0] : 0.0;
     double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double v = act ? uc[base + k * NS] : 0.0;
+        double v = act ? uc[vb + k * vs] : 0.0;
         if (upd && act) {
-            v = zc[base + k * NS] + beta * v;
-            const_cast<double *>(uc)[base + k * NS] = v;
+            v = zc[vb + k * vs] + beta * v;
+            const_cast<double *>(uc)[vb + k * vs] = v;
         }
         uk[k] = v;
         wk[k] = 0.0;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     for (int k = 0; k < N; ++k) {
         const double g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3], g4 = gn[4], g5 = gn[5], bm = gn[6];
         if (k + 1 < N) {
-            const int64_t q = base + (k + 1) * NS;
+            const int q = base + (k + 1) * NS;
             gn[0] = G0[q], gn[1] = G1[q], gn[2] = G2[q], gn[3] = G3[q], gn[4] = G4[q], gn[5] = G5[q], gn[6] = bm1[q];
         }
         if (lane < NS) mU[i + NQ * j] = uk[k];
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     if (act) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            wc[base + k * NS] = wk[k];
+            wc[vb + k * vs] = wk[k];
             pw += wk[k] * uk[k];
         }
     }
@@ -1581,8 +1588,11 @@ double *sem_scratch2(nlg_mesh *m, int i) {
     return m->scratch2[i];
 }
 
-int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate) {
+int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int layout) {
     if (m->gs.ngroups == 0 && !m->halo.active) return 0;
+    NLG_CHECK(layout == LAYOUT_NAT || (layout == LAYOUT_XP && (m->gs.d_indices_xp || m->gs.ngroups == 0)), "sem_gs: layout %d has no tables", layout);
+    const int *goff = layout == LAYOUT_XP ? m->gs.d_offsets_xp : m->gs.d_offsets;
+    const int *gidx = layout == LAYOUT_XP ? m->gs.d_indices_xp : m->gs.d_indices;
     ProfScope ps(m->ctx, P_GS);
     if (nf < 1 || nf > 3) {
         set_error("sem_gs: nf=%d unsupported", nf);
@@ -1592,15 +1602,56 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate) {
         F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
         const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
         if (nf == 1)
-            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
+            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
         else if (nf == 2)
-            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
+            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
         else
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
+            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
         NLG_HIP(hipGetLastError());
     }
-    return halo_exchange(m, fields, nf);   // no-op on a single rank
+    return halo_exchange(m, fields, nf, layout);   // no-op on a single rank
 }
+
+// natural <-> x-planes-first, out of place, one thread per point
+template <int NF, bool TO>
+__global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__restrict__ slot, CF3 src, F3 dst) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int64_t e = i / np;
+        const int64_t q = e * np + slot[(int)(i - e * np)];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            if (TO)
+                dst.p[c][q] = src.p[c][i];
+            else
+                dst.p[c][i] = src.p[c][q];
+        }
+    }
+}
+
+static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, bool to) {
+    NLG_CHECK(m->d_slot_xp && nf >= 1 && nf <= 3, "sem_to_xp: no x-planes-first table (3-D only) or bad field count");
+    CF3 a = {{src[0], nf > 1 ? src[1] : nullptr, nf > 2 ? src[2] : nullptr}};
+    F3 b = {{dst[0], nf > 1 ? dst[1] : nullptr, nf > 2 ? dst[2] : nullptr}};
+    const dim3 g(grid_for(m->lvn)), t(NT);
+    hipStream_t st = m->ctx->stream;
+#define XPL(NF_)                                                                                               \
+    if (to)                                                                                                    \
+        hipLaunchKernelGGL((k_xp_perm<NF_, true>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b);  \
+    else                                                                                                       \
+        hipLaunchKernelGGL((k_xp_perm<NF_, false>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b);
+    if (nf == 1) {
+        XPL(1)
+    } else if (nf == 2) {
+        XPL(2)
+    } else {
+        XPL(3)
+    }
+#undef XPL
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf) { return xp_perm(m, src, dst, nf, true); }
+int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf) { return xp_perm(m, src, dst, nf, false); }
 
 // (element, field) slots per block of k_axhelm3: bounded by 512 threads and by 64 KB of dynamic LDS
 static int axhelm3_nslot(int N) {
@@ -1644,8 +1695,9 @@ int sem_axhelm_blocks(nlg_mesh *m, int nf) {
 }
 
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part,
-               double *const *zf, const double *beta_p, const double *done_p) {
+               double *const *zf, const double *beta_p, const double *done_p, bool xp) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
+    NLG_CHECK(!xp || (m->dim == 3 && m->n <= 8), "sem_axhelm: the x-planes-first layout exists for 3-D, lx1 <= 8 only");
     ProfScope ps(m->ctx, P_AXHELM);
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
     F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
@@ -1659,10 +1711,14 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         const int64_t tot = m->E * nf;                                                                                \
         const int grid = (int)((tot + nslot - 1) / nslot);                                                            \
         const size_t lds = sizeof(double) * (size_t)(N_ * N_ + nslot * 4 * N_ * N_ * N_);                             \
-        if constexpr (N_ <= 8)                                                                                        \
-            hipLaunchKernelGGL((k_axhelm3r<N_, 4>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+        if constexpr (N_ <= 8) {                                                                                      \
+            if (xp)                                                                                                   \
+            hipLaunchKernelGGL((k_axhelm3r<N_, 4, true>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
                                m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
-        else                                                                                                          \
+            else                                                                                                      \
+            hipLaunchKernelGGL((k_axhelm3r<N_, 4, false>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+        } else                                                                                                          \
         hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
                            m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
     }
@@ -2211,6 +2267,34 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
             NLG_HIP(hipMemcpy(m->gs.d_offsets_fg, off2.data(), sizeof(int) * off2.size(), hipMemcpyHostToDevice));
             NLG_HIP(hipMemcpy(m->gs.d_indices_fg, idx2.data(), sizeof(int) * idx2.size(), hipMemcpyHostToDevice));
         }
+        if (dim == 3) {
+            // ... and in the x-planes-first numbering (velocity PCG)
+            std::vector<int> slot((size_t)m->np1);
+            for (int p = 0; p < m->np1; ++p) slot[p] = xp_slot(n, p % n, (p / n) % n, p / (n * n));
+            m->h_slot_xp = slot;
+            NLG_HIP(hipMalloc(&m->d_slot_xp, sizeof(int) * slot.size()));
+            NLG_HIP(hipMemcpy(m->d_slot_xp, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
+            if (!groups.empty()) {
+                std::vector<std::vector<int>> gl(groups.size());
+                for (size_t gi = 0; gi + 1 < off.size(); ++gi) {
+                    for (int q = off[gi]; q < off[gi + 1]; ++q) gl[gi].push_back((idx[q] / m->np1) * m->np1 + slot[idx[q] % m->np1]);
+                    std::sort(gl[gi].begin(), gl[gi].end());
+                }
+                std::sort(gl.begin(), gl.end(), [](const std::vector<int> &a, const std::vector<int> &b) {
+                    const int ca = a.size() == 2 ? 0 : (a.size() == 4 ? 1 : 2), cb = b.size() == 2 ? 0 : (b.size() == 4 ? 1 : 2);
+                    return ca != cb ? ca < cb : a[0] < b[0];
+                });
+                std::vector<int> off2{0}, idx2;
+                for (auto &v : gl) {
+                    idx2.insert(idx2.end(), v.begin(), v.end());
+                    off2.push_back((int)idx2.size());
+                }
+                NLG_HIP(hipMalloc(&m->gs.d_offsets_xp, sizeof(int) * off2.size()));
+                NLG_HIP(hipMalloc(&m->gs.d_indices_xp, sizeof(int) * idx2.size()));
+                NLG_HIP(hipMemcpy(m->gs.d_offsets_xp, off2.data(), sizeof(int) * off2.size(), hipMemcpyHostToDevice));
+                NLG_HIP(hipMemcpy(m->gs.d_indices_xp, idx2.data(), sizeof(int) * idx2.size(), hipMemcpyHostToDevice));
+            }
+        }
         NLG_HIP(hipMalloc(&m->gs.d_offsets, sizeof(int) * off.size()));
         NLG_HIP(hipMalloc(&m->gs.d_indices, sizeof(int) * std::max<size_t>(idx.size(), 1)));
         NLG_HIP(hipMemcpy(m->gs.d_offsets, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
@@ -2230,6 +2314,11 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         for (int c = 0; c < dim; ++c)
             hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_mbinv[c], m->d_mask[c], m->d_binvm1, m->lvn);
         NLG_HIP(hipGetLastError());
+        if (dim == 3 && m->d_slot_xp) {
+            NLG_TRY(dalloc(&m->d_vmult_xp, m->lvs, s));
+            double *a[1] = {m->d_vmult}, *b[1] = {m->d_vmult_xp};
+            NLG_TRY(sem_to_xp(m, a, b, 1));
+        }
         if (dim == 3 && !m->h_slot.empty()) {
             std::vector<double> h((size_t)m->lvn), hp((size_t)m->lvs, 0.0);
             for (int c = 0; c < dim; ++c) {
@@ -2337,6 +2426,10 @@ int nlg_mesh_destroy(nlg_mesh *m) {
     pprec_free(m);
     if (m->gs.d_offsets_fg) hipFree(m->gs.d_offsets_fg);
     if (m->gs.d_indices_fg) hipFree(m->gs.d_indices_fg);
+    if (m->gs.d_offsets_xp) hipFree(m->gs.d_offsets_xp);
+    if (m->gs.d_indices_xp) hipFree(m->gs.d_indices_xp);
+    if (m->d_slot_xp) hipFree(m->d_slot_xp);
+    if (m->d_vmult_xp) hipFree(m->d_vmult_xp);
     for (int c = 0; c < 3; ++c)
         if (m->d_mbinv_fg[c]) hipFree(m->d_mbinv_fg[c]);
     if (m->gs.d_offsets) hipFree(m->gs.d_offsets);

@@ -281,6 +281,145 @@ __global__ __launch_bounds__(NT) void k_block_axpy(const double *V, int64_t vstr
     }
 }
 
+// ---- block (multi-vector) orthogonalisation: S new vectors W = [w_0 .. w_{S-1}] (consecutive basis columns, wstride apart)
+// against k basis vectors in ONE sweep over the basis per pass -- the basis is read once per S vectors instead of once per
+// vector.  Partial sums: row (j * S + v) of the reduction workspace holds V_j^T (bm1 o w_v).
+template <int KB, int S>
+__global__ __launch_bounds__(NT) void k_block_dot_s(const double *V, int64_t vstride, int k, const double *W, int64_t wstride,
+                                                    const double *bm1, int64_t lvs, int nblk, int nper, double *partial) {
+    __shared__ double sm[4 * KB * S];
+    const int c = blockIdx.y;
+    const int j0 = blockIdx.z * KB;
+    const int kc = (k - j0 < KB) ? (k - j0) : KB;
+    const int64_t n2 = lvs >> 1;
+    const int64_t per = (n2 + nblk - 1) / nblk;
+    const int64_t beg = blockIdx.x * per, end = (beg + per < n2) ? beg + per : n2;
+    const double2 *m2 = reinterpret_cast<const double2 *>(bm1);
+    const double2 *v2[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        const int jj = (j < kc) ? j : 0;
+        v2[j] = reinterpret_cast<const double2 *>(V + (int64_t)(j0 + jj) * vstride + c * lvs);
+    }
+    double acc[KB][S];
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int v = 0; v < S; ++v) acc[j][v] = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += NT) {
+        const double2 mv = m2[i];
+        double x0[S], x1[S];
+#pragma unroll
+        for (int v = 0; v < S; ++v) {
+            const double2 wv = reinterpret_cast<const double2 *>(W + (int64_t)v * wstride + c * lvs)[i];
+            x0[v] = wv.x * mv.x;
+            x1[v] = wv.y * mv.y;
+        }
+        double2 vv[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) vv[j] = v2[j][i];
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int v = 0; v < S; ++v) acc[j][v] += vv[j].x * x0[v] + vv[j].y * x1[v];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int v = 0; v < S; ++v) {
+            const double t = wave_sum(acc[j][v]);
+            if (lane == 0) sm[wid * KB * S + j * S + v] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < kc * S) {
+        const int q = threadIdx.x;   // j * S + v
+        const double t = (sm[q] + sm[KB * S + q]) + (sm[2 * KB * S + q] + sm[3 * KB * S + q]);
+        partial[((int64_t)j0 * S + q) * nper + c * nblk + blockIdx.x] = t;
+    }
+}
+
+// w_v += sign * sum_j h[j * S + v] V_j for v < S over [0, n2) double2 entries; entries at or beyond blk2 (the history
+// blocks) use the coefficient set hh instead (CGS2: second-pass coefficients on the main block, the sum of both passes on
+// the history, which no inner product reads).  The k basis values of a point are loaded once for all S vectors.
+template <int S>
+__global__ __launch_bounds__(NT) void k_block_axpy_s(const double *V, int64_t vstride, int k, const double *h, const double *hh,
+                                                     double *W, int64_t wstride, int64_t n2, int64_t blk2, double sign) {
+    extern __shared__ double shs[];
+    double *sh0 = shs, *sh1 = shs + (size_t)k * S;
+    for (int j = threadIdx.x; j < k * S; j += NT) {
+        sh0[j] = h[j];
+        sh1[j] = hh ? hh[j] : h[j];
+    }
+    __syncthreads();
+    const int64_t vs2 = vstride >> 1, ws2 = wstride >> 1;
+    double2 *w2 = reinterpret_cast<double2 *>(W);
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        const double *sh = (hh && i >= blk2) ? sh1 : sh0;
+        const double2 *v = reinterpret_cast<const double2 *>(V) + i;
+        double s0[S], s1[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) s0[q] = s1[q] = 0.0;
+        int j = 0;
+        for (; j + 8 <= k; j += 8) {
+            double2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = v[(int64_t)(j + u) * vs2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    s0[q] += sh[(j + u) * S + q] * t[u].x;
+                    s1[q] += sh[(j + u) * S + q] * t[u].y;
+                }
+        }
+        for (; j < k; ++j) {
+            const double2 t = v[(int64_t)j * vs2];
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                s0[q] += sh[j * S + q] * t.x;
+                s1[q] += sh[j * S + q] * t.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            double2 wv = w2[i + q * ws2];
+            wv.x += sign * s0[q];
+            wv.y += sign * s1[q];
+            w2[i + q * ws2] = wv;
+        }
+    }
+}
+
+// W <- W T with a small S x S matrix T (row-major, on the device) over [0, n2) double2 entries of every vector: the
+// triangular solve of a Cholesky QR, applied to all fields and history blocks like `scal`
+template <int S>
+__global__ __launch_bounds__(NT) void k_block_rmul(double *W, int64_t wstride, const double *T, int64_t n2) {
+    double t[S][S];
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b) t[a][b] = T[a * S + b];
+    const int64_t ws2 = wstride >> 1;
+    double2 *w2 = reinterpret_cast<double2 *>(W);
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
+        double2 x[S], y[S];
+#pragma unroll
+        for (int a = 0; a < S; ++a) x[a] = w2[i + a * ws2];
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+            y[b].x = y[b].y = 0.0;
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                y[b].x += x[a].x * t[a][b];
+                y[b].y += x[a].y * t[a][b];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < S; ++b) w2[i + b * ws2] = y[b];
+    }
+}
+
 __global__ void k_vadd(double *a, const double *b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] += b[i];
@@ -552,6 +691,7 @@ int nlg_basis_destroy(nlg_basis *b) {
     for (auto *v : b->views) delete v;
     if (b->d) hipFree(b->d);
     if (b->d_h) hipFree(b->d_h);
+    if (b->d_hb) hipFree(b->d_hb);
     delete b;
     return 0;
 }
@@ -715,6 +855,130 @@ int nlg_basis_cgs2(const nlg_basis *bc, int k, nlg_vec *w, double *h, double *be
     NLG_HIP(hipStreamSynchronize(b->mesh->ctx->stream));
     for (int j = 0; j < k; ++j) h[j] = tmp[j];
     *beta = sqrt(tmp[k]);
+    return 0;
+}
+
+// Block classical Gram-Schmidt with re-orthogonalisation for the s consecutive columns k .. k+s-1 against the columns
+// 0 .. k-1, followed by a Cholesky QR (twice) among the s columns themselves; see include/neklab_gpu.h.
+int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
+    NLG_CHECK(b && coef, "nlg_basis_block_cgs2: NULL argument");
+    NLG_CHECK(s >= 1 && s <= 4, "nlg_basis_block_cgs2: block size %d unsupported (1..4)", s);
+    NLG_CHECK(k >= 0 && k + s <= b->nvec, "nlg_basis_block_cgs2: columns %d..%d outside the basis (nvec=%d)", k, k + s - 1, b->nvec);
+    NLG_CHECK(g_axpby_consistent, "nlg_basis_block_cgs2: the block path implements the consistent restart-history update only");
+    nlg_ctx *ctx = b->mesh->ctx;
+    hipStream_t st = ctx->stream;
+    const int ld = k + s;
+    if (s == 1) {   // the single-vector path, same output convention
+        std::vector<double> h(std::max(k, 1));
+        double beta = 0.0;
+        NLG_TRY(nlg_basis_cgs2(b, k, b->views[k], h.data(), &beta));
+        for (int j = 0; j < k; ++j) coef[j] = h[j];
+        coef[k] = beta;
+        return 0;
+    }
+    if (!b->d_hb) NLG_HIP(hipMalloc(&b->d_hb, sizeof(double) * ((size_t)2 * b->nvec * 4 + 64)));
+    nlg_vec *w0 = b->views[k];
+    int nrst = 0;
+    for (int v = 0; v < s; ++v) nrst = std::max(nrst, b->views[k + v]->nrst);
+    for (int v = 0; v < s; ++v) b->views[k + v]->nrst = nrst;
+    double *W = w0->d;
+    double *H1 = b->d_hb, *H2 = b->d_hb + (size_t)b->nvec * 4, *dG = b->d_hb + (size_t)2 * b->nvec * 4, *dT = dG + 16;
+    const int nblk = dot_nblk(w0), nper = nblk * w0->ncomp;
+    const int64_t n2 = w0->main_len / 2, n2all = n2 * (1 + nrst);
+    constexpr int KB = 8;
+    NLG_TRY(reduce_ws_reserve(ctx, std::max(k, s) * s));
+    auto dots = [&](const double *V, int kk, double *out, double *acc) -> int {
+        ProfScope ps(ctx, P_BLOCKDOT);
+        const dim3 g(nblk, w0->ncomp, (kk + KB - 1) / KB);
+#define BD(S_) hipLaunchKernelGGL((k_block_dot_s<KB, S_>), g, dim3(NT), 0, st, V, b->stride, kk, (const double *)W, b->stride, \
+                                  (const double *)b->mesh->d_bm1, b->mesh->lvs, nblk, nper, ctx->d_partial)
+        if (s == 2) BD(2);
+        else if (s == 3) BD(3);
+        else BD(4);
+#undef BD
+        if (ctx->distributed()) {
+            hipLaunchKernelGGL(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, 0, (double *)nullptr);
+            NLG_TRY(allreduce_sum(ctx, out, kk * s));
+            if (acc) hipLaunchKernelGGL(k_vadd, dim3((kk * s + 255) / 256), dim3(256), 0, st, acc, out, kk * s);
+        } else {
+            hipLaunchKernelGGL(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, acc ? 1 : 0, acc);
+        }
+        return 0;
+    };
+    auto axpy = [&](const double *h, const double *hh, int64_t n, int64_t blk2) -> int {
+        ProfScope ps(ctx, P_BLOCKAXPY);
+        const size_t lds = sizeof(double) * 2 * (size_t)k * s;
+#define BA(S_) hipLaunchKernelGGL((k_block_axpy_s<S_>), dim3(grid_for(n)), dim3(NT), lds, st, (const double *)b->d, b->stride, k, h, hh, W, \
+                                  b->stride, n, blk2, -1.0)
+        if (s == 2) BA(2);
+        else if (s == 3) BA(3);
+        else BA(4);
+#undef BA
+        return 0;
+    };
+    if (k > 0) {
+        NLG_TRY(dots(b->d, k, H1, nullptr));
+        NLG_TRY(axpy(H1, nullptr, n2, n2));          // first pass: main block only
+        NLG_TRY(dots(b->d, k, H2, H1));              // H1 <- H1 + H2
+        NLG_TRY(axpy(H2, H1, n2all, n2));            // second pass: H2 on the main block, the sum on the history blocks
+    }
+    double R[4][4] = {};
+    for (int a = 0; a < s; ++a) R[a][a] = 1.0;
+    for (int round = 0; round < 2; ++round) {
+        NLG_TRY(dots(W, s, dG, nullptr));
+        double G[16];
+        NLG_HIP(hipMemcpyAsync(G, dG, sizeof(double) * s * s, hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        double L[4][4] = {};
+        for (int i = 0; i < s; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double a = G[i * s + j];
+                for (int q = 0; q < j; ++q) a -= L[i][q] * L[j][q];
+                if (i == j) {
+                    NLG_CHECK(a > 0.0 && std::isfinite(a), "nlg_basis_block_cgs2: the block is rank deficient (column %d, pivot %.3e)", k + i, a);
+                    L[i][i] = std::sqrt(a);
+                } else {
+                    L[i][j] = a / L[j][j];
+                }
+            }
+        // Rr = L^T (upper); T = Rr^-1 (upper, back substitution column by column); W <- W T; R <- Rr R
+        double T[4][4] = {};
+        for (int c = 0; c < s; ++c) {
+            T[c][c] = 1.0 / L[c][c];
+            for (int r = c - 1; r >= 0; --r) {
+                double a = 0.0;
+                for (int q = r + 1; q <= c; ++q) a += L[q][r] * T[q][c];
+                T[r][c] = -a / L[r][r];
+            }
+        }
+        double Tf[16], Rn[4][4] = {};
+        for (int a = 0; a < s; ++a)
+            for (int c = 0; c < s; ++c) {
+                Tf[a * s + c] = T[a][c];
+                for (int q = 0; q < s; ++q) Rn[a][c] += L[q][a] * R[q][c];
+            }
+        memcpy(R, Rn, sizeof(R));
+        NLG_HIP(hipMemcpyAsync(dT, Tf, sizeof(double) * s * s, hipMemcpyHostToDevice, st));
+        {
+            ProfScope ps(ctx, P_BLOCKAXPY);
+#define BR(S_) hipLaunchKernelGGL((k_block_rmul<S_>), dim3(grid_for(n2all)), dim3(NT), 0, st, W, b->stride, (const double *)dT, n2all)
+            if (s == 2) BR(2);
+            else if (s == 3) BR(3);
+            else BR(4);
+#undef BR
+        }
+        NLG_HIP(hipStreamSynchronize(st));   // Tf lives on this stack frame
+    }
+    std::vector<double> hs((size_t)std::max(k, 1) * s);
+    if (k > 0) {
+        NLG_HIP(hipMemcpyAsync(hs.data(), H1, sizeof(double) * (size_t)k * s, hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+    }
+    for (int v = 0; v < s; ++v) {
+        for (int j = 0; j < k; ++j) coef[(size_t)v * ld + j] = hs[(size_t)j * s + v];
+        for (int a = 0; a < s; ++a) coef[(size_t)v * ld + k + a] = R[a][v];
+    }
+    NLG_HIP(hipGetLastError());
     return 0;
 }
 

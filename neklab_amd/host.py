@@ -271,6 +271,13 @@ class KrylovBasis:
         check(self.lib.nlg_basis_cgs2(self.h, k, w.h, dptr(h), C.byref(beta)))
         return h[:k], beta.value
 
+    def block_cgs2(self, k: int, s: int) -> np.ndarray:
+        """Columns k .. k+s-1 orthogonalised against 0 .. k-1 and among themselves (nlg_basis_block_cgs2); returns the
+        (k+s, s) coefficient matrix: projection coefficients on top, the upper-triangular R below."""
+        coef = np.zeros((k + s, s), order="F")
+        check(self.lib.nlg_basis_block_cgs2(self.h, int(k), int(s), dptr(coef)))
+        return coef
+
     def combine(self, k: int, c, out: nek_dvector):
         a = np.ascontiguousarray(c, dtype=np.float64)
         check(self.lib.nlg_basis_combine(self.h, k, dptr(a), out.h))
@@ -648,6 +655,12 @@ def arnoldi_step(exptA: exptA_linop, basis: KrylovBasis, k: int, H: np.ndarray, 
     """H is Fortran-ordered (kdim+1, kdim)."""
     assert H.flags.f_contiguous
     check(exptA.lib.nlg_arnoldi_step(exptA.h, basis.h, int(k), dptr(H), H.shape[0], int(bool(transpose))))
+
+
+def block_arnoldi_step(exptA: exptA_linop, basis: KrylovBasis, k: int, s: int, H: np.ndarray, transpose: bool = False):
+    """Columns k .. k+s-1 -> k+s .. k+2s-1; H (Fortran-ordered) receives H[0:k+2s, k:k+s]."""
+    assert H.flags.f_contiguous
+    check(exptA.lib.nlg_block_arnoldi_step(exptA.h, basis.h, int(k), int(s), dptr(H), H.shape[0], int(bool(transpose))))
 
 
 def eigs(exptA: exptA_linop, X: list, kdim: int = 0, tol: float = 0.0, x0: nek_dvector | None = None,

@@ -48,6 +48,45 @@ def arnoldi_step(matvec, V, H, k):
     return beta
 
 
+def block_cgs2(V, k, s):
+    """Block classical Gram-Schmidt with re-orthogonalisation of the s vectors V[k:k+s] against V[:k], then a Cholesky QR
+    (twice) among them; returns the (k+s, s) coefficient matrix [projection coefficients; R] with
+    W_old = V[:k] coef[:k] + W_new R.  The twin of nlg_basis_block_cgs2 (block Arnoldi; LightKrylov's block variants are
+    not in the reference tree -- restated from the published method: Stathopoulos & Wu 2002 for CholQR2)."""
+    W = V[k:k + s]
+    coef = np.zeros((k + s, s))
+    for _ in range(2):
+        if k == 0:
+            break
+        h = np.array([[V[j].dot(W[v]) for v in range(s)] for j in range(k)])     # all projections from the same W
+        for v in range(s):
+            W[v].axpby(-1.0, lincomb(V, h[:, v], k), 1.0)
+        coef[:k] += h
+    R = np.eye(s)
+    for _ in range(2):
+        G = np.array([[W[a].dot(W[b]) for b in range(s)] for a in range(s)])
+        Rr = np.linalg.cholesky(G).T
+        T = np.linalg.inv(Rr)
+        Wn = []
+        for b in range(s):
+            w = lincomb(W, T[:, b], s)
+            Wn.append(w)
+        for b in range(s):
+            W[b] = Wn[b]
+        R = Rr @ R
+    coef[k:] = R
+    for v in range(s):
+        V[k + v] = W[v]
+    return coef
+
+
+def block_arnoldi_step(matvec, V, H, k, s):
+    """V[k:k+s] -> V[k+s:k+2s]; H[:k+2s, k:k+s] written."""
+    for v in range(s):
+        V[k + s + v] = matvec(V[k + v])
+    H[:k + 2 * s, k:k + s] = block_cgs2(V, k + s, s)
+
+
 def lincomb(V, c, k):
     """sum_i c[i] V[i], i < k.  With the consistent treatment of the restart history (oracle/vectors.py
     CONSISTENT_RST) the combination also carries the combined history slots of the basis vectors."""

@@ -33,8 +33,8 @@ def leading(H, k):
 THRESHOLDS = (1e-6, 1e-7, 1.5e-8, 1e-9, 1e-10)
 
 
-def run(name, history="consistent", lxd=None, tags=("v", "W"), tol=1e-6, zero_pr=False, seed=1, deep=False, **kw):
-    hm, ux, uy, p, re, lxd0, _ = load_cylinder(with_bcs=True, dirichlet_tags=tags)
+def run(name, history="consistent", lxd=None, tags=("v", "W"), tol=1e-6, zero_pr=False, seed=1, deep=False, geometry="fld", **kw):
+    hm, ux, uy, p, re, lxd0, _ = load_cylinder(with_bcs=True, dirichlet_tags=tags, geometry=geometry)
     gm = host.Mesh(ctx, hm, lxd=lxd if lxd else lxd0)
     bf = host.nek_dvector(gm)
     bf.set_field(0, ux)
@@ -46,6 +46,13 @@ def run(name, history="consistent", lxd=None, tags=("v", "W"), tol=1e-6, zero_pr
     A.init()
     B = host.KrylovBasis(gm, KDIM + 1)
     B[0].rand(True, seed=seed)
+    if history == "warm":
+        # start from the IMAGE of the random vector: it carries a restart history like every later Krylov vector, so all
+        # columns of the Arnoldi relation come from one and the same linear map (see the header of the seeds table)
+        w = host.nek_dvector(gm)
+        A.matvec(B[0], w)
+        w.scal(1.0 / w.norm())
+        B[0].assign(w)
     H = np.zeros((KDIM + 2, KDIM + 1), order="F")
     t0 = time.time()
     first, last = None, None
@@ -106,6 +113,19 @@ if __name__ == "__main__":
     if which == ["seeds"]:      # scatter over the start vector (the reference draws it with the compiler's random_number)
         for sd in (1, 2, 3, 5, 7, 11, 13, 17):
             lines.append(run("start vector seed %d" % sd, seed=sd, deep=True))
+    if which == ["geometry"]:   # float32-quantised coordinates of the field file vs the double-precision rebuild from 1cyl.re2
+        for geo in ("fld", "re2"):
+            for hist in ("warm", "none"):
+                lines.append(run("geometry %s, %s start" % (geo, hist), history=hist, geometry=geo, deep=True))
+        open(os.path.join(ROOT, "gpurun_out", "r02_cylinder_geometry.txt"), "w").write("\n".join(lines) + "\n")
+        sys.exit(0)
+    if which == ["protocol"]:   # is the scatter the missing history of the start vector?
+        for hist in ("warm", "none", "literal"):
+            for sd in (1, 2, 11):
+                lines.append(run("%s, seed %d" % (hist, sd), history=hist, seed=sd, deep=True))
+        open(os.path.join(ROOT, "gpurun_out", "r02_cylinder_protocol.txt"), "w").write("\n".join(lines) + "\n")
+        sys.exit(0)
+    if which == ["seeds"]:
         open(os.path.join(ROOT, "gpurun_out", "r02_cylinder_seeds.txt"), "w").write("\n".join(lines) + "\n")
         sys.exit(0)
     for i, (name, kw) in enumerate(V):

@@ -49,3 +49,14 @@ if __name__ == "__main__":
                         bc_elem=np.array([b[0] for b in bcs]), bc_face=np.array([b[1] for b in bcs]),
                         bc_tag=np.array([b[2] for b in bcs]))
     print(OUT, os.path.getsize(OUT), "bytes")
+    # the mesh files of the same case as data: vertex coordinates and circular-arc records of 1cyl.re2, global vertex
+    # ids and bisection keys of 1cyl.ma2 (what Nek5000's genxyz / set_vert start from)
+    from neklab_amd.nekio import read_ma2, read_re2
+    r = read_re2(SRC.replace("BF_1cyl0.f00001", "1cyl.re2"))
+    m = read_ma2(SRC.replace("BF_1cyl0.f00001", "1cyl.ma2"))
+    assert all(c[3] == "C" for c in r["curves"])
+    out2 = OUT.replace("reference_cyl_baseflow", "reference_cyl_mesh")
+    np.savez_compressed(out2, xc=r["xc"], yc=r["yc"], curve_elem=np.array([c[0] for c in r["curves"]]),
+                        curve_edge=np.array([c[1] for c in r["curves"]]), curve_par=np.array([c[2] for c in r["curves"]]),
+                        vert=m["vert"], pmap=m["pmap"])
+    print(out2, os.path.getsize(out2), "bytes")

@@ -8,7 +8,14 @@ from neklab_amd.mesh import BoxMesh
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_cylinder(with_bcs=False, dirichlet_tags=("v", "W")):
+def load_cylinder_mesh():
+    """(xc, yc, curves, vert, pmap) of the reference's 1cyl.re2 / 1cyl.ma2 (tests/golden/reference_cyl_mesh.npz)."""
+    d = np.load(os.path.join(HERE, "golden", "reference_cyl_mesh.npz"))
+    curves = [(int(e), int(s), p, "C") for e, s, p in zip(d["curve_elem"], d["curve_edge"], d["curve_par"])]
+    return d["xc"], d["yc"], curves, d["vert"], d["pmap"]
+
+
+def load_cylinder(with_bcs=False, dirichlet_tags=("v", "W"), geometry="fld"):
     """with_bcs=False: connectivity from coincident coordinates only, no masks (operator-level checks).
     with_bcs=True : the boundary conditions of 1cyl.re2 applied: 'v' / 'W' faces Dirichlet-masked, 'O' natural,
     'P' faces (y = -16 <-> y = +16) identified in the global numbering."""
@@ -16,13 +23,25 @@ def load_cylinder(with_bcs=False, dirichlet_tags=("v", "W")):
     d = np.load(os.path.join(HERE, "golden", "reference_cyl_baseflow.npz"))
     n = int(d["n"])
     x, y = d["x"].copy(), d["y"].copy()
+    if geometry == "re2":
+        # GLL coordinates rebuilt in double precision from the vertices and circular arcs of 1cyl.re2 (Nek5000's genxyz)
+        # instead of the field file's, which carry float32 precision only (79 % of them are exactly float32 numbers)
+        from neklab_amd.nekio import re2_gll_coords
+        xc, yc, curves, vert, _ = load_cylinder_mesh()
+        X, Y = re2_gll_coords(xc, yc, curves, n)
+        x, y = X[d["elmap"] - 1], Y[d["elmap"] - 1]
     E = x.shape[0]
     yk = y.copy()
     if with_bcs:
         yk = np.where(np.abs(y - 16.0) < 1e-9, -16.0, y)      # periodic identification
     # global numbering from coincident coordinates (the field file carries no connectivity)
-    key = np.round(np.stack([x.ravel(), yk.ravel()], 1) / 1e-8).astype(np.int64)
+    key = np.round(np.stack([x.ravel(), yk.ravel()], 1) / 1e-7).astype(np.int64)
     _, glo = np.unique(key, axis=0, return_inverse=True)
+    if geometry == "re2":
+        # ... with that geometry the connectivity comes from the global vertex ids of 1cyl.ma2 as in Nek5000 (periodic
+        # faces are already identified there); it is the same partition of the points as the coordinate-based one
+        from neklab_amd.nekio import glo_num_from_vertices
+        glo = glo_num_from_vertices(vert, n, 2)[d["elmap"] - 1]
     ones = np.ones((E, n * n))
     mask = [ones.copy(), ones.copy()]
     if with_bcs:

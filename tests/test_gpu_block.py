@@ -1,0 +1,133 @@
+"""Block orthogonalisation and block Arnoldi (BASELINE.json config 5 names a block-Arnoldi run; the reference advances
+several perturbations together through Nek5000's lpert / npert, src/neklab_nek_setup.f90:39-247) on the GPU against the
+oracle twin, and against the single-vector path: the same spectrum from a block Krylov space."""
+import numpy as np
+import pytest
+
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+from oracle.krylov import block_arnoldi_step as o_block_step
+from oracle.krylov import block_cgs2 as o_block_cgs2
+from oracle.krylov import cgs2_step
+from oracle.lns import ExptA, LNSConfig
+from oracle.sem import SEM
+from oracle.vectors import NekDVector
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(sem, gm, seed, with_history):
+    ov = NekDVector(sem)
+    ov.rand(ifnorm=True, seed=seed)
+    ov.pr[...] = 0.1 * np.random.default_rng(seed).standard_normal(sem.shape2)
+    if with_history:
+        for r in (1, 2):
+            h = NekDVector(sem)
+            h.rand(ifnorm=True, seed=100 * r + seed)
+            ov.save_rst(h, r)
+    return ov
+
+
+def upload(gv, ov, dim):
+    for i in range(dim):
+        gv.set_field(i, ov.v[i])
+    gv.set_field(host.PR, ov.pr)
+    for r in range(ov.nrst):
+        tmp = host.nek_dvector(gv.mesh)
+        for i in range(dim):
+            tmp.set_field(i, ov.v_rst[r][i])
+        tmp.set_field(host.PR, ov.pr_rst[r])
+        gv.save_rst(tmp, r + 1)
+
+
+@pytest.mark.parametrize("dim,n", [(2, 6), (3, 5), (3, 8)])
+@pytest.mark.parametrize("s", [2, 3, 4])
+def test_block_cgs2_matches_oracle(gpu_ctx, dim, n, s):
+    nel = (4, 3) if dim == 2 else (3, 2, 2)
+    hm = box_mesh(nel, n, periodic=(True,) + (False,) * (dim - 1), deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    k = 9                                          # not a multiple of the kernel's tile of 8 basis vectors
+    B = host.KrylovBasis(gm, k + s)
+    oV = []
+    for j in range(k):                              # an orthonormal basis with history, built by the single-vector path on both sides
+        ov = pair(sem, gm, 10 + j, with_history=True)
+        upload(B[j], ov, dim)
+        B.cgs2(j, B[j])
+        if j:
+            cgs2_step(oV, ov)
+        ov.scal(1.0 / ov.norm())
+        oV.append(ov)
+    for v in range(s):
+        ov = pair(sem, gm, 50 + v, with_history=True)
+        upload(B[k + v], ov, dim)
+        oV.append(ov)
+    coef = B.block_cgs2(k, s)
+    ocoef = o_block_cgs2(oV, k, s)
+    assert np.max(np.abs(coef - ocoef)) < 1e-11 * np.max(np.abs(ocoef)), np.max(np.abs(coef - ocoef))
+    assert np.allclose(np.tril(coef[k:], -1), 0.0)                     # R upper triangular
+    sc = max(np.abs(a).max() for a in oV[k].v)
+    for v in range(s):
+        for i in range(dim):
+            assert np.max(np.abs(B[k + v].get_field(i) - oV[k + v].v[i].ravel())) < 1e-10 * sc
+            assert np.max(np.abs(B[k + v].get_field(i, 2) - oV[k + v].v_rst[1][i].ravel())) < 1e-10 * sc     # history follows
+        assert np.max(np.abs(B[k + v].get_field(host.PR) - oV[k + v].pr.ravel())) < 1e-10 * max(sc, np.abs(oV[k + v].pr).max())
+    G = np.array([[B[i].dot(B[j]) for j in range(k + s)] for i in range(k + s)])
+    assert np.max(np.abs(G - np.eye(k + s))) < 1e-13
+    # s = 1 falls back to the single-vector path with the same output convention
+    w = pair(sem, gm, 99, with_history=False)
+    B2 = host.KrylovBasis(gm, 3)
+    for j in range(2):
+        upload(B2[j], oV[j], dim)
+    upload(B2[2], w, dim)
+    c1 = B2.block_cgs2(2, 1)
+    assert abs(c1[0, 0] - oV[0].dot(w)) < 1e-12 and c1[2, 0] > 0
+    with pytest.raises(host.NlgError):
+        B.block_cgs2(k, 5)
+
+
+def test_block_arnoldi_matches_oracle_and_single_vector_spectrum(gpu_ctx):
+    hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), periodic=(True, False), deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    U = [sem.mask[0] * (1.0 + np.sin(sem.X[0]) * np.cos(sem.X[1])), sem.mask[1] * np.sin(2 * sem.X[0]) * np.cos(sem.X[1])]
+    kw = dict(re=10.0, torder=3, tau=1.0, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    oA = ExptA(sem, U, LNSConfig(**kw))
+    gb = host.nek_dvector(gm)
+    for i in range(2):
+        gb.set_field(i, U[i])
+    gA = host.exptA_linop(1.0, gb, **{k: v for k, v in kw.items() if k != "tau"})
+    gA.init()
+    s, nblk = 2, 2
+    m = s * nblk
+    B = host.KrylovBasis(gm, m + s)
+    oV = [pair(sem, gm, 3 + v, with_history=False) for v in range(s)] + [None] * m
+    for v in range(s):
+        upload(B[v], oV[v], 2)
+    B.block_cgs2(0, s)
+    o_block_cgs2(oV, 0, s)
+    H, oH = np.zeros((m + s, m), order="F"), np.zeros((m + s, m))
+    for j in range(nblk):
+        host.block_arnoldi_step(gA, B, j * s, s, H)
+        o_block_step(oA.matvec, oV, oH, j * s, s)
+    assert np.max(np.abs(H - oH)) < 1e-9 * np.max(np.abs(oH)), np.max(np.abs(H - oH))
+    # the block Arnoldi relation A V_m = V_{m+s} H on the device vectors themselves
+    for c in range(m):
+        w = host.nek_dvector(gm)
+        gA.matvec(B[c], w)
+        r = w.copy()
+        for i in range(m + s):
+            r.axpby(-H[i, c], B[i], 1.0)
+        assert r.norm() < 1e-9 * w.norm()
+    # a longer block run finds the leading eigenvalue of the single-vector Arnoldi
+    m2 = 24
+    B2 = host.KrylovBasis(gm, m2 + s)
+    for v in range(s):
+        B2[v].rand(True, seed=21 + v)
+    B2.block_cgs2(0, s)
+    H2 = np.zeros((m2 + s, m2), order="F")
+    for j in range(m2 // s):
+        host.block_arnoldi_step(gA, B2, j * s, s, H2)
+    lam = np.linalg.eigvals(H2[:m2, :m2])
+    lead = lam[np.argmax(np.abs(lam))]
+    X = [host.nek_dvector(gm) for _ in range(2)]
+    mu, res, info = host.eigs(gA, X, kdim=24, tol=1e-9, write_intermediate=False, seed=1)
+    assert abs(abs(lead) - abs(mu[0])) < 1e-7 * abs(mu[0]), (lead, mu[0])

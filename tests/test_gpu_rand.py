@@ -35,7 +35,9 @@ def test_rand_noise_matches_oracle_hash(gpu_ctx, nel, n, periodic):
             got = gv.get_field(f if f < dim else host.THETA + f - dim)
             assert np.all(np.abs(got) <= 1.0)
             worst = max(worst, np.max(np.abs(got - raw.ravel())))
-        assert worst < 1e-7, worst
+        # 3-D: the first-stage value goes through sin() once more and is multiplied by fcoeff(1) ~ 1e4 before the two
+        # 1e3 sin(): an ulp of difference in that sin() reaches 1e-4 in the result (measured on the CPU: 8e-5)
+        assert worst < (1e-7 if dim == 2 else 5e-4), worst
         # "adds to the current contents" (real_vectors.f90:80-98): a second call doubles the field
         before = gv.get_field(0)
         host.check(gm.lib.nlg_vec_rand_noise(gv.h, seed))
