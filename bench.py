@@ -309,6 +309,29 @@ def main():
             ctx.sync()
             u3_vs_k[str(kk)] = round(1e3 * (time.perf_counter() - t_u), 3)
         del va, vb
+    # block Arnoldi (BASELINE.json config 5 names it): s = 4 vectors per step at the same basis size -- s matvecs, then
+    # ONE block CGS2 that reads the basis once per pass for all four (nlg_basis_block_cgs2)
+    blk = None
+    if not args.no_units and m + 1 >= 12:
+        sb = 4
+        kb = m + 1 - 2 * sb
+        Hb = np.zeros((m + 2, m + 1), order="F")
+        host.block_arnoldi_step(A, B, kb, sb, Hb)          # warm-up (the last 2 s basis columns are sacrificed)
+        B.block_cgs2(kb, sb)                                 # re-orthonormalise the input block
+        ctx.sync()
+        t_u = time.perf_counter()
+        host.block_arnoldi_step(A, B, kb, sb, Hb)
+        ctx.sync()
+        t_b = time.perf_counter() - t_u
+        for v in range(sb):
+            B[kb + sb + v].rand(False, seed=300 + v)
+        ctx.sync()
+        t_u = time.perf_counter()
+        B.block_cgs2(kb + sb, sb)
+        ctx.sync()
+        t_o = time.perf_counter() - t_u
+        blk = {"block_size": sb, "k": kb + sb, "matvecs_per_s": round(sb / t_b, 3), "ms_per_block_step": round(1e3 * t_b, 3),
+               "block_cgs2_ms": round(1e3 * t_o, 3), "block_cgs2_ms_per_vector": round(1e3 * t_o / sb, 3)}
 
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle restatement on a bounded sample
@@ -345,6 +368,7 @@ def main():
                        "operator_applies_per_s_per_field_per_gpu": None if u12_per_s is None else round(u12_per_s, 1),
                        "arnoldi_orthogonalisation_ms_at_k=m": None if u3_ms is None else round(u3_ms, 3),
                        "arnoldi_orthogonalisation_ms_vs_k": u3_vs_k,
+                       "block_arnoldi": blk,
                        "parallelism": "1 process per GPU, contiguous element blocks, RCCL all-reduce for every reduction, "
                                       "RCCL send/recv halo for the gather-scatter"},
             "roofline": roofline,

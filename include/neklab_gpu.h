@@ -309,6 +309,12 @@ typedef struct nlg_eigs_opts {
     double tol;             /* tolerance=, <= 0 => sqrt(1e-15) (LightKrylov rtol_dp)               */
     const char *logfile;    /* NULL => "eigs_output.txt"                                           */
     uint64_t seed;          /* start vector seed when x0 == NULL                                   */
+    int block_size;         /* > 1: block Arnoldi with this many vectors per step (<= 4): the basis is read once per
+                               block in every Gram-Schmidt pass; the first column is x0 / seed, the others are drawn;
+                               no restart (kdim = size of the block Krylov space).  0 / 1: Arnoldi + Krylov-Schur  */
+    int warm_start;         /* != 0: start from the image A x0 (which carries a restart history like every later Krylov
+                               vector) instead of x0 itself; removes the start-vector dependence of the converged Ritz
+                               values that the history-free first column causes.  Default 0 = LightKrylov */
 } nlg_eigs_opts;
 
 int nlg_eigs_opts_default(nlg_eigs_opts *o);

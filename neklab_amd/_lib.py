@@ -43,7 +43,7 @@ class ExptAConfig(C.Structure):
 class EigsOpts(C.Structure):
     _fields_ = [
         ("kdim", C.c_int), ("transpose", C.c_int), ("max_restarts", C.c_int), ("write_intermediate", C.c_int),
-        ("tol", C.c_double), ("logfile", C.c_char_p), ("seed", C.c_uint64),
+        ("tol", C.c_double), ("logfile", C.c_char_p), ("seed", C.c_uint64), ("block_size", C.c_int), ("warm_start", C.c_int),
     ]
 
 

@@ -124,18 +124,49 @@ __host__ __device__ inline int fg_slot(int N, int a, int j, int k) {
     return fbase + 6 * M * M + (a - 1) + M * ((j - 1) + M * (k - 1));
 }
 
-// "x-planes first" slot of point (a, j, k): the two x-faces of an element first -- per k the row (j = 0..N-1) of the a = 0
-// face followed by the row of the a = N-1 face, 2N doubles = one 128-byte line at N = 8 -- then the rest with a' = a - 1
-// fastest.  A k-slab of an element is then two dense runs (2N and (N-2) N doubles) for a kernel whose lanes are (a, j)
-// columns -- as many cache lines as the natural layout, whose slab is one run of N N -- while the copies of a shared
-// x-face, one 8-byte word per 64-byte row in the natural layout, become runs of N; y-faces are runs of N-2, z-faces stay
-// dense.  Used for the vectors of the velocity PCG (3-D), whose gather-scatter moved 3.2 times its algorithmic bytes in
-// the natural layout.  (Measured first with the two faces as separate N x N planes: the half-line rows cost the operator
-// kernel 11 %, more than the gather-scatter gained.)
-__host__ __device__ inline int xp_slot(int N, int a, int j, int k) {
-    if (a == 0) return 2 * N * k + j;
-    if (a == N - 1) return 2 * N * k + N + j;
-    return 2 * N * N + (a - 1) + (N - 2) * (j + N * k);
+// "Slab-permuted" slot of point (a, j, k) (historically "xp", x-planes first): every k-slab of an element stays one dense run
+// of N N doubles, but inside the slab the points are permuted so that the element-boundary points are contiguous:
+//   [ a = 0 row (j = 0..N-1) | a = N-1 row | j = 0 row (a = 1..N-2) | j = N-1 row | interior ]
+// and, at N = 8, two interior points pad each j-row so that it sits inside one 64-byte sector.  A kernel whose lanes are
+// (a, j) columns reads a slab as ONE coalesced run exactly as in the natural layout (the permutation only decides which
+// lane gets which word), while the copies of a shared x-face -- one 8-byte word per 64-byte row in the natural layout --
+// become sector-aligned runs of N, y-faces runs of N-2 inside one sector, z-faces whole slabs.  Used for the vectors of
+// the velocity PCG (3-D), whose gather-scatter moved 3.2 times its algorithmic bytes in the natural layout.
+// Measured on the way here (10^4 elements, lx1 = 8, ms per step): natural gs 7.09 / operator 6.07; x-faces as two separate
+// N x N planes: gs 6.2 / operator 6.7 (half-line rows); both x-rows of a slab in one line, rest natural: 6.07 / 6.32.
+inline void sp_slab_table(int N, int *tab /* [N*N], index a + N*j */) {
+    std::vector<int> order;   // slab positions (a + N*j) in storage order
+    std::vector<char> used((size_t)N * N, 0);
+    auto put = [&](int a, int j) {
+        order.push_back(a + N * j);
+        used[a + N * j] = 1;
+    };
+    for (int j = 0; j < N; ++j) put(0, j);
+    for (int j = 0; j < N; ++j) put(N - 1, j);
+    auto filler = [&](int count) {
+        for (int j = 1; j < N - 1 && count > 0; ++j)
+            for (int a = 1; a < N - 1 && count > 0; ++a)
+                if (!used[a + N * j]) {
+                    put(a, j);
+                    --count;
+                }
+    };
+    for (int a = 1; a < N - 1; ++a) put(a, 0);
+    if (N == 8) filler(2);
+    for (int a = 1; a < N - 1; ++a) put(a, N - 1);
+    if (N == 8) filler(2);
+    filler(N * N);
+    for (int q = 0; q < N * N; ++q) tab[order[q]] = q;
+}
+inline int xp_slot(int N, int a, int j, int k) {
+    static thread_local int cachedN = 0;
+    static thread_local std::vector<int> tab;
+    if (cachedN != N) {
+        tab.assign((size_t)N * N, 0);
+        sp_slab_table(N, tab.data());
+        cachedN = N;
+    }
+    return N * N * k + tab[a + N * j];
 }
 
 struct nlg_gs {

@@ -354,11 +354,43 @@ __global__ void k_mul(double *y, const double *a, const double *b, int64_t n) {
 // shared edge: four copies), then the rest: a thread of the pair / quad range reads its indices as one int2 / int4 and
 // needs neither the offset array nor a loop with dependent loads; the remaining groups (corners, irregular valences)
 // go through the general CSR path.  Sums run over ascending local index in every class.
+// Two pairs per thread where they are neighbours in memory (the face-grouped and slab-permuted layouts make the copies of
+// a shared face contiguous in both elements, and the pairs are ordered by their first index): one int4 of indices and
+// 16-byte loads / stores instead of two int2 and 8-byte accesses.  (In the natural layout the same idea lost -- 72 -> 86 us,
+// DESIGN.md -- because there neighbouring pairs are 64 bytes apart; the check below falls back to the scalar path then.)
 template <int NF>
 __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const int *__restrict__ idx, int64_t ngroups,
                                            int64_t npairs, int64_t nquads, F3 f, const double *__restrict__ gate) {
     if (gate && gate[0] != 0.0) return;
-    const int64_t g = blockIdx.x * (int64_t)NT + threadIdx.x;
+    const int64_t t = blockIdx.x * (int64_t)NT + threadIdx.x;
+    const int64_t np2 = npairs >> 1;
+    if (t < np2) {
+        const int4 q = reinterpret_cast<const int4 *>(idx)[t];
+        if (q.z == q.x + 1 && q.w == q.y + 1 && !((q.x | q.y) & 1)) {
+#pragma unroll
+            for (int c = 0; c < NF; ++c) {
+                double2 *pa = reinterpret_cast<double2 *>(f.p[c] + q.x), *pb = reinterpret_cast<double2 *>(f.p[c] + q.y);
+                const double2 a = *pa, b = *pb;
+                double2 s;
+                s.x = a.x + b.x;
+                s.y = a.y + b.y;
+                *pa = s;
+                *pb = s;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NF; ++c) {
+                const double s0 = f.p[c][q.x] + f.p[c][q.y];
+                const double s1 = f.p[c][q.z] + f.p[c][q.w];
+                f.p[c][q.x] = s0;
+                f.p[c][q.y] = s0;
+                f.p[c][q.z] = s1;
+                f.p[c][q.w] = s1;
+            }
+        }
+        return;
+    }
+    const int64_t g = 2 * np2 + (t - np2);   // the odd pair (if any), then quads, then the rest: one group per thread
     if (g >= ngroups) return;
     if (g < npairs) {
         const int2 ab = reinterpret_cast<const int2 *>(idx)[g];
@@ -541,7 +573,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
                                                        const double *__restrict__ G4, const double *__restrict__ G5,
                                                        const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                        double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                       const double *__restrict__ done_p) {
+                                                       const double *__restrict__ done_p, const int *__restrict__ xptab) {
     static_assert(N * N <= 64, "one lane per (i, j)");
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1;
     __shared__ double sD[N * N];
@@ -561,8 +593,8 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     const int64_t eoff = (e < E ? e : 0) * NP;
     const int base = ij;   // offset inside the element, natural layout (metric factors)
     // field offsets inside the element: vb + k * vs
-    const int vb = XP ? (i == 0 ? j : (i == N - 1 ? N + j : 2 * NS + (i - 1) + (N - 2) * j)) : ij;
-    const int vs = XP ? ((i == 0 || i == N - 1) ? 2 * N : (N - 2) * N) : NS;
+    const int vb = XP ? xptab[ij] : ij;   // slab-permuted layout: position inside the slab from the table (internal.h sp_slab_table)
+    constexpr int vs = NS;
     const double *uc = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2])) + eoff;
     double *wc = (c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2])) + eoff;
     const double *zc = (c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2])) + eoff;
@@ -1443,6 +1475,126 @@ __global__ __launch_bounds__(NT, 2) void k_conv3(int64_t E, const double *__rest
     }
 }
 
+// =================================================================================================
+// Dealiasing interpolation on the matrix cores: one velocity-mesh field -> its value and its three reference-space
+// derivatives on the fine (Gauss) mesh,
+//   uf = (J x J x J) u,   dx = (J x J x DJ) u,   dy = (J x DJ x J) u,   dz = (DJ x J x J) u        (z x y x x factors)
+// as three passes of small GEMMs  out(ND x cols) = M(ND x N) in(N x cols)  on v_mfma_f64_16x16x4_f64: M = a 16-row tile
+// (ND = 12 real rows, 4 of padding), K = N = 8 in two steps of 4, cols in tiles of 16.  Operand layout (the f64 form has
+// its own C/D map, cdna_hip_programming.md): A: lane l holds M[l & 15][l >> 4 (+ 4 ks)]; B: lane l holds in[l >> 4 (+ 4 ks)]
+// [col l & 15]; D: register r of lane l holds out[(l >> 4) + 4 r][col l & 15] -- r = 3 is the padding rows.
+// One element per block, four waves; a wave owns column tiles.  Shared stages: the x pass feeds two arrays (J u, DJ u),
+// the y pass three (JJ, J DJ, DJ J), the z pass the four results: 16 + 36 + 72 = 124 MFMAs per element.
+// Used for the base-flow side of the convective term (sem_conv_setup: once per operator for exptA, once per TIME STEP in
+// the nonlinear map of the Newton-Krylov solver), where the generic tensor kernel took twelve launches per field triple.
+// fp64 MFMA has the same peak rate as the fp64 vector pipe on MI355X (and the 12 -> 16 row padding costs a quarter of it),
+// so this is not about flops: it removes the LDS operand traffic and the instruction count of the scalar-FMA form; the
+// kernel is bound by its 55 KB of output per element.
+// =================================================================================================
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <int N, int ND>
+__global__ __launch_bounds__(256) void k_interp4_mfma(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
+                                                      const double *__restrict__ u, double *__restrict__ uf, double *__restrict__ dx,
+                                                      double *__restrict__ dy, double *__restrict__ dz) {
+    static_assert(N == 8 && ND <= 16 && ND > 8, "two k-steps of 4, one 16-row tile, three result registers");
+    constexpr int NP = N * N * N, NPD = ND * ND * ND, NDQ = ND + 1;
+    constexpr int CY = ND * N, CZ = ND * ND;                 // columns of the y and z passes
+    __shared__ double sA[NDQ * N * N], sB[NDQ * N * N];      // x pass: (a | j, k), J u and DJ u
+    __shared__ double sAA[CZ * N], sAD[CZ * N], sBA[CZ * N]; // y pass: (a, b | k)
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t e = blockIdx.x;
+    if (e >= E) return;
+    double ja[2], da[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        ja[ks] = l15 < ND ? Jg[l15 * N + lg + 4 * ks] : 0.0;
+        da[ks] = l15 < ND ? DJg[l15 * N + lg + 4 * ks] : 0.0;
+    }
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    // ---- x pass: columns (j, k), 64 = 4 tiles, one per wave
+    {
+        const int col = 16 * wave + l15;
+        const double b0 = u[e * NP + lg + N * col], b1 = u[e * NP + lg + 4 + N * col];
+        v4f64 aj = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], b0, zero, 0, 0, 0);
+        aj = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], b1, aj, 0, 0, 0);
+        v4f64 ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], b0, zero, 0, 0, 0);
+        ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], b1, ad, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int a = lg + 4 * r;
+            if (a < ND) {
+                sA[a + NDQ * col] = aj[r];
+                sB[a + NDQ * col] = ad[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- y pass: columns (a, k), ND * N = 96 = 6 tiles
+    for (int t = wave; t * 16 < CY; t += 4) {
+        const int col = 16 * t + l15;
+        const int a = col % ND, kz = col / ND;
+        const bool ok = col < CY;
+        double va[2], vb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int j = lg + 4 * ks;
+            va[ks] = ok ? sA[a + NDQ * (j + N * kz)] : 0.0;
+            vb[ks] = ok ? sB[a + NDQ * (j + N * kz)] : 0.0;
+        }
+        v4f64 aa = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], va[0], zero, 0, 0, 0);
+        aa = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], va[1], aa, 0, 0, 0);
+        v4f64 ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], va[0], zero, 0, 0, 0);
+        ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], va[1], ad, 0, 0, 0);
+        v4f64 ba = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], vb[0], zero, 0, 0, 0);
+        ba = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], vb[1], ba, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int b = lg + 4 * r;
+            if (ok && b < ND) {
+                const int q = a + ND * (b + ND * kz);
+                sAA[q] = aa[r];
+                sAD[q] = ad[r];
+                sBA[q] = ba[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- z pass: columns (a, b), ND * ND = 144 = 9 tiles; results straight to HBM (16 consecutive doubles per row)
+    for (int t = wave; t * 16 < CZ; t += 4) {
+        const int col = 16 * t + l15;
+        const bool ok = col < CZ;
+        double v0[2], v1[2], v2[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k = lg + 4 * ks;
+            v0[ks] = ok ? sAA[col + CZ * k] : 0.0;
+            v1[ks] = ok ? sAD[col + CZ * k] : 0.0;
+            v2[ks] = ok ? sBA[col + CZ * k] : 0.0;
+        }
+        v4f64 r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v0[0], zero, 0, 0, 0);
+        r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v0[1], r0, 0, 0, 0);
+        v4f64 r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], v0[0], zero, 0, 0, 0);
+        r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], v0[1], r1, 0, 0, 0);
+        v4f64 r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v1[0], zero, 0, 0, 0);
+        r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v1[1], r2, 0, 0, 0);
+        v4f64 r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v2[0], zero, 0, 0, 0);
+        r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v2[1], r3, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int c = lg + 4 * r;
+            if (ok && c < ND) {
+                const int64_t q = e * NPD + col + (int64_t)CZ * c;
+                uf[q] = r0[r];
+                dz[q] = r1[r];
+                dy[q] = r2[r];
+                dx[q] = r3[r];
+            }
+        }
+    }
+}
+
 // CFL (Nek compute_cfl): max over points of dt * sum_j |u_rj| * rdr
 __global__ __launch_bounds__(NT) void k_cfl(int dim, int n, int64_t E, CF9 rst, const double *jac, const double *rdr,
                                             CF3 U, double dt, double *partial) {
@@ -1714,10 +1866,10 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         if constexpr (N_ <= 8) {                                                                                      \
             if (xp)                                                                                                   \
             hipLaunchKernelGGL((k_axhelm3r<N_, 4, true>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
-                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp); \
             else                                                                                                      \
             hipLaunchKernelGGL((k_axhelm3r<N_, 4, false>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
-                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr); \
         } else                                                                                                          \
         hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
                            m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
@@ -1938,6 +2090,25 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
     const int dim = m->dim;
     CF9 rd;
     for (int q = 0; q < 9; ++q) rd.p[q] = m->d_rstdw[q];
+    static const int use_mfma = getenv("NLG_MFMA") ? atoi(getenv("NLG_MFMA")) : 1;
+    if (dim == 3 && m->n == 8 && m->nd == 12 && use_mfma) {
+        // matrix-core path: per component one launch produces the fine-mesh value and the three derivatives
+        double *ufb[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), sem_scratchd(m, 2)};
+        double *du[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), sem_scratchd(m, 5)};
+        NLG_CHECK(ufb[0] && ufb[1] && ufb[2] && du[0] && du[1] && du[2], "sem_conv_setup: scratch allocation failed");
+        for (int i = 0; i < 3; ++i) {
+            hipLaunchKernelGGL((k_interp4_mfma<8, 12>), dim3((unsigned)m->E), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd,
+                               (const double *)m->d_DJd, (const double *)U[i], ufb[i], du[0], du[1], du[2]);
+            CF3 dd = {{du[0], du[1], du[2]}};
+            F3 gu = {{GU[i * 3 + 0], GU[i * 3 + 1], GU[i * 3 + 2]}};
+            hipLaunchKernelGGL(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, dd, gu);
+        }
+        CF3 uf = {{ufb[0], ufb[1], ufb[2]}};
+        F3 ur = {{Ur[0], Ur[1], Ur[2]}};
+        hipLaunchKernelGGL(k_conv_ur, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, uf, ur);
+        NLG_HIP(hipGetLastError());
+        return 0;
+    }
     double *t[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
     NLG_CHECK(t[0] && t[1], "sem_conv_setup: scratch allocation failed");
     for (int i = 0; i < dim; ++i) NLG_TRY(sem_tensor(m, U[i], t[i], m->n, m->nd, m->d_Jd, m->d_Jd, m->d_Jd, nullptr));

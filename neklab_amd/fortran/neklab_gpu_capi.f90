@@ -38,6 +38,7 @@ module neklab_gpu_capi
       real(c_double) :: tol = 0.0_c_double
       type(c_ptr) :: logfile = c_null_ptr
       integer(c_int64_t) :: seed = 0
+      integer(c_int) :: block_size = 0, warm_start = 0
    end type
 
    !> what the reference reads from Nek5000's `param(.)` / logical flags: the template every exptA_linop starts from,

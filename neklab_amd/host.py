@@ -665,7 +665,7 @@ def block_arnoldi_step(exptA: exptA_linop, basis: KrylovBasis, k: int, s: int, H
 
 def eigs(exptA: exptA_linop, X: list, kdim: int = 0, tol: float = 0.0, x0: nek_dvector | None = None,
          transpose: bool = False, write_intermediate: bool = True, logfile: str | None = None, seed: int = 0,
-         max_restarts: int = 50):
+         max_restarts: int = 50, block_size: int = 0, warm_start: bool = False):
     """reference call: eigs(exptA, eigvecs, eigvals, residuals, info, x0=, kdim=, transpose=,
     write_intermediate=) at neklab_analysis.f90:80-81.  Returns (eigvals complex[nev], residuals, info)."""
     lib = exptA.lib
@@ -674,6 +674,7 @@ def eigs(exptA: exptA_linop, X: list, kdim: int = 0, tol: float = 0.0, x0: nek_d
     check(lib.nlg_eigs_opts_default(C.byref(o)))
     o.kdim, o.transpose, o.write_intermediate, o.tol, o.seed = int(kdim), int(bool(transpose)), int(bool(write_intermediate)), float(tol), int(seed)
     o.max_restarts = int(max_restarts)
+    o.block_size, o.warm_start = int(block_size), int(bool(warm_start))
     if logfile is not None:
         o.logfile = logfile.encode()
     re, im, res = np.zeros(nev), np.zeros(nev), np.zeros(nev)
@@ -783,7 +784,8 @@ def save_eigenspectrum(eigvals, residuals, filename: str):
 
 def linear_stability_analysis_fixed_point(exptA: exptA_linop, kdim: int, nev: int, adjoint: bool = False,
                                           X0: nek_dvector | None = None, tol: float = 0.0, outdir: str = ".",
-                                          seed: int = 0, outpost: bool = False, session: str = "neklab"):
+                                          seed: int = 0, outpost: bool = False, session: str = "neklab",
+                                          block_size: int = 0, warm_start: bool = False):
     """reference: neklab_analysis.f90:38-105.  Returns (eigvals continuous-time, residuals, eigvecs)."""
     mesh = exptA.mesh
     eigvecs = [nek_dvector(mesh, 0, 3) for _ in range(nev)]   # lorder = 3 as in every reference SIZE file
@@ -791,7 +793,8 @@ def linear_stability_analysis_fixed_point(exptA: exptA_linop, kdim: int, nev: in
         v.zero()                                                     # zero_basis, :77
     prefix = "adj" if adjoint else "dir"
     mu, residuals, info = eigs(exptA, eigvecs, kdim=kdim, x0=X0, transpose=adjoint, write_intermediate=True,
-                               logfile=os.path.join(outdir, "eigs_output.txt"), tol=tol, seed=seed)
+                               logfile=os.path.join(outdir, "eigs_output.txt"), tol=tol, seed=seed,
+                               block_size=block_size, warm_start=warm_start)
     eigvals = np.log(mu.astype(complex)) / exptA.info()["tau"]       # :84
     save_eigenspectrum(eigvals, residuals, os.path.join(outdir, prefix + "_eigenspectrum.npy"))   # :90
     if outpost:

@@ -32,8 +32,9 @@ for k,v in cands.items():
 
 r3=fc[0]*(ieg+xl[2]*np.sin(r2))+fc[1]*iz*ix+fc[2]*iz
 d=np.abs(got-cands['oracle'].ravel())
-big=(np.maximum(np.abs(r2),np.abs(r3))>2**20).ravel()
-print('points with max(|r2|,|r3|) > 2^20:',big.sum(),' of ',big.size)
-print('err where big: max %.3e median %.3e ; where small: max %.3e median %.3e'%(d[big].max(),np.median(d[big]),d[~big].max(),np.median(d[~big])))
-bad=np.nonzero(d>1e-3)[0][:10]
-for i in bad: print(i, got[i], cands['oracle'].ravel()[i], r2.ravel()[i], r3.ravel()[i])
+bad=np.nonzero(d>1e-5)[0]
+print('bad points',len(bad),'of',d.size)
+s2=np.sin(r2).ravel()
+for i in bad[:12]: print(i, 'got %.6f want %.6f'%(got[i], cands['oracle'].ravel()[i]), 'r2 %.6f r3 %.6f sin(r2) %.17g'%(r2.ravel()[i], r3.ravel()[i], s2[i]), 'fc', [f.ravel()[i] for f in fc])
+print('r2 range of bad', np.abs(r2.ravel()[bad]).min(), np.abs(r2.ravel()[bad]).max(), ' all', np.abs(r2).min(), np.abs(r2).max())
+print('r3 range of bad', np.abs(r3.ravel()[bad]).min(), np.abs(r3.ravel()[bad]).max(), ' all', np.abs(r3).min(), np.abs(r3).max())

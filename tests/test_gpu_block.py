@@ -120,8 +120,10 @@ def test_block_arnoldi_matches_oracle_and_single_vector_spectrum(gpu_ctx):
     # a longer block run finds the leading eigenvalue of the single-vector Arnoldi
     m2 = 24
     B2 = host.KrylovBasis(gm, m2 + s)
-    for v in range(s):
-        B2[v].rand(True, seed=21 + v)
+    for v in range(s):                       # start from IMAGES of random vectors: every column then carries a restart
+        x = host.nek_dvector(gm)             # history and the whole block Krylov space belongs to one linear map
+        x.rand(True, seed=21 + v)            # (otherwise the converged Ritz values depend on the start vectors)
+        gA.matvec(x, B2[v])
     B2.block_cgs2(0, s)
     H2 = np.zeros((m2 + s, m2), order="F")
     for j in range(m2 // s):
@@ -129,5 +131,40 @@ def test_block_arnoldi_matches_oracle_and_single_vector_spectrum(gpu_ctx):
     lam = np.linalg.eigvals(H2[:m2, :m2])
     lead = lam[np.argmax(np.abs(lam))]
     X = [host.nek_dvector(gm) for _ in range(2)]
-    mu, res, info = host.eigs(gA, X, kdim=24, tol=1e-9, write_intermediate=False, seed=1)
+    mu, res, info = host.eigs(gA, X, kdim=24, tol=1e-9, write_intermediate=False, seed=1, warm_start=True)
     assert abs(abs(lead) - abs(mu[0])) < 1e-7 * abs(mu[0]), (lead, mu[0])
+
+
+def test_eigs_block_mode_and_warm_start(gpu_ctx):
+    """nlg_eigs options: block_size = 2 (block Arnoldi inside eigs) finds the eigenvalues of the single-vector run started
+    the same way; warm_start removes the dependence of the converged Ritz values on the start vector that the history-
+    free first Krylov column causes: two seeds agree to 1e-8 warm, and differ by more than 1e-5 cold."""
+    hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), periodic=(True, False), deform=0.04)
+    gm = host.Mesh(gpu_ctx, hm)
+    U = [hm.mask[0] * (1.0 + np.sin(hm.x) * np.cos(hm.y)), hm.mask[1] * np.sin(2 * hm.x) * np.cos(hm.y)]
+    gb = host.nek_dvector(gm)
+    for i in range(2):
+        gb.set_field(i, U[i])
+    gA = host.exptA_linop(1.0, gb, re=10.0, torder=3, vtol=1e-12, ptol=1e-12, maxit_v=400, maxit_p=4000)
+    gA.init()
+
+    def lead(**kw):
+        X = [host.nek_dvector(gm) for _ in range(2)]
+        mu, res, info = host.eigs(gA, X, kdim=28, tol=1e-9, write_intermediate=False, **kw)
+        assert res[0] < 1e-9
+        return mu[0], info, X
+
+    cold = [lead(seed=sd)[0] for sd in (1, 2)]
+    warm = [lead(seed=sd, warm_start=True)[0] for sd in (1, 2)]
+    assert abs(warm[0] - warm[1]) < 1e-8 * abs(warm[0]), warm
+    assert abs(cold[0] - cold[1]) > 1e-5 * abs(cold[0]), cold
+    assert abs(cold[0] - warm[0]) < 1e-2 * abs(warm[0])
+    mu_b, info_b, Xb = lead(seed=1, warm_start=True, block_size=2)
+    assert info_b % 2 == 0                                    # two warm-up matvecs + an even number of block matvecs
+    assert abs(mu_b - warm[0]) < 1e-8 * abs(warm[0]), (mu_b, warm[0])
+    # the Ritz vector of the block run is an eigenvector: residual of the matvec itself
+    w = host.nek_dvector(gm)
+    gA.matvec(Xb[0], w)
+    if abs(mu_b.imag) < 1e-12:
+        w.axpby(-mu_b.real, Xb[0], 1.0)
+        assert w.norm() < 1e-6 * Xb[0].norm()
