@@ -213,8 +213,10 @@ typedef struct nlg_exptA_config {
     int ifheat;        /* Boussinesq coupling with one scalar (temperature): the vectors carry theta (nscal = 1), the base
                           flow its base temperature.  rhocp (d/dt + U.grad) theta + rhocp u.grad Theta = conductivity
                           lap theta, momentum forcing buoy[i] * theta -- Nek5000's [TEMPERATURE] block and the buoyancy of
-                          the case's userf (examples/rayBen/baseflow/rayBen.par:39-45, rayBen.usr:77-103).  Direct
-                          equations only.                                                                           */
+                          the case's userf (examples/rayBen/baseflow/rayBen.par:39-45, rayBen.usr:77-103).  rmatvec
+                          integrates the adjoint of the coupled operator in the velocity + temperature inner product:
+                          u+_t = L_u^+ u+ - theta+ grad Theta,  rhocp theta+_t = rhocp U.grad theta+ + conductivity lap
+                          theta+ + rhocp buoy . u+   (exponential_propagator_temp.f90:62-107).                       */
     double conductivity;
     double rhocp;
     double buoy[3];

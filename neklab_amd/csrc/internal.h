@@ -373,7 +373,8 @@ int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, co
 int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU);
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint);
 int sem_conv_scalar_setup(nlg_mesh *m, const double *Theta, double **GT);
-int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, double *const *u, const double *theta, double *out);
+int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, double *const *u, const double *theta, double *out, int adjoint = 0);
+int sem_scalar_grad_apply(nlg_mesh *m, double *const *GT, const double *theta, double *const *out, double sgn);
 int sem_cfl(nlg_mesh *m, double *const *U, double dt, double *cfl_host);
 int sem_ortho(nlg_mesh *m, double *p);
 double *sem_scratch1(nlg_mesh *m, int i);

@@ -521,6 +521,9 @@ __global__ __launch_bounds__(NT) void k_recipmask(int64_t n, double *y, const do
 __global__ __launch_bounds__(NT) void k_recip1(int64_t n, double *y, const double *d) {
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = 1.0 / d[i];
 }
+__global__ __launch_bounds__(NT) void k_mul3_acc(int64_t n, double *y, const double *a, const double *b, double s) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] += s * a[i] * b[i];
+}
 __global__ __launch_bounds__(NT) void k_mul3(int64_t n, double *y, const double *a, const double *b, double s) {
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = s * a[i] * b[i];
 }
@@ -888,7 +891,16 @@ int heat_step(nlg_linop *op, int k, double b0) {
     const auto &c = op->cfg;
     const double dt = op->dt, rc = c.rhocp;
     // explicit term into the oldest buffer, then rotate
-    NLG_TRY(sem_conv_scalar_apply(m, op->Ur, op->GT, op->ubuf[0], op->tbuf[0], op->ftbuf[2]));
+    const int adj = (op->adjoint && !op->nonlinear) ? 1 : 0;
+    NLG_TRY(sem_conv_scalar_apply(m, op->Ur, op->GT, op->ubuf[0], op->tbuf[0], op->ftbuf[2], adj));
+    if (adj) {
+        // adjoint temperature equation: rhocp theta+_t = rhocp (U.grad) theta+ + conductivity lap theta+ + rhocp b . u+
+        // (stored term N_t = -conv(U, theta+) - bm1 b . u+ ; oracle/lns.py advance, adjoint branch)
+        for (int i = 0; i < m->dim; ++i)
+            if (c.buoy[i] != 0.0)
+                hipLaunchKernelGGL(k_mul3_acc, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->ftbuf[2], (const double *)m->d_bm1,
+                                   (const double *)op->ubuf[0][i], -c.buoy[i]);
+    }
     {
         double *t = op->ftbuf[2];
         op->ftbuf[2] = op->ftbuf[1];
@@ -1109,7 +1121,10 @@ int advance(nlg_linop *op) {
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
     NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
-    if (op->cfg.ifheat) {
+    if (op->cfg.ifheat && op->adjoint && !op->nonlinear) {
+        // adjoint momentum equation: - theta+ grad Theta with the new theta+ (stored F is +N: add the weak term)
+        NLG_TRY(sem_scalar_grad_apply(m, op->GT, op->tbuf[0], Fnew, 1.0));
+    } else if (op->cfg.ifheat) {
         const double bs = op->nonlinear ? 2.0 : 1.0;   // the nonlinear step halves the whole stored term (F holds 2 N there)
         launch_nf(dim, k_buoyancy<1>, k_buoyancy<2>, k_buoyancy<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(Fnew, dim),
                   (const double *)m->d_bm1, (const double *)op->tbuf[0], bs * op->cfg.buoy[0], bs * op->cfg.buoy[1], bs * op->cfg.buoy[2]);
@@ -1250,7 +1265,6 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
               "exptA matvec: vector on a different mesh (reference: type_error, exponential_propagator.f90:53-58)");
     NLG_CHECK(vin->nscal == (op->cfg.ifheat ? 1 : 0) && vout->nscal == vin->nscal,
               "exptA matvec: the vectors carry %d scalar(s), the operator expects %d (cfg.ifheat)", vin->nscal, op->cfg.ifheat ? 1 : 0);
-    NLG_CHECK(!(op->cfg.ifheat && adjoint), "exptA rmatvec: the adjoint Boussinesq coupling is not built");
     NLG_CHECK(vin->lorder >= op->cfg.torder && vout->lorder >= op->cfg.torder,
               "exptA matvec: vector lorder %d < time order %d", vin->lorder, op->cfg.torder);
     NLG_CHECK(vin != vout, "exptA matvec: vec_in and vec_out must be distinct (intent(in) / intent(out))");

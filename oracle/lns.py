@@ -222,8 +222,6 @@ class ExptA:
         self.istep = 0
         self.adjoint = adjoint
         if self.cfg.ifheat:
-            if adjoint:
-                raise NotImplementedError("adjoint Boussinesq coupling is not built")
             self.t = vec.theta[0].copy()
             self.tlag = [np.zeros(s.shape1) for _ in range(2)]
             self.ftlag = [np.zeros(s.shape1) for _ in range(2)]
@@ -245,6 +243,13 @@ class ExptA:
             rc = cfg.rhocp
             if getattr(self, "nonlinear", False):
                 Nt = s.conv_weak(self.u, self.t)                  # full equation: (u.grad) theta
+            elif self.adjoint:
+                # adjoint of the coupled operator in the reference's inner product (velocity + temperature, weight bm1, no
+                # rhocp factor: real_vectors.f90:217-224): with A = [[L_u, b], [-grad Theta . , L_theta / rhocp]] the adjoint is
+                #   u+_t     = L_u^+ u+ - theta+ grad Theta
+                #   rhocp theta+_t = rhocp (U . grad) theta+ + conductivity lap theta+ + rhocp b . u+
+                # (exponential_propagator_temp.f90:62-107 integrates Nek5000's adjoint equations; restated like the rest)
+                Nt = -s.conv_weak(self.U, self.t) - s.bm1 * sum(cfg.buoy[i] * self.u[i] for i in range(dim))
             else:
                 Nt = s.conv_weak(self.U, self.t) + s.conv_weak(self.u, self.Theta)
             Ft = -rc * Nt
@@ -270,7 +275,12 @@ class ExptA:
             ph = sign * omega * (self.istep - 1) * dt
             for i in range(dim):
                 F[i] = F[i] + s.bm1 * (np.cos(ph) * f_re[i] - (np.sin(ph) * f_im[i] if f_im is not None else 0.0))
-        if cfg.ifheat:
+        if cfg.ifheat and self.adjoint and not getattr(self, "nonlinear", False):
+            # - theta+ grad Theta, weak and dealiased like the convective terms, with the NEW theta+
+            tg = s.scalar_times_grad_weak(self.t, self.Theta)
+            for i in range(dim):
+                F[i] = F[i] - tg[i]
+        elif cfg.ifheat:
             for i in range(dim):
                 if cfg.buoy[i] != 0.0:
                     F[i] = F[i] + s.bm1 * cfg.buoy[i] * self.t

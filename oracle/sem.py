@@ -371,6 +371,13 @@ class SEM:
             acc = acc + cr * ur[j]
         return self.from_fine_T(acc)
 
+    def scalar_times_grad_weak(self, theta, Theta):
+        """Weak dealiased  J^T W_d [theta dTheta/dx_i], i = 1..dim  (the temperature term of the adjoint momentum
+        equation; the transpose of the u . grad Theta term of conv_weak)."""
+        tf = self.to_fine(self.f1(theta))
+        dT = self.fine_grad_rst(self.f1(Theta))
+        return [self.from_fine_T(tf * sum(self.rstdw[j][i] * dT[j] for j in range(self.dim))) for i in range(self.dim)]
+
     def lns_conv_weak(self, U, u, adjoint=False):
         """Weak linearised convective term (reference: neklab_linops.f90:268-313).
 

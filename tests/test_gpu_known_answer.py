@@ -5,9 +5,18 @@ exp(tau L), cylinder wake at Re = 50, tau = 1, lx1 = 6, bdf3, kdim = 128, nev = 
 Mesh coordinates, boundary conditions and base flow come from the reference's data files (fixture made by
 tests/golden/make_reference_fixture.py); everything else is this repository's HIP path.
 
-Measured (profiles/r01_cylinder_known_answer_sensitivity.log): |mu_1| = 1.015780, independent of dt
-(1.015782 at half the time step), i.e. 1.8e-4 above the printed reference value -- agreement in the 4th
-decimal, not inside the reference's own +-1e-4 window; the assertion below states what is achieved.
+What round 2 established (profiles/r02_cylinder_*.txt):
+* the discrete eigenvalue of the bdf3 propagator on this mesh is |mu_1| = 1.0157265 -- independent of the start vector
+  (three seeds agree to 1e-7), of dt (1.015728 at dt / 2), of the solver tolerances, of lxd (6 .. 12), of the geometry
+  source (float32-quantised coordinates of the field file or the double-precision rebuild from 1cyl.re2), and of the
+  pressure projection -- PROVIDED every Krylov vector, the first included, carries a restart history (`warm_start`);
+* with the reference's protocol the start vector has no history, its matvec starts impulsively at bdf1, and that rank-one
+  inconsistency of the Arnoldi relation moves the converged Ritz value by up to +-8e-5 depending on the (compiler-RNG)
+  start vector: 1.015705 .. 1.015865 over eight seeds, each converged to residual < 1e-8;
+* with the literal reading of real_vectors.f90:188-192 the scatter is 2.4e-3 (1.0170 .. 1.0194).
+The printed reference value 1.0156 is 1.27e-4 below the discrete eigenvalue and 1.05e-4 below the lowest sample of the
+reference's own protocol: outside the +-1e-4 window by a quarter of its width, inside the scatter that the protocol itself
+produces.  The assertions below state exactly that.
 """
 import numpy as np
 import pytest
@@ -18,7 +27,7 @@ from refdata import load_cylinder
 pytestmark = pytest.mark.gpu
 
 
-def test_cylinder_re50_leading_eigenvalue(gpu_ctx, tmp_path):
+def _cylinder_operator(gpu_ctx):
     hm, ux, uy, p, re, lxd, _ = load_cylinder(with_bcs=True)
     gm = host.Mesh(gpu_ctx, hm, lxd=lxd)
     bf = host.nek_dvector(gm)
@@ -26,12 +35,19 @@ def test_cylinder_re50_leading_eigenvalue(gpu_ctx, tmp_path):
     bf.set_field(host.VY, uy)
     A = host.exptA_linop(1.0, bf, re=re, torder=3, vtol=1e-9, ptol=1e-7, maxit_v=400, maxit_p=4000)
     A.init()
+    return gm, A
+
+
+def test_cylinder_re50_leading_eigenvalue(gpu_ctx, tmp_path):
+    """The reference's protocol (start vector without history), as in round 1."""
+    gm, A = _cylinder_operator(gpu_ctx)
     info = A.info()
     assert info["nsteps"] == 100 and abs(info["cfl"] - 0.5) < 0.01        # dt rule, neklab_nek_setup.f90:195-198
     eigvals, residuals, eigvecs, mu, nmv = host.linear_stability_analysis_fixed_point(
         A, 128, 2, tol=1e-6, outdir=str(tmp_path), seed=1)
     assert residuals[0] < 1e-6
-    assert abs(abs(mu[0]) - 1.0156) < 3e-4, abs(mu[0])
+    assert abs(abs(mu[0]) - 1.0156) < 3e-4, abs(mu[0])                    # published value +- (its window + the protocol's scatter)
+    assert abs(abs(mu[0]) - 1.0157265) < 1.7e-4, abs(mu[0])               # the scatter of this protocol around the discrete eigenvalue
     assert abs(mu[0].imag) > 0.6 and np.isclose(mu[0], np.conj(mu[1]))    # oscillatory wake mode, St ~ 0.12
     assert abs(eigvals[0].real - np.log(1.0156)) < 3e-4                   # growth rate log|mu|/tau
     # outputs the reference's tooling reads
@@ -40,6 +56,21 @@ def test_cylinder_re50_leading_eigenvalue(gpu_ctx, tmp_path):
     assert abs(float(conv[0][3]) - abs(mu[0])) < 1e-12                    # get_converged_eigs_data()['lambda_1']['modulus']
     spec = np.load(tmp_path / "dir_eigenspectrum.npy")
     assert spec.shape == (2, 3)
+
+
+def test_cylinder_re50_discrete_eigenvalue_is_start_vector_independent(gpu_ctx, tmp_path):
+    """With every Krylov vector carrying a restart history (warm_start) the leading Ritz value no longer depends on the
+    start vector: two seeds, |mu_1| = 1.0157265 +- 2e-6 each -- 1.27e-4 above the printed reference value."""
+    gm, A = _cylinder_operator(gpu_ctx)
+    vals = []
+    for seed in (2, 11):
+        eigvals, residuals, eigvecs, mu, nmv = host.linear_stability_analysis_fixed_point(
+            A, 128, 2, tol=1e-7, outdir=str(tmp_path), seed=seed, warm_start=True)
+        assert residuals[0] < 1e-7
+        vals.append(abs(mu[0]))
+    assert abs(vals[0] - vals[1]) < 2e-6, vals
+    assert abs(vals[0] - 1.0157265) < 2e-6, vals
+    assert 1.0e-4 < abs(vals[0] - 1.0156) < 1.5e-4
 
 
 def test_cylinder_base_flow_is_fixed_point_and_newton_returns_to_it(gpu_ctx):
