@@ -251,7 +251,9 @@ int nlg_linop_set_tolerances(nlg_linop *op, double vtol, double ptol);
  * derives from nelx, nely, nelz).  line_label2 / x2 (both or neither): the same for the pressure mesh, with the
  * coordinate along idir of every pressure point -- the pressure is then projected as well (bm2 weights); the reference
  * projects the velocity only, see DESIGN.md for why that is not enough behind an inner product that ignores the
- * pressure.  Single rank.  nlg_linop_project applies the projection to the state held by a vector. */
+ * pressure.  Several ranks: the labels are GLOBAL line names (the same line carries the same label on every rank
+ * that holds a part of it); the weighted sums are all-reduced, as the reference's planar_avg is a global operation
+ * (exponential_propagator_proj.f90:146-169).  nlg_linop_project applies the projection to the state held by a vector. */
 int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_t *line_label, const int64_t *line_label2,
                              const double *x2);
 int nlg_linop_project(nlg_linop *op, nlg_vec *v);

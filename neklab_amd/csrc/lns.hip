@@ -432,6 +432,81 @@ __global__ __launch_bounds__(NT) void k_proj_alpha(int64_t nlines, const int *__
         for (int c = 0; c < NF; ++c) u.p[c][i] = cv[i] * (ac[c] * id) + sv[i] * (as[c] * id);
     }
 }
+// Several ranks: a line along the homogeneous direction may cross rank boundaries.  The weighted sums of a rank's part of a
+// line go to the line's slot in a global array (one slot per distinct line label over all ranks), the array is all-reduced,
+// and a second kernel applies the projection with the global sums.
+template <int NF>
+__global__ __launch_bounds__(NT) void k_proj_sums(int64_t nlines, const int *__restrict__ off, const int *__restrict__ idx,
+                                                  const int *__restrict__ gslot, const double *__restrict__ bm1,
+                                                  const double *__restrict__ cv, const double *__restrict__ sv, CF3 u,
+                                                  double *__restrict__ glob) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (g >= nlines) return;
+    const int b = off[g], e = off[g + 1];
+    double ac[NF], as[NF];
+#pragma unroll
+    for (int c = 0; c < NF; ++c) ac[c] = as[c] = 0.0;
+    for (int q = b + lane; q < e; q += 64) {
+        const int i = idx[q];
+        const double w = 2.0 * bm1[i], c0 = cv[i], s0 = sv[i];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double v = u.p[c][i];
+            ac[c] += w * v * c0;
+            as[c] += w * v * s0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NF; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ac[c] += __shfl_xor(ac[c], o, 64);
+            as[c] += __shfl_xor(as[c], o, 64);
+        }
+    }
+    if (lane == 0) {
+        double *dst = glob + (int64_t)gslot[g] * (2 * NF);
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            dst[2 * c] = ac[c];
+            dst[2 * c + 1] = as[c];
+        }
+    }
+}
+template <int NF>
+__global__ __launch_bounds__(NT) void k_proj_apply(int64_t nlines, const int *__restrict__ off, const int *__restrict__ idx,
+                                                   const int *__restrict__ gslot, const double *__restrict__ cv,
+                                                   const double *__restrict__ sv, const double *__restrict__ inv_den,
+                                                   const double *__restrict__ glob, F3 u) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (g >= nlines) return;
+    const int b = off[g], e = off[g + 1];
+    const double *src = glob + (int64_t)gslot[g] * (2 * NF);
+    const double id = inv_den[g];
+    for (int q = b + lane; q < e; q += 64) {
+        const int i = idx[q];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) u.p[c][i] = cv[i] * (src[2 * c] * id) + sv[i] * (src[2 * c + 1] * id);
+    }
+}
+// weights of a rank's part of every line into the global slots (set-up: the denominators)
+__global__ __launch_bounds__(NT) void k_proj_wsum(int64_t nlines, const int *__restrict__ off, const int *__restrict__ idx,
+                                                  const int *__restrict__ gslot, const double *__restrict__ w, double *__restrict__ glob) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (g >= nlines) return;
+    double a = 0.0;
+    for (int q = off[g] + lane; q < off[g + 1]; q += 64) a += w[idx[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) glob[gslot[g]] = a;
+}
+__global__ __launch_bounds__(NT) void k_proj_iden(int64_t nlines, const int *__restrict__ gslot, const double *__restrict__ glob, double *__restrict__ iden) {
+    for (int64_t g = blockIdx.x * (int64_t)NT + threadIdx.x; g < nlines; g += (int64_t)gridDim.x * NT) iden[g] = 1.0 / glob[gslot[g]];
+}
+
 __global__ __launch_bounds__(NT) void k_cossin(int64_t n, const double *__restrict__ x, double alpha, double *__restrict__ cv,
                                                double *__restrict__ sv) {
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -580,6 +655,10 @@ struct nlg_linop {
     // wavenumber projection (exptA_proj_linop): lines along the homogeneous direction, cos / sin of alpha x, 1 / sum bm1
     int proj_nlines = 0, proj_nlines2 = 0;     // velocity-mesh lines; pressure-mesh lines (0 = pressure not projected)
     int *proj_off = nullptr, *proj_idx = nullptr, *proj_off2 = nullptr, *proj_idx2 = nullptr;
+    // several ranks: slot of every local line in the global line list, number of global lines, all-reduce buffer
+    int *proj_gslot = nullptr, *proj_gslot2 = nullptr;
+    int64_t proj_nglob = 0, proj_nglob2 = 0;
+    double *proj_glob = nullptr;
     double *proj_cv = nullptr, *proj_sv = nullptr, *proj_iden = nullptr, *proj_cv2 = nullptr, *proj_sv2 = nullptr, *proj_iden2 = nullptr;
     // time-harmonic body force Re(f exp(i s omega t)) of the resolvent integrations (null = none)
     const nlg_vec *force_re = nullptr, *force_im = nullptr;
@@ -1235,6 +1314,45 @@ int project_alpha(nlg_linop *op, int slot = 0) {
     nlg_mesh *m = op->mesh;
     const unsigned grid = (unsigned)((op->proj_nlines + NT / 64 - 1) / (NT / 64));
     F3 u = f3(op->ubuf[slot], m->dim);
+    if (op->proj_gslot) {
+        // several ranks: partial sums -> global slots -> all-reduce -> apply (the reference's planar_avg is a global
+        // operation, exponential_propagator_proj.f90:146-169)
+        hipStream_t st = m->ctx->stream;
+        auto pass = [&](int nf, int64_t nl, const int *off, const int *idx, const int *gs, int64_t nglob, const double *wt,
+                        const double *cv, const double *sv, const double *iden, F3 f) -> int {
+            const unsigned g = (unsigned)((nl + NT / 64 - 1) / (NT / 64));
+            const int64_t cnt = nglob * 2 * nf;
+            NLG_HIP(hipMemsetAsync(op->proj_glob, 0, sizeof(double) * (size_t)cnt, st));
+            CF3 cf = {{f.p[0], f.p[1], f.p[2]}};
+            if (nl > 0) {
+                if (nf == 3)
+                    hipLaunchKernelGGL(k_proj_sums<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                else if (nf == 2)
+                    hipLaunchKernelGGL(k_proj_sums<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                else
+                    hipLaunchKernelGGL(k_proj_sums<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+            }
+            NLG_TRY(allreduce_sum(m->ctx, op->proj_glob, (int)cnt));
+            if (nl > 0) {
+                if (nf == 3)
+                    hipLaunchKernelGGL(k_proj_apply<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                else if (nf == 2)
+                    hipLaunchKernelGGL(k_proj_apply<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                else
+                    hipLaunchKernelGGL(k_proj_apply<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+            }
+            return 0;
+        };
+        NLG_TRY(pass(m->dim, op->proj_nlines, op->proj_off, op->proj_idx, op->proj_gslot, op->proj_nglob, m->d_bm1, op->proj_cv, op->proj_sv,
+                     op->proj_iden, u));
+        if (op->proj_gslot2 && slot == 0) {
+            F3 pp = {{op->p, nullptr, nullptr}};
+            NLG_TRY(pass(1, op->proj_nlines2, op->proj_off2, op->proj_idx2, op->proj_gslot2, op->proj_nglob2, m->d_bm2, op->proj_cv2,
+                         op->proj_sv2, op->proj_iden2, pp));
+        }
+        NLG_HIP(hipGetLastError());
+        return 0;
+    }
     if (m->dim == 3)
         hipLaunchKernelGGL(k_proj_alpha<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
                            (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
@@ -1475,6 +1593,9 @@ int nlg_linop_destroy(nlg_linop *op) {
     if (op->proj_idx) hipFree(op->proj_idx);
     if (op->proj_off2) hipFree(op->proj_off2);
     if (op->proj_idx2) hipFree(op->proj_idx2);
+    if (op->proj_gslot) hipFree(op->proj_gslot);
+    if (op->proj_gslot2) hipFree(op->proj_gslot2);
+    fr(op->proj_glob);
     fr(op->nwv);
     fr(op->nwv_xp);
     fr(op->nwp);
@@ -1631,13 +1752,17 @@ int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_
     NLG_CHECK(op && line_label, "nlg_linop_set_projection: NULL argument");
     nlg_mesh *m = op->mesh;
     NLG_CHECK(idir >= 1 && idir <= m->dim, "nlg_linop_set_projection: idir %d out of range", idir);
-    NLG_CHECK(!m->ctx->distributed(), "nlg_linop_set_projection: lines across ranks are not supported (single rank only)");
     NLG_CHECK(op->inited, "nlg_linop_set_projection: call init first");
     NLG_CHECK((line_label2 == nullptr) == (x2 == nullptr), "nlg_linop_set_projection: pressure-mesh labels and coordinates go together");
     hipStream_t st = m->ctx->stream;
+    int64_t proj_glob_cap = 0;
+    if (op->proj_glob) {
+        hipFree(op->proj_glob);
+        op->proj_glob = nullptr;
+    }
     // one set of lists per mesh: lines = groups of local dofs with the same label, ordered by label then by index
     auto build = [&](int64_t n, const int64_t *lab, const double *d_w, const double *d_x, const double *h_x, int *nl, int **d_off, int **d_idx,
-                     double **d_cv, double **d_sv, double **d_iden) -> int {
+                     double **d_cv, double **d_sv, double **d_iden, int **d_gslot, int64_t *nglob) -> int {
         std::vector<int> order((size_t)n);
         for (int64_t i = 0; i < n; ++i) order[i] = (int)i;
         std::sort(order.begin(), order.end(), [lab](int a, int b) { return lab[a] < lab[b] || (lab[a] == lab[b] && a < b); });
@@ -1679,14 +1804,70 @@ int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_
         NLG_HIP(hipStreamSynchronize(st));
         if (tmp) hipFree(tmp);
         *nl = nlines;
+        if (*d_gslot) hipFree(*d_gslot);
+        *d_gslot = nullptr;
+        *nglob = 0;
+        if (m->ctx->distributed()) {
+            // the labels are global line names: gather every rank's distinct labels, number the union (identically on all
+            // ranks), and sum the weights of the parts of a line over the ranks for the denominators
+            nlg_ctx *ctx = m->ctx;
+            const int nr = ctx->nranks;
+            double *d_cnt = nullptr;
+            NLG_HIP(hipMalloc(&d_cnt, sizeof(double) * (nr + 1)));
+            const double mine = (double)nlines;
+            NLG_HIP(hipMemcpy(d_cnt + nr, &mine, sizeof(double), hipMemcpyHostToDevice));
+            NLG_TRY(allgather_f64(ctx, d_cnt + nr, d_cnt, 1));
+            std::vector<double> cnts(nr);
+            NLG_HIP(hipMemcpyAsync(cnts.data(), d_cnt, sizeof(double) * nr, hipMemcpyDeviceToHost, st));
+            NLG_HIP(hipStreamSynchronize(st));
+            hipFree(d_cnt);
+            int64_t maxc = 1;
+            for (double c : cnts) maxc = std::max<int64_t>(maxc, (int64_t)c);
+            std::vector<int64_t> mylab((size_t)maxc, -1), all((size_t)maxc * nr);
+            for (int g = 0; g < nlines; ++g) mylab[g] = lab[order[off[g]]];
+            int64_t *d_lab = nullptr;
+            NLG_HIP(hipMalloc(&d_lab, sizeof(int64_t) * (size_t)maxc * (nr + 1)));
+            NLG_HIP(hipMemcpy(d_lab + (size_t)maxc * nr, mylab.data(), sizeof(int64_t) * (size_t)maxc, hipMemcpyHostToDevice));
+            NLG_TRY(allgather_f64(ctx, reinterpret_cast<const double *>(d_lab + (size_t)maxc * nr), reinterpret_cast<double *>(d_lab), maxc));
+            NLG_HIP(hipMemcpyAsync(all.data(), d_lab, sizeof(int64_t) * (size_t)maxc * nr, hipMemcpyDeviceToHost, st));
+            NLG_HIP(hipStreamSynchronize(st));
+            hipFree(d_lab);
+            std::vector<int64_t> uni;
+            for (int q = 0; q < nr; ++q)
+                for (int64_t g = 0; g < (int64_t)cnts[q]; ++g) uni.push_back(all[(size_t)q * maxc + g]);
+            std::sort(uni.begin(), uni.end());
+            uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+            std::vector<int> gs((size_t)std::max(nlines, 1));
+            for (int g = 0; g < nlines; ++g) gs[g] = (int)(std::lower_bound(uni.begin(), uni.end(), mylab[g]) - uni.begin());
+            NLG_HIP(hipMalloc(d_gslot, sizeof(int) * gs.size()));
+            NLG_HIP(hipMemcpy(*d_gslot, gs.data(), sizeof(int) * gs.size(), hipMemcpyHostToDevice));
+            *nglob = (int64_t)uni.size();
+            const int64_t need = *nglob * 2 * 3;
+            if (need > proj_glob_cap) {
+                if (op->proj_glob) hipFree(op->proj_glob);
+                NLG_HIP(hipMalloc(&op->proj_glob, sizeof(double) * (size_t)need));
+                proj_glob_cap = need;
+            }
+            NLG_HIP(hipMemsetAsync(op->proj_glob, 0, sizeof(double) * (size_t)*nglob, st));
+            const unsigned g1 = (unsigned)((nlines + NT / 64 - 1) / (NT / 64));
+            if (nlines > 0)
+                hipLaunchKernelGGL(k_proj_wsum, dim3(g1), dim3(NT), 0, st, (int64_t)nlines, (const int *)*d_off, (const int *)*d_idx,
+                                   (const int *)*d_gslot, d_w, op->proj_glob);
+            NLG_TRY(allreduce_sum(ctx, op->proj_glob, (int)*nglob));
+            if (nlines > 0)
+                hipLaunchKernelGGL(k_proj_iden, dim3(grid_for(nlines)), dim3(NT), 0, st, (int64_t)nlines, (const int *)*d_gslot,
+                                   (const double *)op->proj_glob, *d_iden);
+            NLG_HIP(hipGetLastError());
+            NLG_HIP(hipStreamSynchronize(st));
+        }
         return 0;
     };
     NLG_TRY(build(m->lvn, line_label, m->d_bm1, m->d_x[idir - 1], nullptr, &op->proj_nlines, &op->proj_off, &op->proj_idx, &op->proj_cv,
-                  &op->proj_sv, &op->proj_iden));
+                  &op->proj_sv, &op->proj_iden, &op->proj_gslot, &op->proj_nglob));
     op->proj_nlines2 = 0;
     if (line_label2)
         NLG_TRY(build(m->lpn, line_label2, m->d_bm2, nullptr, x2, &op->proj_nlines2, &op->proj_off2, &op->proj_idx2, &op->proj_cv2,
-                      &op->proj_sv2, &op->proj_iden2));
+                      &op->proj_sv2, &op->proj_iden2, &op->proj_gslot2, &op->proj_nglob2));
     return 0;
 }
 

@@ -67,10 +67,10 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
 // The same transform in place: a lane reads its whole column into registers before it writes the outputs, and the
 // columns of one stage are disjoint, so one LDS array serves as input and output (half the LDS per element -> twice
 // the resident elements per CU for a kernel that mostly waits).
-template <int N2, bool FWD, int AX>
+template <int N2, bool FWD, int AX, int ST = 64>
 __device__ __forceinline__ void fdm_stage_inplace3(double *buf, const double *__restrict__ S, int lane) {
     constexpr int NCOL = N2 * N2;
-    for (int col = lane; col < NCOL; col += 64) {
+    for (int col = lane; col < NCOL; col += ST) {
         int base, stride;
         if (AX == 0) {
             base = col * N2;
@@ -233,8 +233,10 @@ __device__ __forceinline__ int ext_slot(int N, int a, int b, int c) { return fg_
 
 // WPB waves (= elements) per block.  WPB = 1 makes every __syncthreads a single-wave barrier: the stages of one element
 // never wait for another element's.
-template <int N, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
+// WPE > 1 (with WPB = 1): WPE waves share ONE element -- for lx1 > 8 a single wave has to sweep N N = 100 (144) columns
+// with 64 lanes in two (three) rounds, 56 % (75 %) of them busy; two (three) waves take one column per lane.
+template <int N, int WPB, int WPE = 1>
+__global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                 const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                 const double *__restrict__ wq, double *__restrict__ W,
                                                 double *__restrict__ z, const int *__restrict__ tab) {
@@ -242,7 +244,9 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
     __shared__ double sL[WPB][3][N];
     __shared__ double sA[WPB][NP];   // the six transforms run in place (fdm_stage_inplace3)
     if (flag && flag[0] != 0.0) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    static_assert(WPB == 1 || WPE == 1, "either several elements per block or several waves per element");
+    constexpr int ST = 64 * WPE;                                   // threads that share one element
+    const int lane = WPE > 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63), wv = WPE > 1 ? 0 : (int)(threadIdx.x >> 6);
     const int64_t e = (int64_t)blockIdx.x * WPB + wv;
     const bool act = e < E;
     const int64_t ee = act ? e : 0;
@@ -250,21 +254,21 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
     // scalar loads straight into FMA operands instead of 384 broadcast LDS reads per lane
     const int eu = __builtin_amdgcn_readfirstlane((int)ee);
     const double *__restrict__ Sg = S + (int64_t)eu * (3 * N * N);
-    for (int q = lane; q < 3 * N; q += 64) sL[wv][q / N][q % N] = lam[ee * (3 * N) + q];
+    for (int q = lane; q < 3 * N; q += ST) sL[wv][q / N][q % N] = lam[ee * (3 * N) + q];
     const double *re = r + ee * NP2;
     double *We = W + ee * NP;
     // packed per-point constants (pprec_setup): bits 0-1 boundary directions, 2-12 exchange slot, 13-22 pressure point,
     // 23-28 ghost-neighbour flags; kept in registers for the store phase
-    constexpr int NQL = (NP + 63) / 64;
+    constexpr int NQL = (NP + ST - 1) / ST;
     int te[NQL];
 #pragma unroll
     for (int u = 0; u < NQL; ++u) {
-        const int q = lane + 64 * u;
+        const int q = lane + ST * u;
         te[u] = q < NP ? tab[q] : 3;
     }
 #pragma unroll
     for (int u = 0; u < NQL; ++u) {
-        const int q = lane + 64 * u;
+        const int q = lane + ST * u;
         if (q >= NP) break;
         const int nb = te[u] & 3;
         double v = 0.0;
@@ -276,27 +280,27 @@ __global__ __launch_bounds__(64 * WPB) void k_fdm_ext(const double *__restrict__
         sA[wv][q] = v;
     }
     __syncthreads();
-    fdm_stage_inplace3<N, true, 0>(sA[wv], Sg + 0 * N * N, lane);
+    fdm_stage_inplace3<N, true, 0, ST>(sA[wv], Sg + 0 * N * N, lane);
     __syncthreads();
-    fdm_stage_inplace3<N, true, 1>(sA[wv], Sg + 1 * N * N, lane);
+    fdm_stage_inplace3<N, true, 1, ST>(sA[wv], Sg + 1 * N * N, lane);
     __syncthreads();
-    fdm_stage_inplace3<N, true, 2>(sA[wv], Sg + 2 * N * N, lane);
+    fdm_stage_inplace3<N, true, 2, ST>(sA[wv], Sg + 2 * N * N, lane);
     __syncthreads();
-    for (int q = lane; q < NP; q += 64) {
+    for (int q = lane; q < NP; q += ST) {
         const double den = sL[wv][0][q % N] + sL[wv][1][(q / N) % N] + sL[wv][2][q / (N * N)];
         sA[wv][q] = den > thr ? sA[wv][q] / den : 0.0;
     }
     __syncthreads();
-    fdm_stage_inplace3<N, false, 2>(sA[wv], Sg + 2 * N * N, lane);
+    fdm_stage_inplace3<N, false, 2, ST>(sA[wv], Sg + 2 * N * N, lane);
     __syncthreads();
-    fdm_stage_inplace3<N, false, 1>(sA[wv], Sg + 1 * N * N, lane);
+    fdm_stage_inplace3<N, false, 1, ST>(sA[wv], Sg + 1 * N * N, lane);
     __syncthreads();
-    fdm_stage_inplace3<N, false, 0>(sA[wv], Sg + 0 * N * N, lane);
+    fdm_stage_inplace3<N, false, 0, ST>(sA[wv], Sg + 0 * N * N, lane);
     __syncthreads();
     if (act) {
 #pragma unroll
         for (int u = 0; u < NQL; ++u) {
-            const int q = lane + 64 * u;
+            const int q = lane + ST * u;
             if (q >= NP) break;
             const int nb = te[u] & 3;
             if (nb == 1) {
@@ -1626,9 +1630,10 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
         NLG_TRY(overlap_halo(m, st, true));
 #define FX_CASE(N_)                                                                                                   \
-    case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_fdm_ext<N_, 1>), dim3((unsigned)E), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab); \
-        break;
+    case N_: {                                                                                                        \
+        constexpr int WPE_ = (N_ * N_ + 63) / 64;   /* one column per lane: 1 wave up to lx1 = 8, 2 at 9 / 10, 3 at 12 */ \
+        hipLaunchKernelGGL((k_fdm_ext<N_, 1, WPE_>), dim3((unsigned)E), dim3(64 * WPE_), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab); \
+    } break;
         switch (m->n) {
             FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(12)
             default: set_error("pprec: overlapping variant built for lx1 = 4..10 and 12, got %d", m->n); return 1;

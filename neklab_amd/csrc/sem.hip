@@ -685,6 +685,114 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     }
 }
 
+// Register-column variant for N > 8: one block of ceil(N N / 64) waves per (element, field); thread (i, j) keeps its
+// k-column of u and of w in registers as in k_axhelm3r, the three N x N slabs are shared by the block's waves, so the two
+// hand-overs per slab are block barriers (two or three waves: cheap) instead of the wave-level LDS ordering.  Row k of D
+// comes from LDS at a block-uniform address (broadcast).  Replaces the LDS-cube kernel k_axhelm3, which ran at 25 % of
+// the HBM roofline at lx1 = 10 (452 us for 912 MB at 6000 elements) against 58 % for k_axhelm3r at lx1 = 8.
+template <int N>
+__global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E, int nf, const double *__restrict__ Dg,
+                                                                        const double *__restrict__ G0, const double *__restrict__ G1,
+                                                                        const double *__restrict__ G2, const double *__restrict__ G3,
+                                                                        const double *__restrict__ G4, const double *__restrict__ G5,
+                                                                        const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
+                                                                        double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
+                                                                        const double *__restrict__ done_p) {
+    constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((NS + 63) / 64) * 64, NWB = NTB / 64;
+    __shared__ double sD[NS];
+    __shared__ double mU[N * NQ], mR[N * NQ], mS[N * NQ];
+    __shared__ double sred[NWB];
+    if (done_p && done_p[0] != 0.0) return;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < NS; p += NTB) sD[p] = Dg[p];
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x / nf;
+    const int c = (int)((int64_t)blockIdx.x % nf);
+    const bool act = tid < NS;
+    const int ij = act ? tid : 0;
+    const int i = ij % N, j = ij / N;
+    const int64_t eoff = e * NP;
+    const double *uc = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2])) + eoff;
+    double *wc = (c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2])) + eoff;
+    const double *zc = (c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2])) + eoff;
+    G0 += eoff, G1 += eoff, G2 += eoff, G3 += eoff, G4 += eoff, G5 += eoff, bm1 += eoff;
+    const bool upd = beta_p != nullptr && done_p[0] == 0.0;
+    const double beta = upd ? beta_p[0] : 0.0;
+    double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double v = act ? uc[ij + k * NS] : 0.0;
+        if (upd && act) {
+            v = zc[ij + k * NS] + beta * v;
+            const_cast<double *>(uc)[ij + k * NS] = v;
+        }
+        uk[k] = v;
+        wk[k] = 0.0;
+    }
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        di[l] = sD[i * N + l];
+        dj[l] = sD[j * N + l];
+        dti[l] = sD[l * N + i];
+        dtj[l] = sD[l * N + j];
+    }
+    double gn[7];
+    gn[0] = G0[ij], gn[1] = G1[ij], gn[2] = G2[ij], gn[3] = G3[ij], gn[4] = G4[ij], gn[5] = G5[ij], gn[6] = bm1[ij];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3], g4 = gn[4], g5 = gn[5], bm = gn[6];
+        if (k + 1 < N) {
+            const int q = ij + (k + 1) * NS;
+            gn[0] = G0[q], gn[1] = G1[q], gn[2] = G2[q], gn[3] = G3[q], gn[4] = G4[q], gn[5] = G5[q], gn[6] = bm1[q];
+        }
+        if (act) mU[i + NQ * j] = uk[k];
+        __syncthreads();
+        double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            ur += di[l] * mU[l + NQ * j];
+            us += dj[l] * mU[i + NQ * l];
+            ut += sD[k * N + l] * uk[l];
+        }
+        const double gr = h1 * (g0 * ur + g1 * us + g2 * ut);
+        const double gs = h1 * (g1 * ur + g3 * us + g4 * ut);
+        const double gt = h1 * (g2 * ur + g4 * us + g5 * ut);
+        if (act) {
+            mR[i + NQ * j] = gr;
+            mS[i + NQ * j] = gs;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < N; ++l) wk[l] += sD[k * N + l] * gt;
+        double a = h2 * bm * uk[k];
+#pragma unroll
+        for (int l = 0; l < N; ++l) a += dti[l] * mR[l + NQ * j] + dtj[l] * mS[i + NQ * l];
+        wk[k] += a;
+#pragma unroll
+        for (int l = 0; l < N; ++l) asm volatile("" : "+v"(wk[l]));   // see k_axhelm3r: keeps the sums from sinking
+        asm volatile("" ::: "memory");
+    }
+    double pw = 0.0;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            wc[ij + k * NS] = wk[k];
+            pw += wk[k] * uk[k];
+        }
+    }
+    if (pw_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+        if ((tid & 63) == 0) sred[tid >> 6] = pw;
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0;
+            for (int q = 0; q < NWB; ++q) a += sred[q];
+            pw_part[blockIdx.x] = a;
+        }
+    }
+}
+
 // 2-D: one thread per point.
 template <int N, int NF>
 __global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) void k_axhelm2(
@@ -834,12 +942,21 @@ struct PMats {
     double Dm[(N - 2) * N];   // D12
 };
 
+// Block size of the two pressure-mesh kernels: with all three velocity components in flight (NC = 3, lx1 <= 8) the stages
+// keep 144 - 216 of 256 threads busy; with one component at a time (NC = 1, lx1 > 8: the LDS budget) only 64 - 128 of them
+// have work, so those instantiations run with 128 threads per block (and twice the blocks per CU).
+template <int N, int NC>
+struct PBlock {
+    static constexpr int NTB = (NC == 1 && N > 8) ? 128 : 256;
+};
+
 // opgradt: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise)
 template <int N, int NC, bool FG>
-__global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w,
+__global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w,
                                                  const double *__restrict__ gate) {
     if (gate && gate[0] != 0.0) return;   // the surrounding PCG has converged (device-side done flag)
     constexpr int N2 = N - 2, NS2 = N2 * N2;
+    constexpr int NT = PBlock<N, NC>::NTB;   // (shadows the file-level block size: 128 threads when one component is in flight)
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SA = N2 * N2 * N, SB = N2 * N * N;
     __shared__ double sA[NC * 3][SA];
@@ -932,11 +1049,12 @@ __global__ __launch_bounds__(NT) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, c
 // `pdot`/`part` (may be null): first-stage sums of the surrounding PCG, part[e] = sum_q pdot_q out_q and
 // part[E + e] = sum_q out_q over the element -- saves a separate pass over two pressure-mesh vectors.
 template <int N, int NC, bool FG>
-__global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
+__global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
                                                double scale, const double *__restrict__ pdot, double *__restrict__ part,
                                                const double *__restrict__ gate) {
     if (gate && gate[0] != 0.0) return;
     constexpr int N2 = N - 2, NS2 = N2 * N2;
+    constexpr int NT = PBlock<N, NC>::NTB;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
     constexpr int SB = N2 * N * N, SC = N2 * N2 * N;
     constexpr int SBTOT = NC * 2 * SB, SPTOT = NC * 3 * NP2;
@@ -1075,8 +1193,13 @@ __global__ __launch_bounds__(NT) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3
         }
         __syncthreads();
         if (tid == 0) {
-            part[e] = red[0] + red[1] + red[2] + red[3];
-            part[E + e] = red[4] + red[5] + red[6] + red[7];
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < NT / 64; ++q) {
+                a += red[q];
+                b += red[4 + q];
+            }
+            part[e] = a;
+            part[E + e] = b;
         }
     }
 }
@@ -1268,8 +1391,12 @@ __global__ void k_conv_combine_adj(int dim, int64_t n, CF3 Ur, CF3 du, double *a
 // entry a wave needs has a wave-uniform address -> scalar loads straight into FMA operands (two 96-entry matrices
 // do not fit the scalar register file as kernel arguments: 366 spilled SGPRs and 2 ms per launch at E = 10k).
 // LDS leading dimensions are padded to odd values where a thread walks a row.
-template <int N, int ND>
-__global__ __launch_bounds__(NT, 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
+// lx1 > 8: the LDS arrays exceed the 64 KB a kernel may declare statically, so they are carved out of dynamic LDS (up to
+// 160 KB per workgroup on gfx950: one block per CU): lx1 = 9, 10 keep u in LDS as before (104 KB at lx1 = 10); at lx1 = 12
+// (ULDS = false) the stage arrays alone take 134 KB and the x stages read u from global memory (41 KB per element, L2).
+// NTC threads: one per fine-mesh column along z (ND^2 = 324 at lx1 = 12 -> 384 threads).
+template <int N, int ND, int NTC, bool ULDS, bool DYN>
+__global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
                                                  CF3 Ur, CF9 GU, CF3 u, F3 out, int adjoint) {
     constexpr int NP = N * N * N, NPD = ND * ND * ND;
     constexpr int NQ = N | 1, NDQ = ND | 1;          // padded (odd) leading dimensions
@@ -1277,19 +1404,24 @@ __global__ __launch_bounds__(NT, 2) void k_conv3(int64_t E, const double *__rest
     constexpr int SX = NDQ * N * N;                  // after the x stage: (a | j, k), row stride NDQ
     constexpr int SY = ND * ND * N;                  // after the y stage: (a, b, k)
     constexpr int NCOLZ = ND * ND;                   // fine columns along z
+    constexpr int NT = NTC;                          // (shadows the file-level block size inside this kernel)
     constexpr int NW = NT / 64;
     static_assert(NCOLZ <= NT, "one thread per fine-mesh column");
-    __shared__ double sU[3][SU];
-    __shared__ double sW[2 * SX + 3 * SY];
+    extern __shared__ double conv_dyn[];
+    __shared__ double sU_st[DYN ? 1 : 3 * SU];
+    __shared__ double sW_st[DYN ? 1 : 2 * SX + 3 * SY];
+    double *sW = DYN ? conv_dyn : sW_st;
+    double(*sU)[SU] = reinterpret_cast<double(*)[SU]>(DYN ? conv_dyn + 2 * SX + 3 * SY : sU_st);
     double *sA = sW, *sB = sW + SX, *sAA = sW + 2 * SX, *sAD = sAA + SY, *sBA = sAD + SY;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t e = blockIdx.x;
     if (e >= E) return;
-    for (int t = tid; t < 3 * NP; t += NT) {
-        const int c = t / NP, q = t % NP;
-        sU[c][(q % N) + NQ * (q / N)] = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]))[e * NP + q];
-    }
+    if (ULDS)
+        for (int t = tid; t < 3 * NP; t += NT) {
+            const int c = t / NP, q = t % NP;
+            sU[c][(q % N) + NQ * (q / N)] = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]))[e * NP + q];
+        }
     double ufr[3][ND];
     constexpr int OD = (ND + NW - 1) / NW;   // fine-index outputs per wave
     constexpr int ON = (N + NW - 1) / NW;    // coarse-index outputs per wave
@@ -1300,7 +1432,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3(int64_t E, const double *__rest
         for (int col = lane; col < N * N; col += 64) {
             double v[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = sU[mcomp][i + NQ * col];
+            for (int i = 0; i < N; ++i) v[i] = ULDS ? sU[mcomp][i + NQ * col] : (mcomp == 0 ? u.p[0] : (mcomp == 1 ? u.p[1] : u.p[2]))[e * NP + i + N * col];
 #pragma unroll
             for (int o = 0; o < OD; ++o) {
                 const int a = wave + NW * o;
@@ -1354,7 +1486,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3(int64_t E, const double *__rest
         for (int col = lane; col < N * N; col += 64) {
             double v[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = sU[ic][i + NQ * col];
+            for (int i = 0; i < N; ++i) v[i] = ULDS ? sU[ic][i + NQ * col] : (ic == 0 ? u.p[0] : (ic == 1 ? u.p[1] : u.p[2]))[e * NP + i + N * col];
 #pragma unroll
             for (int o = 0; o < OD; ++o) {
                 const int a = wave + NW * o;
@@ -1852,6 +1984,8 @@ int sem_axhelm_blocks(nlg_mesh *m, int nf) {
         const int epb = NT / (m->n * m->n) > 0 ? NT / (m->n * m->n) : 1;
         return (int)((m->E + epb - 1) / epb);
     }
+    static const bool use_cube = getenv("NLG_AXHELM_CUBE") && atoi(getenv("NLG_AXHELM_CUBE")) != 0;
+    if (m->n > 8 && !use_cube) return (int)(m->E * nf);   // k_axhelm3c: one block per (element, field)
     const int nslot = axhelm3_nslot(m->n);
     return (int)((m->E * nf + nslot - 1) / nslot);
 }
@@ -1866,6 +2000,7 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
     hipStream_t s = m->ctx->stream;
     NLG_CHECK(!beta_p || (zf && done_p), "sem_axhelm: the fused direction update needs zf and the done flag");
     CF3 cz = {{zf ? zf[0] : nullptr, (zf && nf > 1) ? zf[1] : nullptr, (zf && nf > 2) ? zf[2] : nullptr}};
+    static const bool use_cube = getenv("NLG_AXHELM_CUBE") && atoi(getenv("NLG_AXHELM_CUBE")) != 0;   // the LDS-cube kernel (lx1 > 8), for A/B runs
     if (m->dim == 3) {
 #define AX3(N_)                                                                                                       \
     {                                                                                                                 \
@@ -1880,8 +2015,11 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
             else                                                                                                      \
             hipLaunchKernelGGL((k_axhelm3r<N_, 4, false>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
                                m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr); \
-        } else                                                                                                          \
+        } else if (use_cube)                                                                                          \
         hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+        else                                                                                                          \
+        hipLaunchKernelGGL((k_axhelm3c<N_>), dim3((unsigned)tot), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
                            m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
     }
         NLG_FOR_N(AX3)
@@ -1949,9 +2087,9 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
         else if (N_ <= 8)                                                                                              \
             hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);   \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, p, cw, gate);    \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, p, cw, gate);   \
     }
         NLG_FOR_N(GT3)
 #undef GT3
@@ -1993,9 +2131,9 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
         else if (N_ <= 8)                                                                                              \
             hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
     }
         NLG_FOR_N(DV3)
 #undef DV3
@@ -2210,23 +2348,40 @@ int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, dou
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
     ProfScope ps(m->ctx, P_CONV);
     const int dim = m->dim;
-    if (dim == 3 && m->n <= 8 && m->nd == (3 * m->n) / 2) {
-        // fused kernel (LDS budget: lx1 <= 8 with the standard 3/2 dealiasing mesh)
+    if (dim == 3 && (m->n <= 10 || m->n == 12) && m->nd == (3 * m->n) / 2) {
+        // fused kernel: static LDS up to lx1 = 8, dynamic LDS (one block per CU) for lx1 = 9, 10, 12
         CF3 cur = {{Ur[0], Ur[1], Ur[2]}}, cu = {{u[0], u[1], u[2]}};
         CF9 cg;
         for (int q = 0; q < 9; ++q) cg.p[q] = GU[q];
         F3 co = {{out[0], out[1], out[2]}};
 #define CV3(N_)                                                                                                       \
-    hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E,           \
+    hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
                        (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, adjoint);
+#define CV3D(N_, NTC_, ULDS_)                                                                                          \
+    {                                                                                                                  \
+        constexpr int ND_ = (3 * N_) / 2, NQ_ = N_ | 1, NDQ_ = ND_ | 1;                                                \
+        constexpr size_t lds = sizeof(double) * (2 * NDQ_ * N_ * N_ + 3 * ND_ * ND_ * N_ + (ULDS_ ? 3 * NQ_ * N_ * N_ : 0)); \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            NLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3<N_, ND_, NTC_, ULDS_, true>),          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_conv3<N_, ND_, NTC_, ULDS_, true>), dim3((unsigned)m->E), dim3(NTC_), lds, m->ctx->stream, m->E, \
+                           (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, adjoint);              \
+    }
         switch (m->n) {
             case 4: CV3(4); break;
             case 5: CV3(5); break;
             case 6: CV3(6); break;
             case 7: CV3(7); break;
-            default: CV3(8); break;
+            case 8: CV3(8); break;
+            case 9: CV3D(9, 256, true); break;
+            case 10: CV3D(10, 256, true); break;
+            default: CV3D(12, 384, false); break;
         }
 #undef CV3
+#undef CV3D
         NLG_HIP(hipGetLastError());
         return 0;
     }

@@ -100,7 +100,54 @@ def run_heat(rank, world, segment, outdir, case):
     ctx.sync()
 
 
+def run_proj(rank, world, segment, outdir, case):
+    """Wavenumber-projected propagator with the homogeneous direction ACROSS the rank boundaries: the lines of the planar
+    averages (exponential_propagator_proj.f90:146-169) have parts on every rank; labels are global line names."""
+    _, _, mult = case.partition("@")
+    nel, n = (2, 2, 2 * int(mult or 1)), 6
+    ctx = host.Context(0)
+    if world > 1:
+        ctx.comm_init_shm(rank, world, segment)
+    gnel = (nel[0], nel[1], nel[2] * world)
+    Lz = 2.0 * np.pi
+    hm = box_mesh(gnel, n, lengths=(2.0, 2.0, Lz), periodic=(True, False, True), deform=0.0,
+                  last_range=(rank * nel[2], (rank + 1) * nel[2]))
+    gm = host.Mesh(ctx, hm)
+    bf = host.nek_dvector(gm)
+    bf.set_field(0, hm.mask[0] * (hm.y * (2.0 - hm.y)))
+    A = host.exptA_linop(0.03, bf, re=40.0, dt=0.01, vtol=1e-13, ptol=1e-13, maxit_p=2000)
+    A.init()
+
+    def name(*coords):      # a global name for the line through a point: its coordinates across the line, hashed
+        k = [np.round(np.asarray(c).ravel() / 1e-7).astype(np.int64) for c in coords]
+        return np.ascontiguousarray(k[0] * 40000003 + k[1], dtype=np.int64)
+
+    X2 = host.pressure_mesh_coords(gm)
+    lab, lab2, z2 = name(hm.x, hm.y), name(X2[0], X2[1]), np.ascontiguousarray(X2[2], dtype=np.float64)
+    from neklab_amd import _lib
+    host.check(gm.lib.nlg_linop_set_projection(A.h, 1.0, 3, lab.ctypes.data_as(_lib.c_int64_p), lab2.ctypes.data_as(_lib.c_int64_p),
+                                                z2.ctypes.data_as(_lib.c_double_p)))
+    v, pv, out = host.nek_dvector(gm), host.nek_dvector(gm), host.nek_dvector(gm)
+    v.rand(True, seed=21)
+    v.set_field(host.PR, np.cos(X2[2]) * X2[1])
+    pv.assign(v)
+    host.check(gm.lib.nlg_linop_project(A.h, pv.h))
+    A.matvec(v, out)
+    fields = {"scal": np.array([v.norm(), pv.norm(), out.norm(), out.dot(pv)]), "H": np.zeros((2, 1)),
+              "stats": np.array([A.stats()["p_iters"], A.stats()["v_iters"]], dtype=float)}
+    for i in range(3):
+        fields["out%d" % i] = out.get_field(i)
+        fields["outT%d" % i] = pv.get_field(i)
+        fields["v%d" % i] = v.get_field(i)
+    fields["outp"] = out.get_field(host.PR)
+    fields["outq"] = pv.get_field(host.PR)
+    np.savez(os.path.join(outdir, "%s_w%d_r%d.npz" % (case, world, rank)), **fields)
+    ctx.sync()
+
+
 def run(rank, world, segment, outdir, case):
+    if case.startswith("proj"):
+        return run_proj(rank, world, segment, outdir, case)
     if case.startswith("heat"):
         return run_heat(rank, world, segment, outdir, case)
     if case.startswith("cyl"):
