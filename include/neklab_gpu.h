@@ -233,6 +233,14 @@ int nlg_linop_init(nlg_linop *op);
 int nlg_linop_matvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
 /* exptA_rmatvec exponential_propagator.f90:62-107  (interface neklab_linops.f90:58-62) */
 int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
+/* s <= 4 vectors through the propagator TOGETHER (vec_out[v] = exp(tau L) vec_in[v], transpose != 0: the adjoint), time
+ * step by time step: what Nek5000 does with npert > 1 perturbations (src/neklab_nek_setup.f90:39-247, src/neklab_otd.f90:
+ * 37-49).  The s velocity solves and the s pressure solves run as independent PCGs in lockstep (own scalars and
+ * convergence flag per vector: every vector gets exactly the iteration of nlg_linop_matvec), with the operator
+ * applications of an iteration issued together, so that metric factors, base-flow fields of the convective term and
+ * preconditioner data are read once per iteration for all vectors.  Each vector keeps its restart-history protocol
+ * (replay of vec_in's history, history of vec_out).  Not with cfg.ifheat or a wavenumber projection. */
+int nlg_linop_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vec_in, nlg_vec *const *vec_out, int transpose);
 /* Newton-Krylov base-flow solver.
  * nonlinear_map  src/systems/fixed_point.f90:4-38 : vec_out = Phi_tau(vec_in) - vec_in with the nonlinear integrator,
  *   time step from the CFL number of vec_in (cfg.cfl_limit; the reference uses 0.4), tolerances cfg.vtol / cfg.ptol.

@@ -79,6 +79,7 @@ SIGNATURES = {
     "nlg_vec_rand_noise": (C.c_int, [vp, C.c_uint64]),
     "nlg_vec_size_value": (C.c_int64, [vp]),
     "nlg_basis_block_cgs2": (C.c_int, [vp, C.c_int, C.c_int, c_double_p]),
+    "nlg_linop_matvec_block": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int]),
     "nlg_block_arnoldi_step": (C.c_int, [vp, vp, C.c_int, C.c_int, c_double_p, C.c_int, C.c_int]),
     "nlg_vec_outpost": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_double, C.c_int]),
     "nlg_vec_rand_finish": (C.c_int, [vp, C.c_int]),

@@ -346,6 +346,9 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
                double *rz_part = nullptr, bool overlap = false);
 void pprec_free(nlg_mesh *m);
 
+// ---- lns.hip
+bool linop_can_block(const nlg_linop *op);   // the multi-vector stepper covers this operator (no Boussinesq coupling / projection)
+
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);
 int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout = 0);   // LAYOUT_*

@@ -170,9 +170,17 @@ int nlg_block_arnoldi_step(nlg_linop *op, nlg_basis *basis, int k, int s, double
     NLG_CHECK(k >= 0 && k + 2 * s <= basis->nvec, "nlg_block_arnoldi_step: k=%d, s=%d need basis columns up to %d (nvec=%d)", k, s,
               k + 2 * s - 1, basis->nvec);
     NLG_CHECK(ldh >= k + 2 * s, "nlg_block_arnoldi_step: ldh=%d too small for k=%d, s=%d", ldh, k, s);
-    for (int v = 0; v < s; ++v) {
-        nlg_vec *vin = basis->views[k + v], *w = basis->views[k + s + v];
-        NLG_TRY(transpose ? nlg_linop_rmatvec(op, vin, w) : nlg_linop_matvec(op, vin, w));
+    static const bool lockstep = !(getenv("NLG_BLOCK_MATVEC") && atoi(getenv("NLG_BLOCK_MATVEC")) == 0);
+    if (s > 1 && lockstep && linop_can_block(op)) {   // the s vectors advance together (shared operator data per iteration)
+        const nlg_vec *vi[4];
+        nlg_vec *vo[4];
+        for (int v = 0; v < s; ++v) vi[v] = basis->views[k + v], vo[v] = basis->views[k + s + v];
+        NLG_TRY(nlg_linop_matvec_block(op, s, vi, vo, transpose));
+    } else {
+        for (int v = 0; v < s; ++v) {
+            nlg_vec *vin = basis->views[k + v], *w = basis->views[k + s + v];
+            NLG_TRY(transpose ? nlg_linop_rmatvec(op, vin, w) : nlg_linop_matvec(op, vin, w));
+        }
     }
     const int kk = k + s;
     std::vector<double> coef((size_t)(kk + s) * s);

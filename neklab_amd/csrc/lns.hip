@@ -652,6 +652,12 @@ struct nlg_linop {
     double *d_part = nullptr;  // first-stage sums written by opdiv ([2][E]) and by the FDM kernel ([2][E/4])
     double *h_s = nullptr;     // pinned
     int istep = 0, adjoint = 0;
+    // block stepper: lanes 1 .. 3 (created on first use by the operator that owns them); a lane shares the base-flow data
+    // of its owner and must never free it
+    nlg_linop *lanes[3] = {nullptr, nullptr, nullptr};
+    bool is_lane = false;
+    int adv_k = 1;             // state handed from one phase of a time step to the next (adv_a / adv_b / adv_c)
+    double adv_b0 = 1.0, adv_h2 = 0.0;
     // wavenumber projection (exptA_proj_linop): lines along the homogeneous direction, cos / sin of alpha x, 1 / sum bm1
     int proj_nlines = 0, proj_nlines2 = 0;     // velocity-mesh lines; pressure-mesh lines (0 = pressure not projected)
     int *proj_off = nullptr, *proj_idx = nullptr, *proj_off2 = nullptr, *proj_idx2 = nullptr;
@@ -897,14 +903,25 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     return 0;
 }
 
-int helm_solve(nlg_linop *op, int order, double h2) {
+// The velocity solve in three pieces, so that the single-vector path and the block (multi-vector) stepper share them:
+// problem set-up, one operator application, bookkeeping afterwards.
+struct HelmSolve {
+    CGProblem P;
+    bool xp = false;
+    double nu = 0.0, h2 = 0.0;
+    double *pw_part = nullptr;
+};
+
+int helm_problem(nlg_linop *op, int order, double h2, HelmSolve &H) {
     nlg_mesh *m = op->mesh;
     const int dim = m->dim;
     const auto &c = op->cfg;
-    CGProblem P;
+    CGProblem &P = H.P;
     // x-planes-first layout for every vector of the iteration: the right-hand side is permuted on the way in (into gp,
     // free at this point), the solution on the way out (into rhs, which the caller reads as the increment)
     const bool xp = op->use_xp > 0;
+    H.xp = xp;
+    H.h2 = h2;
     if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim));
     P.nf = dim;
     P.n = m->lvn;
@@ -927,38 +944,52 @@ int helm_solve(nlg_linop *op, int order, double h2) {
         const int pred = (op->istep < (int)op->vit_hist.size() && op->vit_hist[op->istep] > 0) ? op->vit_hist[op->istep] : op->last_viters;
         P.chunk = std::max(2, std::min(pred, 64));
     }
-    const double nu = 1.0 / c.re;
+    H.nu = 1.0 / c.re;
     // w = QQ^T (nu A + h2 B) p.  The Dirichlet mask is not applied to w: p is masked (z = pc r with pc = mask/diag), so
     // (p, w) does not see the masked entries, and k_cg_update zeroes the residual where pc == 0.
     // 3-D: (p, w) = sum over the local dofs of p . w_local (p is continuous), summed inside the operator kernel.
-    double *pw_part = op->d_part;   // both the 2-D and the 3-D operator kernels sum (p, w) and update p themselves
-    if (pw_part) {
-        P.pw_part = pw_part;
+    H.pw_part = op->d_part;   // both the 2-D and the 3-D operator kernels sum (p, w) and update p themselves
+    if (H.pw_part) {
+        P.pw_part = H.pw_part;
         P.pw_n = sem_axhelm_blocks(m, dim);
         P.pw_sum = false;
         P.fused_pupdate = true;   // 3-D: p <- z + beta p happens while the operator kernel loads p
     }
-    auto apply = [&](double *) -> int {
-        if (pw_part)
-            NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, xp));
-        else
-            NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, nu, h2, pw_part));
-        NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE, xp ? LAYOUT_XP : LAYOUT_NAT));
-        return 0;
-    };
     {
         char tb[96];
-        snprintf(tb, sizeof(tb), "helm|%a|%a|%d|%d", nu, h2, pw_part ? 1 : 0, xp ? 1 : 0);
+        snprintf(tb, sizeof(tb), "helm|%a|%a|%d|%d", H.nu, h2, H.pw_part ? 1 : 0, xp ? 1 : 0);
         P.tag = tb;
     }
-    int iters = 0;
-    NLG_TRY(run_pcg(op, P, apply, &iters));
-    if (xp) NLG_TRY(sem_from_xp(m, op->x, op->rhs, dim));   // the increment, natural layout
+    return 0;
+}
+
+int helm_apply(nlg_linop *op, const HelmSolve &H) {
+    nlg_mesh *m = op->mesh;
+    const int dim = m->dim;
+    if (H.pw_part)
+        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, H.xp));
+    else
+        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part));
+    NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE, H.xp ? LAYOUT_XP : LAYOUT_NAT));
+    return 0;
+}
+
+int helm_finish(nlg_linop *op, const HelmSolve &H, int iters) {
+    if (H.xp) NLG_TRY(sem_from_xp(op->mesh, op->x, op->rhs, op->mesh->dim));   // the increment, natural layout
     op->st_viters += iters;
     op->last_viters = iters;
     if ((int)op->vit_hist.size() <= op->istep) op->vit_hist.resize(op->istep + 1, 0);
     op->vit_hist[op->istep] = iters;
     return 0;
+}
+
+int helm_solve(nlg_linop *op, int order, double h2) {
+    HelmSolve H;
+    NLG_TRY(helm_problem(op, order, h2, H));
+    auto apply = [&](double *) -> int { return helm_apply(op, H); };
+    int iters = 0;
+    NLG_TRY(run_pcg(op, H.P, apply, &iters));
+    return helm_finish(op, H, iters);
 }
 
 // One scalar (temperature) step of the Boussinesq coupling, see oracle/lns.py advance (ifheat branch):
@@ -1061,19 +1092,29 @@ int heat_step(nlg_linop *op, int k, double b0) {
     return 0;
 }
 
-int pres_solve(nlg_linop *op, double scale) {
+// The pressure solve in three pieces (see HelmSolve): set-up incl. the residual projection onto the previous increments,
+// one application of E, and the update of the projection space afterwards.
+struct PresSolve {
+    CGProblem P;
+    double *x[1], *r[1], *z[1], *p[1], *w[1], *pc[1], *nopc[1];
+    double *pw_part = nullptr;
+    bool proj = false;
+    int nold = 0;
+};
+
+int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
     nlg_mesh *m = op->mesh;
     const auto &c = op->cfg;
-    double *x[1] = {op->pr_x}, *r[1] = {op->pr_r}, *z[1] = {op->pr_z}, *p[1] = {op->pr_p}, *w[1] = {op->pr_w}, *pc[1] = {op->pce};
-    CGProblem P;
+    Q.x[0] = op->pr_x, Q.r[0] = op->pr_r, Q.z[0] = op->pr_z, Q.p[0] = op->pr_p, Q.w[0] = op->pr_w, Q.pc[0] = op->pce, Q.nopc[0] = nullptr;
+    CGProblem &P = Q.P;
     P.nf = 1;
     P.n = m->lpn;
-    P.x = x;
-    P.r = r;
-    P.z = z;
-    P.p = p;
-    P.w = w;
-    P.pc = pc;
+    P.x = Q.x;
+    P.r = Q.r;
+    P.z = Q.z;
+    P.p = Q.p;
+    P.w = Q.w;
+    P.pc = Q.pc;
     P.ipw = nullptr;
     P.nw = op->nwp;
     P.tol2 = (c.ptol / scale) * (c.ptol / scale);
@@ -1081,10 +1122,9 @@ int pres_solve(nlg_linop *op, double scale) {
     P.maxit = c.fixed_iters_p > 0 ? c.fixed_iters_p : c.maxit_p;
     P.s = op->d_s + S_N;
     P.inv_n = m->has_outflow ? 0.0 : 1.0 / (double)m->lpn_global;
-    double *nopc[1] = {nullptr};
     if (c.pprecond == 0 || c.pprecond == 2) {   // two-level Schwarz (pprec.hip): 0 = with overlap where available, 2 = without; 1 = Jacobi on diag(E), as in the oracle
         const bool overlap = c.pprecond == 0 && m->pprec.overlap;
-        P.pc = nopc;
+        P.pc = Q.nopc;
         P.npe = m->np2;
         // r.z / z sums from the last kernel of the preconditioner: 3-D always, 2-D with the overlapping variant
         double *rzp = (m->dim == 3 || overlap) ? op->d_part + 2 * m->E : nullptr;
@@ -1116,46 +1156,56 @@ int pres_solve(nlg_linop *op, double scale) {
     }
     // fused first-stage sums (rank-local; the all-reduce follows the second stage): p.w and sum w from the divergence kernel,
     // r.z and sum z from the preconditioner's last kernel
-    double *pw_part = op->d_part;
-    P.pw_part = pw_part;
+    Q.pw_part = op->d_part;
+    P.pw_part = Q.pw_part;
     P.pw_n = sem_opdiv_blocks(m);
     if (P.precond && (m->dim == 3 || (c.pprecond == 0 && m->pprec.overlap))) {
         P.rz_part = op->d_part + 2 * m->E;
         P.rz_n = m->dim == 3 ? (int)((m->E + 3) / 4) : (int)((m->E * m->np2 + NT - 1) / NT);
     }
-    // gated: launches past convergence (the host only looks at the flag once per chunk) return at once
-    auto apply = [&](double *sflag) -> int { return sem_cdabdtp(m, op->pr_p, op->pr_w, pw_part, sflag + S_DONE); };
     // ---- residual projection (c.pproj): start from the A-orthogonal projection of the solution onto the span of the
     // previous increments of this matvec; the PCG then solves for the remainder
     hipStream_t st = m->ctx->stream;
     // (not in the fixed-iteration parity mode: there the iteration is the oracle's, run on the full right-hand side)
-    const bool proj = c.pproj != 0 && op->prX != nullptr && c.fixed_iters_p <= 0;
-    double *alpha = op->d_pc, *beta = op->d_pc + PROJ_L, *nrm2 = op->d_pc + 2 * PROJ_L, *ppart = op->d_pc + 4 * PROJ_L;
-    const int gp = red_grid(m->lpn);
-    const int nold = op->nproj;
-    auto dots = [&](const double *y, int nvec, const double *M, double *out) -> int {
-        hipLaunchKernelGGL(k_proj_dots, dim3(gp), dim3(NT), 0, st, m->lpn, M, m->lps, nvec, y, ppart);
-        hipLaunchKernelGGL(k_proj_reduce, dim3(1), dim3(NT), 0, st, (const double *)ppart, gp, nvec, out);
-        return allreduce_sum(m->ctx, out, nvec);
-    };
-    if (proj && nold > 0) {
+    Q.proj = c.pproj != 0 && op->prX != nullptr && c.fixed_iters_p <= 0;
+    Q.nold = op->nproj;
+    if (Q.proj && Q.nold > 0) {
+        double *alpha = op->d_pc, *ppart = op->d_pc + 4 * PROJ_L;
+        const int gp = red_grid(m->lpn);
         ProfScope ps(m->ctx, P_VECOPS);
-        NLG_TRY(dots(op->pr_r, nold, op->prX, alpha));                       // alpha = X^T b
+        hipLaunchKernelGGL(k_proj_dots, dim3(gp), dim3(NT), 0, st, m->lpn, (const double *)op->prX, m->lps, Q.nold, (const double *)op->pr_r, ppart);
+        hipLaunchKernelGGL(k_proj_reduce, dim3(1), dim3(NT), 0, st, (const double *)ppart, gp, Q.nold, alpha);
+        NLG_TRY(allreduce_sum(m->ctx, alpha, Q.nold));                       // alpha = X^T b
         hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_r, (const double *)op->prB, m->lps,
-                           nold, (const double *)alpha, -1.0);               // b <- b - B alpha
+                           Q.nold, (const double *)alpha, -1.0);               // b <- b - B alpha
     }
     {
         char tb[96];
         snprintf(tb, sizeof(tb), "pres|%d|%d", c.pprecond, P.precond ? 1 : 0);
         P.tag = tb;
     }
-    int iters = 0;
-    NLG_TRY(run_pcg(op, P, apply, &iters));
+    return 0;
+}
+
+// gated: launches past convergence (the host only looks at the flag once per chunk) return at once
+int pres_apply(nlg_linop *op, const PresSolve &Q) { return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE); }
+
+int pres_finish(nlg_linop *op, const PresSolve &Q, int iters) {
+    nlg_mesh *m = op->mesh;
+    hipStream_t st = m->ctx->stream;
     op->st_piters += iters;
     op->last_piters = iters;
     if ((int)op->pit_hist.size() <= op->istep) op->pit_hist.resize(op->istep + 1, 0);
     op->pit_hist[op->istep] = iters;
-    if (proj) {
+    if (Q.proj) {
+        double *alpha = op->d_pc, *beta = op->d_pc + PROJ_L, *nrm2 = op->d_pc + 2 * PROJ_L, *ppart = op->d_pc + 4 * PROJ_L;
+        const int gp = red_grid(m->lpn);
+        const int nold = Q.nold;
+        auto dots = [&](const double *y, int nvec, const double *M, double *out) -> int {
+            hipLaunchKernelGGL(k_proj_dots, dim3(gp), dim3(NT), 0, st, m->lpn, M, m->lps, nvec, y, ppart);
+            hipLaunchKernelGGL(k_proj_reduce, dim3(1), dim3(NT), 0, st, (const double *)ppart, gp, nvec, out);
+            return allreduce_sum(m->ctx, out, nvec);
+        };
         // new member from the increment d = pr_x: w = A d, A-orthogonalised against the old members, normalised
         NLG_TRY(sem_cdabdtp(m, op->pr_x, op->pr_w));
         if (!m->has_outflow) NLG_TRY(sem_ortho(m, op->pr_w));                // A = P E P
@@ -1181,8 +1231,18 @@ int pres_solve(nlg_linop *op, double scale) {
     return 0;
 }
 
+int pres_solve(nlg_linop *op, double scale) {
+    PresSolve Q;
+    NLG_TRY(pres_problem(op, scale, Q));
+    auto apply = [&](double *) -> int { return pres_apply(op, Q); };
+    int iters = 0;
+    NLG_TRY(run_pcg(op, Q.P, apply, &iters));
+    return pres_finish(op, Q, iters);
+}
+
 // one restated nek_advance step (perturbation mode), see oracle/lns.py ExptA.advance
-int advance(nlg_linop *op) {
+// one restated nek_advance step in three phases around the two solves (shared by the single-vector and the block stepper)
+int adv_a(nlg_linop *op) {
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
     const int dim = m->dim;
@@ -1252,7 +1312,18 @@ int advance(nlg_linop *op) {
         launch_nf(dim, k_colmul_gated<1>, k_colmul_gated<2>, k_colmul_gated<3>, dim3(grid_for(m->lvn)), st,
                   (const double *)nullptr, f3(op->rhs, dim), mk, m->lvn);
     }
-    NLG_TRY(helm_solve(op, k, h2));
+    op->adv_k = k;
+    op->adv_b0 = b0;
+    op->adv_h2 = h2;
+    return 0;
+}
+
+int adv_b(nlg_linop *op) {
+    nlg_mesh *m = op->mesh;
+    hipStream_t st = m->ctx->stream;
+    const int dim = m->dim;
+    const double dt = op->dt, b0 = op->adv_b0;
+    (void)st;
     // uh = u + du -> into the oldest velocity buffer (slot 2), which becomes the new current after rotation
     double **unew = op->ubuf[2];
     {
@@ -1263,7 +1334,15 @@ int advance(nlg_linop *op) {
     // pressure correction
     NLG_TRY(sem_opdiv(m, unew, op->pr_r, -(b0 / dt)));
     NLG_TRY(sem_ortho(m, op->pr_r));
-    NLG_TRY(pres_solve(op, dt / b0));
+    return 0;
+}
+
+int adv_c(nlg_linop *op) {
+    nlg_mesh *m = op->mesh;
+    hipStream_t st = m->ctx->stream;
+    const int dim = m->dim;
+    const double dt = op->dt, b0 = op->adv_b0;
+    double **unew = op->ubuf[2];
     hipLaunchKernelGGL(k_axpy1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->p, (const double *)op->pr_x, 1.0);
     NLG_TRY(sem_opgradt(m, op->pr_x, op->gp));
     NLG_TRY(sem_opbinv(m, op->gp));
@@ -1284,6 +1363,14 @@ int advance(nlg_linop *op) {
     }
     op->st_steps += 1;
     return 0;
+}
+
+int advance(nlg_linop *op) {
+    NLG_TRY(adv_a(op));
+    NLG_TRY(helm_solve(op, op->adv_k, op->adv_h2));
+    NLG_TRY(adv_b(op));
+    NLG_TRY(pres_solve(op, op->dt / op->adv_b0));
+    return adv_c(op);
 }
 
 int load_state(nlg_linop *op, const nlg_vec *v, int irst) {
@@ -1431,6 +1518,182 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     return 0;
 }
 
+// =====================================================================================================================
+// Multi-vector (block) propagator: s <= 4 perturbations advanced together, time step by time step (the reference advances
+// several perturbations together through Nek5000's lpert / npert, src/neklab_nek_setup.f90:39-247, src/neklab_otd.f90:37-49).
+// Every vector has a LANE: an operator object with its own integrator state, PCG work vectors and device scalars; the base-
+// flow data (fine-mesh fields of the convective term, preconditioners, weights) belongs to lane 0 and is shared.  The s
+// velocity solves (and the s pressure solves) run as independent PCGs in lockstep -- own alpha, beta, convergence flag per
+// lane, so each lane performs exactly the iteration of the single-vector path -- with the operator applications of an
+// iteration issued together, which is where data that does not depend on the vector is read once for all lanes.
+// =====================================================================================================================
+struct PcgState {
+    Red rd_std, rd_rz, rd_rz_loop, rd_pw;
+    const double *xc = nullptr;
+    int g = 0;
+};
+
+int pcg_reduce_post(nlg_linop *op, const CGProblem &P, const Red &rd, int nsums, int gate, int mode) {
+    nlg_ctx *ctx = op->mesh->ctx;
+    hipStream_t st = ctx->stream;
+    if (!ctx->distributed()) {
+        hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, P.s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit, P.inv_n, 1);
+    } else {
+        hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, P.s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit, P.inv_n, 0);
+        NLG_TRY(allreduce_sum(ctx, P.s + S_T0, nsums));
+        hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, P.s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n);
+    }
+    return 0;
+}
+
+// everything run_pcg does before its first operator application
+int pcg_begin(nlg_linop *op, const CGProblem &P, PcgState &S) {
+    nlg_ctx *ctx = op->mesh->ctx;
+    hipStream_t st = ctx->stream;
+    const int nf = P.nf;
+    const int g = S.g = red_grid(P.n);
+    double *partial = ctx->d_partial;
+    F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
+    CF3 pc = cf3(P.pc, nf), cz = cf3(P.z, nf), cr = cf3(P.r, nf);
+    S.rd_std = Red{{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
+    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
+    S.xc = nullptr;
+    S.rd_rz = S.rd_std;
+    if (P.precond) {
+        NLG_TRY(P.precond(nullptr, P.r[0], P.z[0], &S.xc));
+        if (P.rz_part) {
+            S.rd_rz.p[0] = P.rz_part;
+            S.rd_rz.n[0] = P.rz_n;
+            S.rd_rz.p[2] = P.rz_part + P.rz_n;
+            S.rd_rz.n[2] = P.rz_n;
+        } else {
+            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)P.s, 0, P.n, cr, cz, P.ipw, S.xc, P.npe, partial);
+        }
+    }
+    S.rd_rz_loop = S.rd_rz;
+    if (P.rr_part) {
+        S.rd_rz_loop.p[1] = P.rr_part;
+        S.rd_rz_loop.n[1] = P.rr_n;
+    }
+    S.rd_pw = S.rd_std;
+    if (P.pw_part) {
+        S.rd_pw.p[0] = P.pw_part;
+        S.rd_pw.n[0] = P.pw_n;
+        S.rd_pw.p[1] = P.pw_part + P.pw_n;
+        S.rd_pw.n[1] = P.pw_sum ? P.pw_n : 0;
+    }
+    NLG_TRY(pcg_reduce_post(op, P, S.rd_rz, 3, 0, 0));
+    if (!P.fused_pupdate)
+        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)P.s, P.n, p, cz, S.xc, P.npe);   // p = z - zmean
+    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, P.s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
+    return 0;
+}
+
+// the part of a PCG iteration that follows w = A p
+int pcg_after_apply(nlg_linop *op, const CGProblem &P, PcgState &S) {
+    nlg_ctx *ctx = op->mesh->ctx;
+    hipStream_t st = ctx->stream;
+    const int nf = P.nf, g = S.g;
+    double *partial = ctx->d_partial;
+    F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
+    CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf), cr = cf3(P.r, nf);
+    if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
+    if (!P.pw_part) launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)P.s, P.n, cp, cw, P.ipw, partial);
+    NLG_TRY(pcg_reduce_post(op, P, S.rd_pw, 2, 1, 1));
+    if (!P.rr_part)
+        launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)P.s, P.n, x, r, z, cp, cw, pc, P.ipw, P.nw, partial);
+    if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
+    if (P.precond) {
+        NLG_TRY(P.precond(P.s + S_DONE, P.r[0], P.z[0], &S.xc));
+        if (!P.rz_part)
+            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)P.s, 1, P.n, cr, cz, P.ipw, S.xc, P.npe, partial);
+    }
+    NLG_TRY(pcg_reduce_post(op, P, S.rd_rz_loop, 3, 1, 2));
+    if (!P.fused_pupdate)
+        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)P.s, P.n, p, cz, S.xc, P.npe);
+    return 0;
+}
+
+// s PCGs in lockstep.  apply_all() issues w = A p for every lane (each gated by its own done flag on the device).
+template <typename ApplyAll>
+int run_pcg_block(nlg_linop *const *ops, int s, const CGProblem *const *P, ApplyAll apply_all, int *iters) {
+    hipStream_t st = ops[0]->mesh->ctx->stream;
+    PcgState S[4];
+    int chunk = 2, maxit = 0;
+    for (int v = 0; v < s; ++v) {
+        NLG_TRY(pcg_begin(ops[v], *P[v], S[v]));
+        chunk = std::max(chunk, P[v]->chunk);
+        maxit = std::max(maxit, P[v]->maxit);
+    }
+    int launched = 0;
+    while (true) {
+        int todo = launched == 0 ? chunk : 2;
+        if (launched + todo > maxit) todo = maxit - launched;
+        for (int it = 0; it < todo; ++it) {
+            NLG_TRY(apply_all());
+            for (int v = 0; v < s; ++v) NLG_TRY(pcg_after_apply(ops[v], *P[v], S[v]));
+        }
+        launched += todo;
+        NLG_HIP(hipGetLastError());
+        for (int v = 0; v < s; ++v)
+            NLG_HIP(hipMemcpyAsync(ops[0]->h_s + (size_t)v * S_N, P[v]->s, sizeof(double) * S_N, hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        bool all_done = true;
+        for (int v = 0; v < s; ++v) all_done = all_done && ops[0]->h_s[(size_t)v * S_N + S_DONE] != 0.0;
+        if (all_done || launched >= maxit) break;
+    }
+    for (int v = 0; v < s; ++v) {
+        const double *h = ops[0]->h_s + (size_t)v * S_N;
+        if (!std::isfinite(h[S_RN2])) {
+            set_error("PCG diverged (residual is not finite) after %d iterations (lane %d of the block)", (int)h[S_ITERS], v);
+            return 1;
+        }
+        iters[v] = (int)h[S_ITERS];
+    }
+    return 0;
+}
+
+// lane v of the block stepper: lane 0 is the operator itself, lanes 1 .. 3 are created on first use
+nlg_linop *lane_get(nlg_linop *op0, int v);
+int lane_refresh(nlg_linop *op0, nlg_linop *ln);
+
+int advance_block(nlg_linop *const *ops, int s) {
+    for (int v = 0; v < s; ++v) NLG_TRY(adv_a(ops[v]));
+    {
+        HelmSolve H[4];
+        const CGProblem *P[4];
+        for (int v = 0; v < s; ++v) {
+            NLG_TRY(helm_problem(ops[v], ops[v]->adv_k, ops[v]->adv_h2, H[v]));
+            P[v] = &H[v].P;
+        }
+        int iters[4];
+        auto apply_all = [&]() -> int {
+            for (int v = 0; v < s; ++v) NLG_TRY(helm_apply(ops[v], H[v]));
+            return 0;
+        };
+        NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
+        for (int v = 0; v < s; ++v) NLG_TRY(helm_finish(ops[v], H[v], iters[v]));
+    }
+    for (int v = 0; v < s; ++v) NLG_TRY(adv_b(ops[v]));
+    {
+        PresSolve Q[4];
+        const CGProblem *P[4];
+        for (int v = 0; v < s; ++v) {
+            NLG_TRY(pres_problem(ops[v], ops[v]->dt / ops[v]->adv_b0, Q[v]));
+            P[v] = &Q[v].P;
+        }
+        int iters[4];
+        auto apply_all = [&]() -> int {
+            for (int v = 0; v < s; ++v) NLG_TRY(pres_apply(ops[v], Q[v]));
+            return 0;
+        };
+        NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
+        for (int v = 0; v < s; ++v) NLG_TRY(pres_finish(ops[v], Q[v], iters[v]));
+    }
+    for (int v = 0; v < s; ++v) NLG_TRY(adv_c(ops[v]));
+    return 0;
+}
+
 // vec_out = state after the nsteps of one application started from `ic` (null: rest) under the time-harmonic body force
 // Re[(f_re + i f_im) exp(i s omega t)], s = -1 for the adjoint equations: evaluate_rhs / evaluate_imaginary_part of the
 // resolvent (src/linops/resolvent.f90:80-111, :133-166).  No restart-history replay, no history in the result.
@@ -1544,6 +1807,19 @@ int nlg_linop_create(nlg_mesh *mesh, const nlg_exptA_config *cfg, const nlg_vec 
 int nlg_linop_destroy(nlg_linop *op) {
     if (!op) return 0;
     hipDeviceSynchronize();
+    for (nlg_linop *&ln : op->lanes) {
+        if (ln) nlg_linop_destroy(ln);
+        ln = nullptr;
+    }
+    if (op->is_lane) {   // shared with the owner: forget the pointers, free only what the lane allocated itself
+        for (int c = 0; c < 3; ++c) {
+            op->Ur[c] = nullptr;
+            for (int k = 0; k < 4; ++k) op->pcv[k][c] = op->pcv_xp[k][c] = nullptr;
+        }
+        for (int q = 0; q < 9; ++q) op->GU[q] = nullptr;
+        op->pce = op->nwv = op->nwv_xp = op->nwp = nullptr;
+        op->baseflow = nullptr;
+    }
     for (auto &kv : op->graphs)
         if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
     op->graphs.clear();
@@ -1602,7 +1878,7 @@ int nlg_linop_destroy(nlg_linop *op) {
     fr(op->d_s);
     fr(op->d_part);
     if (op->h_s) hipHostFree(op->h_s);
-    nlg_vec_destroy(op->baseflow);
+    if (op->baseflow) nlg_vec_destroy(op->baseflow);
     delete op;
     return 0;
 }
@@ -1912,6 +2188,141 @@ int nlg_linop_get_stats(const nlg_linop *op, int64_t *steps, int64_t *v_iters, i
     if (p_iters) *p_iters = op->st_piters;
     if (matvecs) *matvecs = op->st_matvecs;
     return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// lane v >= 1: own integrator state and PCG work vectors (the allocations of nlg_linop_init), shared base-flow data
+nlg_linop *lane_get(nlg_linop *op0, int v) {
+    if (v == 0) return op0;
+    if (op0->lanes[v - 1]) return op0->lanes[v - 1];
+    nlg_mesh *m = op0->mesh;
+    const int dim = m->dim;
+    nlg_linop *ln = new nlg_linop();
+    ln->mesh = m;
+    ln->is_lane = true;
+    ln->cfg = op0->cfg;
+    bool ok = true;
+    auto al = [&](double **p, int64_t n) { ok = ok && lalloc(ln, p, n) == 0; };
+    for (int c = 0; c < dim; ++c) {
+        for (int q = 0; q < 3; ++q) {
+            al(&ln->ubuf[q][c], m->lvs);
+            al(&ln->fbuf[q][c], m->lvs);
+        }
+        al(&ln->rhs[c], m->lvs);
+        al(&ln->x[c], m->lvs);
+        al(&ln->z[c], m->lvs);
+        al(&ln->pv[c], m->lvs);
+        al(&ln->w[c], m->lvs);
+        al(&ln->gp[c], m->lvs);
+    }
+    for (double **q : {&ln->p, &ln->pr_r, &ln->pr_x, &ln->pr_z, &ln->pr_p, &ln->pr_w}) al(q, m->lps);
+    if (op0->cfg.pproj) {
+        al(&ln->prX, (int64_t)PROJ_L * m->lps);
+        al(&ln->prB, (int64_t)PROJ_L * m->lps);
+        al(&ln->d_pc, 4 * PROJ_L + PROJ_L * NB);
+    }
+    al(&ln->d_s, 4 * S_N);
+    al(&ln->d_part, 3 * m->E + 16);
+    if (!ok) {
+        nlg_linop_destroy(ln);
+        return nullptr;
+    }
+    op0->lanes[v - 1] = ln;
+    return ln;
+}
+
+// base-flow data, time step and tolerances follow the owner (it may have been re-initialised since the lane was made)
+int lane_refresh(nlg_linop *op0, nlg_linop *ln) {
+    if (ln == op0) return 0;
+    ln->cfg = op0->cfg;
+    ln->baseflow = op0->baseflow;
+    ln->inited = op0->inited;
+    ln->dt = op0->dt, ln->cfl = op0->cfl, ln->nsteps = op0->nsteps;
+    for (int c = 0; c < 3; ++c) {
+        ln->Ur[c] = op0->Ur[c];
+        for (int k = 0; k < 4; ++k) ln->pcv[k][c] = op0->pcv[k][c], ln->pcv_xp[k][c] = op0->pcv_xp[k][c];
+    }
+    for (int q = 0; q < 9; ++q) ln->GU[q] = op0->GU[q];
+    ln->pce = op0->pce, ln->nwv = op0->nwv, ln->nwv_xp = op0->nwv_xp, ln->nwp = op0->nwp;
+    ln->use_xp = op0->use_xp;
+    ln->h_s = nullptr;   // the block PCG reads every lane's scalars through the owner's pinned buffer
+    return 0;
+}
+
+int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *const *vout, int adjoint) {
+    NLG_CHECK(op && vin && vout, "exptA block matvec: NULL argument");
+    NLG_CHECK(s >= 1 && s <= 4, "exptA block matvec: %d vectors unsupported (1..4)", s);
+    NLG_CHECK(op->inited, "exptA block matvec: nlg_linop_init has not been called");
+    NLG_CHECK(!op->is_lane, "exptA block matvec: called on a lane");
+    nlg_mesh *m = op->mesh;
+    NLG_CHECK(!op->cfg.ifheat && op->proj_nlines == 0,
+              "exptA block matvec: the Boussinesq coupling and the wavenumber projection run through the single-vector path");
+    for (int v = 0; v < s; ++v) {
+        NLG_CHECK(vin[v] && vout[v] && vin[v]->mesh == m && vout[v]->mesh == m, "exptA block matvec: vector %d NULL or on a different mesh", v);
+        NLG_CHECK(vin[v]->nscal == 0 && vout[v]->nscal == 0, "exptA block matvec: vector %d carries scalars", v);
+        NLG_CHECK(vin[v]->lorder >= op->cfg.torder && vout[v]->lorder >= op->cfg.torder, "exptA block matvec: vector lorder < time order");
+        for (int u = 0; u < s; ++u) NLG_CHECK(vin[v] != vout[u], "exptA block matvec: an input vector is also an output vector");
+        for (int u = 0; u < v; ++u) NLG_CHECK(vout[v] != vout[u], "exptA block matvec: the same output vector twice");
+    }
+    hipStream_t st = m->ctx->stream;
+    nlg_linop *ops[4];
+    for (int v = 0; v < s; ++v) {
+        ops[v] = lane_get(op, v);
+        NLG_CHECK(ops[v], "exptA block matvec: lane allocation failed");
+        NLG_TRY(lane_refresh(op, ops[v]));
+    }
+    const int nrst = op->cfg.torder - 1;
+    for (int v = 0; v < s; ++v) {
+        nlg_linop *ln = ops[v];
+        for (int q = 0; q < 3; ++q)
+            for (int c = 0; c < m->dim; ++c) {
+                NLG_HIP(hipMemsetAsync(ln->ubuf[q][c], 0, sizeof(double) * (size_t)m->lvs, st));
+                NLG_HIP(hipMemsetAsync(ln->fbuf[q][c], 0, sizeof(double) * (size_t)m->lvs, st));
+            }
+        ln->istep = 0;
+        ln->adjoint = adjoint;
+        ln->nproj = 0;
+        NLG_TRY(load_state(ln, vin[v], 0));
+    }
+    for (int istep = 1; istep <= op->nsteps; ++istep) {
+        NLG_TRY(advance_block(ops, s));
+        if (istep <= nrst)
+            for (int v = 0; v < s; ++v)
+                if (vin[v]->nrst > 0) NLG_TRY(load_state(ops[v], vin[v], istep));   // get_rst, exponential_propagator.f90:129-142
+    }
+    for (int v = 0; v < s; ++v) {
+        NLG_TRY(nlg_vec_zero(vout[v]));
+        NLG_TRY(store_state(ops[v], vout[v], 0));
+    }
+    for (int irst = 1; irst <= nrst; ++irst) {   // compute_rst, :109-127
+        NLG_TRY(advance_block(ops, s));
+        for (int v = 0; v < s; ++v) {
+            NLG_TRY(store_state(ops[v], vout[v], irst));
+            vout[v]->nrst = std::max(vout[v]->nrst, irst);
+        }
+    }
+    // the lanes' counters are part of the operator's statistics
+    for (int v = 1; v < s; ++v) {
+        op->st_steps += ops[v]->st_steps, op->st_viters += ops[v]->st_viters, op->st_piters += ops[v]->st_piters;
+        ops[v]->st_steps = ops[v]->st_viters = ops[v]->st_piters = 0;
+    }
+    op->st_matvecs += s;
+    return 0;
+}
+
+}  // namespace
+
+namespace nlg {
+bool linop_can_block(const nlg_linop *op) { return op && !op->cfg.ifheat && op->proj_nlines == 0 && !op->is_lane; }
+}
+
+extern "C" {
+
+int nlg_linop_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vec_in, nlg_vec *const *vec_out, int transpose) {
+    return do_matvec_block(op, s, vec_in, vec_out, transpose ? 1 : 0);
 }
 
 int nlg_op_conv(nlg_mesh *m, const nlg_vec *base, const nlg_vec *in, nlg_vec *out, int adjoint) {

@@ -330,6 +330,14 @@ class exptA_linop:
             raise TypeError("type_error: nek_dvector expected (reference: exponential_propagator.f90:100-105)")
         check(self.lib.nlg_linop_rmatvec(self.h, vec_in.h, vec_out.h))
 
+    def matvec_block(self, vecs_in: list, vecs_out: list, transpose: bool = False):
+        """len(vecs_in) <= 4 vectors advanced together (nlg_linop_matvec_block)."""
+        s = len(vecs_in)
+        assert len(vecs_out) == s
+        ai = (vp * s)(*[x.h for x in vecs_in])
+        ao = (vp * s)(*[x.h for x in vecs_out])
+        check(self.lib.nlg_linop_matvec_block(self.h, s, ai, ao, int(bool(transpose))))
+
     def info(self) -> dict:
         tau, dt, cfl, ns = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         check(self.lib.nlg_linop_get_info(self.h, C.byref(tau), C.byref(dt), C.byref(ns), C.byref(cfl)))

@@ -168,3 +168,49 @@ def test_eigs_block_mode_and_warm_start(gpu_ctx):
     if abs(mu_b.imag) < 1e-12:
         w.axpby(-mu_b.real, Xb[0], 1.0)
         assert w.norm() < 1e-6 * Xb[0].norm()
+
+
+@pytest.mark.parametrize("dim,n,s", [(2, 6, 2), (3, 8, 3), (3, 5, 4)])
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_matvec_block_equals_single_matvecs(gpu_ctx, dim, n, s, adjoint):
+    """nlg_linop_matvec_block: s vectors advanced together in lockstep PCGs give what s single matvecs give -- with
+    restart-history replay on some lanes and not on others, tolerance-terminated solves that converge at different
+    iteration counts per lane, direct and adjoint."""
+    nel = (4, 3) if dim == 2 else (3, 2, 2)
+    hm = box_mesh(nel, n, periodic=(True,) + (False,) * (dim - 1), deform=0.04)
+    gm = host.Mesh(gpu_ctx, hm)
+    X = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
+    gb = host.nek_dvector(gm)
+    gb.set_field(0, hm.mask[0] * (1.0 + 0.5 * np.sin(X[0]) * np.cos(X[1])))
+    gb.set_field(1, hm.mask[1] * 0.3 * np.sin(2 * X[0]))
+    A = host.exptA_linop(0.05, gb, re=40.0, dt=0.01, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    A.init()
+    vin = []
+    for v in range(s):
+        x = host.nek_dvector(gm)
+        x.rand(True, seed=40 + v)
+        x.scal(10.0 ** (-2 * v))                     # very different magnitudes: different iteration counts per lane
+        if v % 2 == 1:                               # odd lanes carry a restart history (the image of a first matvec)
+            y = host.nek_dvector(gm)
+            (A.rmatvec if adjoint else A.matvec)(x, y)
+            x = y
+        vin.append(x)
+    single = [host.nek_dvector(gm) for _ in range(s)]
+    for v in range(s):
+        (A.rmatvec if adjoint else A.matvec)(vin[v], single[v])
+    st0 = A.stats()
+    blk = [host.nek_dvector(gm) for _ in range(s)]
+    A.matvec_block(vin, blk, transpose=adjoint)
+    st1 = A.stats()
+    assert st1["matvecs"] - st0["matvecs"] == s
+    for v in range(s):
+        sc = max(np.abs(single[v].get_field(i)).max() for i in range(dim))
+        for r in range(3):
+            for i in range(dim):
+                assert np.max(np.abs(blk[v].get_field(i, r) - single[v].get_field(i, r))) < 1e-11 * sc, (v, r, i)
+            assert np.max(np.abs(blk[v].get_field(host.PR, r) - single[v].get_field(host.PR, r))) < 1e-9 * max(sc, np.abs(single[v].get_field(host.PR, r)).max())
+        assert blk[v].nrst == 2
+    with pytest.raises(host.NlgError):
+        A.matvec_block(vin[:2], [blk[0], blk[0]])
+    with pytest.raises(host.NlgError):
+        A.matvec_block(vin[:1], vin[:1])
