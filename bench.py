@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-units", action="store_true", help="skip the U1+U2 / U3 unit timings after the timed region (profiling runs)")
     ap.add_argument("--pproj", type=int, default=1, help="pressure residual projection (1 default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--block", type=int, default=1,
+                    help="> 1: a step is one BLOCK Arnoldi step with this many vectors (<= 4) advanced together "
+                         "(nlg_block_arnoldi_step); value counts every vector's matvec")
     return ap.parse_args()
 
 
@@ -196,8 +199,13 @@ def main():
     H = np.zeros((m + 2, m + 1), order="F")
     names = ["axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops", "pprec", "axpy_dot"]
 
+    sblk = max(1, min(args.block, 4))
+
     def step():
-        host.arnoldi_step(A, B, m - 1, H)
+        if sblk > 1:      # columns m+1-2s .. m-s  ->  m+1-s .. m
+            host.block_arnoldi_step(A, B, m + 1 - 2 * sblk, sblk, H)
+        else:
+            host.arnoldi_step(A, B, m - 1, H)
 
     def barrier():
         ctx.sync()
@@ -349,7 +357,7 @@ def main():
         out = {
             "metric": "linop matvecs/sec + Arnoldi iter time, E=10k N=7, 1/2/4/8 GPU",
             # matvecs per second of the GLOBAL operator (strong: the same E-element problem at every N)
-            "value": args.steps / elapsed,
+            "value": sblk * args.steps / elapsed,
             "unit": "matvecs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -358,7 +366,8 @@ def main():
             "config": {"workload": "3-D deformed box E=%d (%s) lx1=%d (N=%d), Krylov dim m=%d, exptA: Re=%g bdf3/ext3 "
                                    "nsteps=%d(+2 history steps), tol 1e-9/1e-7, one Arnoldi iteration per step at k=m"
                                    % (E_global, "x".join(map(str, gnel)), n, n - 1, m, args.re, args.nsteps),
-                       "elements_per_gpu": E_global / world, "time_steps_per_matvec": steps_per_mv,
+                       "vectors_per_step": sblk,
+                       "elements_per_gpu": E_global / world, "time_steps_per_matvec": steps_per_mv / sblk,
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
                        "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
                        "global_elements": E_global,

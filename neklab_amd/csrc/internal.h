@@ -362,6 +362,8 @@ int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);
 int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
                double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr, bool xp = false);   // zf: fused u <- zf + beta u; xp: u, zf, w in the x-planes-first layout (3-D, lx1 <= 8)
+int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *const *w, double h1, double h2, double *const *pw,
+                     double *const *const *zf, const double *const *beta, const double *const *done, bool xp);
 int sem_opdiv_blocks(const nlg_mesh *m);
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
@@ -370,11 +372,17 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
               const double *pdot = nullptr, double *pw_part = nullptr, const double *gate = nullptr);
 int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr, const double *gate = nullptr);
+int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate);
+int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate);
+int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *out, double scale, double *const *wts, bool face_grouped,
+                    const double *const *pdot, double *const *pw_part, const double *const *gate);
 int sem_ediag(nlg_mesh *m, double *out);
 int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, const double *Mx, const double *My,
                const double *Mz, const double *wt);
 int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU);
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint);
+int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int nl, double *const *const *ulanes, double *const *const *olanes, int adjoint);
+int sem_conv_apply_generic(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint);
 int sem_conv_scalar_setup(nlg_mesh *m, const double *Theta, double **GT);
 int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, double *const *u, const double *theta, double *out, int adjoint = 0);
 int sem_scalar_grad_apply(nlg_mesh *m, double *const *GT, const double *theta, double *const *out, double sgn);

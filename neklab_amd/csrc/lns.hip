@@ -1242,24 +1242,34 @@ int pres_solve(nlg_linop *op, double scale) {
 
 // one restated nek_advance step (perturbation mode), see oracle/lns.py ExptA.advance
 // one restated nek_advance step in three phases around the two solves (shared by the single-vector and the block stepper)
-int adv_a(nlg_linop *op) {
+// phase 0: the whole of it; 1: up to the convective term (exclusive); 2: from after the convective term on -- the block stepper
+// evaluates the convective terms of all its lanes in one launch between 1 and 2
+int adv_a(nlg_linop *op, int phase = 0) {
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
     const int dim = m->dim;
     const double dt = op->dt, nu = 1.0 / op->cfg.re;
-    op->istep += 1;
-    // gauge: keep the pressure mean-free (see oracle/lns.py advance)
-    NLG_TRY(sem_ortho(m, op->p));
+    if (phase != 2) {
+        op->istep += 1;
+        // gauge: keep the pressure mean-free (see oracle/lns.py advance)
+        NLG_TRY(sem_ortho(m, op->p));
+    }
     const int k = std::min(op->istep, op->cfg.torder);
     const double b0 = BDF_B0[k];
-    if (op->nonlinear) {   // the "base flow" is the current state (velocity, and temperature when coupled)
-        NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));
-        if (op->cfg.ifheat) NLG_TRY(sem_conv_scalar_setup(m, op->tbuf[0], op->GT));
+    op->adv_k = k;
+    op->adv_b0 = b0;
+    op->adv_h2 = b0 / dt;
+    if (phase != 2) {
+        if (op->nonlinear) {   // the "base flow" is the current state (velocity, and temperature when coupled)
+            NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));
+            if (op->cfg.ifheat) NLG_TRY(sem_conv_scalar_setup(m, op->tbuf[0], op->GT));
+        }
+        if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
     }
-    if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
+    if (phase == 1) return 0;
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
-    NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
+    if (phase == 0) NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
     if (op->cfg.ifheat && op->adjoint && !op->nonlinear) {
         // adjoint momentum equation: - theta+ grad Theta with the new theta+ (stored F is +N: add the weak term)
         NLG_TRY(sem_scalar_grad_apply(m, op->GT, op->tbuf[0], Fnew, 1.0));
@@ -1658,7 +1668,13 @@ nlg_linop *lane_get(nlg_linop *op0, int v);
 int lane_refresh(nlg_linop *op0, nlg_linop *ln);
 
 int advance_block(nlg_linop *const *ops, int s) {
-    for (int v = 0; v < s; ++v) NLG_TRY(adv_a(ops[v]));
+    for (int v = 0; v < s; ++v) NLG_TRY(adv_a(ops[v], 1));
+    {   // convective terms of all lanes against the shared base-flow fields: one launch
+        double *const *ul[4], *const *ol[4];
+        for (int v = 0; v < s; ++v) ul[v] = ops[v]->ubuf[0], ol[v] = ops[v]->fbuf[2];
+        NLG_TRY(sem_conv_apply_lanes(ops[0]->mesh, ops[0]->Ur, ops[0]->GU, s, ul, ol, ops[0]->adjoint));
+    }
+    for (int v = 0; v < s; ++v) NLG_TRY(adv_a(ops[v], 2));
     {
         HelmSolve H[4];
         const CGProblem *P[4];
@@ -1667,8 +1683,27 @@ int advance_block(nlg_linop *const *ops, int s) {
             P[v] = &H[v].P;
         }
         int iters[4];
+        // 3-D, lx1 <= 8: the Helmholtz operator of all lanes in one launch, one (p, w) sum per (lane, element)
+        nlg_mesh *m = ops[0]->mesh;
+        // (measured at E = 10^4, lx1 = 8, s = 4: 715 us per launch = 179 us per lane against 167 - 175 us for the per-lane kernel
+        //  -- the kernel is bound by its LDS hand-overs, not by the metric-factor bytes it saves; opt-in: NLG_AXHELM_LANES=1)
+        static const bool lanes_kernel = getenv("NLG_AXHELM_LANES") && atoi(getenv("NLG_AXHELM_LANES")) != 0;
+        const bool batched = lanes_kernel && m->dim == 3 && m->n <= 8 && s >= 2 && H[0].pw_part != nullptr;
+        double *const *uu[4], *const *ww[4], *const *zz[4];
+        double *pw[4];
+        const double *bb[4], *dd[4];
+        for (int v = 0; v < s; ++v) {
+            uu[v] = ops[v]->pv, ww[v] = ops[v]->w, zz[v] = ops[v]->z, pw[v] = H[v].pw_part;
+            bb[v] = ops[v]->d_s + S_BETA, dd[v] = ops[v]->d_s + S_DONE;
+            if (batched) H[v].P.pw_n = (int)m->E;
+        }
         auto apply_all = [&]() -> int {
-            for (int v = 0; v < s; ++v) NLG_TRY(helm_apply(ops[v], H[v]));
+            if (!batched) {
+                for (int v = 0; v < s; ++v) NLG_TRY(helm_apply(ops[v], H[v]));
+                return 0;
+            }
+            NLG_TRY(sem_axhelm_lanes(m, s, uu, ww, H[0].nu, H[0].h2, pw, zz, bb, dd, H[0].xp));
+            for (int v = 0; v < s; ++v) NLG_TRY(sem_gs(m, ops[v]->w, m->dim, dd[v], H[v].xp ? LAYOUT_XP : LAYOUT_NAT));
             return 0;
         };
         NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
@@ -1683,10 +1718,11 @@ int advance_block(nlg_linop *const *ops, int s) {
             P[v] = &Q[v].P;
         }
         int iters[4];
-        auto apply_all = [&]() -> int {
-            for (int v = 0; v < s; ++v) NLG_TRY(pres_apply(ops[v], Q[v]));
-            return 0;
-        };
+        // E p for all lanes: the gradient and divergence kernels take the lanes in one launch each
+        const double *pp[4], *gg[4];
+        double *ww[4], *pw[4];
+        for (int v = 0; v < s; ++v) pp[v] = ops[v]->pr_p, ww[v] = ops[v]->pr_w, pw[v] = Q[v].pw_part, gg[v] = ops[v]->d_s + S_N + S_DONE;
+        auto apply_all = [&]() -> int { return sem_cdabdtp_lanes(ops[0]->mesh, s, pp, ww, pw, gg); };
         NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
         for (int v = 0; v < s; ++v) NLG_TRY(pres_finish(ops[v], Q[v], iters[v]));
     }

@@ -178,6 +178,18 @@ struct F3 {
 struct CF3 {
     const double *p[3];
 };
+struct CP4 {    // one read-only array per lane
+    const double *p[4];
+};
+struct P4 {
+    double *p[4];
+};
+struct CF3L {   // up to four lanes (vectors of a block step) of three fields
+    const double *p[4][3];
+};
+struct F3L {
+    double *p[4][3];
+};
 struct CF9 {
     const double *p[9];
 };
@@ -685,6 +697,134 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     }
 }
 
+// The same for the NL <= 4 lanes of a block step: one block = one element, 3 NL waves = (lane, component) pairs, so the six
+// metric factors and the mass matrix of the element are fetched from HBM once and served to the other waves by L1.  Every
+// lane has its own direction update (beta), done flag and (p, w) sums -- one sum per (lane, element).
+struct HelmLanes {
+    const double *u[4][3];
+    double *w[4][3];
+    const double *z[4][3];
+    const double *beta[4];
+    const double *done[4];
+    double *pw[4];
+};
+template <int N, int NL, bool XP>
+__global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const double *__restrict__ Dg,
+                                                       const double *__restrict__ G0, const double *__restrict__ G1,
+                                                       const double *__restrict__ G2, const double *__restrict__ G3,
+                                                       const double *__restrict__ G4, const double *__restrict__ G5,
+                                                       const double *__restrict__ bm1, HelmLanes L, double h1, double h2,
+                                                       const int *__restrict__ xptab) {
+    constexpr int WPB = 3 * NL;
+    static_assert(N * N <= 64, "one lane per (i, j)");
+    constexpr int NP = N * N * N, NS = N * N, NQ = N + 1;
+    __shared__ double sD[N * N];
+    __shared__ double sU[WPB][N * NQ], sR[WPB][N * NQ], sS[WPB][N * NQ];
+    __shared__ double sred[WPB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: element, field and every base pointer stay scalar
+    for (int p = tid; p < NS; p += 64 * WPB) sD[p] = Dg[p];
+    __syncthreads();   // the only block-wide barrier: the derivative matrix
+    const int64_t e = blockIdx.x;
+    const int lv = wv / 3, c = wv - 3 * lv;
+    const double *done_p = L.done[lv], *beta_p = L.beta[lv];
+    const bool gated = done_p && done_p[0] != 0.0;   // this lane's PCG has converged: nothing consumes its w any more
+    const bool act = e < E && lane < NS && !gated;
+    const int ij = lane < NS ? lane : 0;
+    const int i = ij % N, j = ij / N;
+    const int64_t eoff = (e < E ? e : 0) * NP;
+    const int base = ij;   // offset inside the element, natural layout (metric factors)
+    // field offsets inside the element: vb + k * vs
+    const int vb = XP ? xptab[ij] : ij;   // slab-permuted layout: position inside the slab from the table (internal.h sp_slab_table)
+    constexpr int vs = NS;
+    const double *uc = L.u[lv][c] + eoff;
+    double *wc = L.w[lv][c] + eoff;
+    const double *zc = L.z[lv][c] + eoff;
+    G0 += eoff, G1 += eoff, G2 += eoff, G3 += eoff, G4 += eoff, G5 += eoff, bm1 += eoff;
+    const bool upd = beta_p != nullptr && !gated;
+    const double beta = upd ? beta_p[0] : 0.0;
+    double pw = 0.0;
+    if (!gated) {   // (a converged lane skips the work; its waves still take part in the block reduction below)
+    double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double v = act ? uc[vb + k * vs] : 0.0;
+        if (upd && act) {
+            v = zc[vb + k * vs] + beta * v;
+            const_cast<double *>(uc)[vb + k * vs] = v;
+        }
+        uk[k] = v;
+        wk[k] = 0.0;
+    }
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        di[l] = sD[i * N + l];
+        dj[l] = sD[j * N + l];
+        dti[l] = sD[l * N + i];
+        dtj[l] = sD[l * N + j];
+    }
+    double *mU = sU[wv], *mR = sR[wv], *mS = sS[wv];
+    // metric factors of slab k+1 are requested while slab k is computed; the compiler barrier at the end of every slab
+    // keeps it from hoisting ALL slabs' loads to the top (which costs 400 registers and the occupancy)
+    double gn[7];
+    gn[0] = G0[base], gn[1] = G1[base], gn[2] = G2[base], gn[3] = G3[base], gn[4] = G4[base], gn[5] = G5[base], gn[6] = bm1[base];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3], g4 = gn[4], g5 = gn[5], bm = gn[6];
+        if (k + 1 < N) {
+            const int q = base + (k + 1) * NS;
+            gn[0] = G0[q], gn[1] = G1[q], gn[2] = G2[q], gn[3] = G3[q], gn[4] = G4[q], gn[5] = G5[q], gn[6] = bm1[q];
+        }
+        if (lane < NS) mU[i + NQ * j] = uk[k];
+        wave_lds_sync();
+        // row k of D, wave-uniform: lane k (i = k, j = 0) holds it in di[] -> scalar registers, no LDS, no vector registers
+        double dk[N];
+#pragma unroll
+        for (int l = 0; l < N; ++l) dk[l] = readlane_f64(di[l], k);
+        double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+            ur += di[l] * mU[l + NQ * j];
+            us += dj[l] * mU[i + NQ * l];
+            ut += dk[l] * uk[l];
+        }
+        const double gr = h1 * (g0 * ur + g1 * us + g2 * ut);
+        const double gs = h1 * (g1 * ur + g3 * us + g4 * ut);
+        const double gt = h1 * (g2 * ur + g4 * us + g5 * ut);
+        if (lane < NS) {
+            mR[i + NQ * j] = gr;
+            mS[i + NQ * j] = gs;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int l = 0; l < N; ++l) wk[l] += dk[l] * gt;
+        double a = h2 * bm * uk[k];
+#pragma unroll
+        for (int l = 0; l < N; ++l) a += dti[l] * mR[l + NQ * j] + dtj[l] * mS[i + NQ * l];
+        wk[k] += a;
+        // pin the accumulators here: otherwise the compiler sinks these sums into the guarded store at the end and keeps
+        // every slab's LDS operands alive until then (400 registers, one wave per SIMD)
+#pragma unroll
+        for (int l = 0; l < N; ++l) asm volatile("" : "+v"(wk[l]));
+        asm volatile("" ::: "memory");
+    }
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            wc[vb + k * vs] = wk[k];
+            pw += wk[k] * uk[k];
+        }
+    }
+    }
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+        if (lane == 0) sred[wv] = pw;
+        __syncthreads();
+        if (tid < NL && L.pw[tid] && !(L.done[tid] && L.done[tid][0] != 0.0)) L.pw[tid][e] = (sred[3 * tid] + sred[3 * tid + 1]) + sred[3 * tid + 2];
+    }
+}
+
 // Register-column variant for N > 8: one block of ceil(N N / 64) waves per (element, field); thread (i, j) keeps its
 // k-column of u and of w in registers as in k_axhelm3r, the three N x N slabs are shared by the block's waves, so the two
 // hand-overs per slab are block barriers (two or three waves: cheap) instead of the wave-level LDS ordering.  Row k of D
@@ -952,9 +1092,7 @@ struct PBlock {
 
 // opgradt: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise)
 template <int N, int NC, bool FG>
-__global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, const double *__restrict__ p, F3 w,
-                                                 const double *__restrict__ gate) {
-    if (gate && gate[0] != 0.0) return;   // the surrounding PCG has converged (device-side done flag)
+__global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NT = PBlock<N, NC>::NTB;   // (shadows the file-level block size: 128 threads when one component is in flight)
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
@@ -963,9 +1101,13 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(i
     __shared__ double sB[NC * 2][SB];
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
-    const double *pe = p + e * NP2;
+    // lanes (the vectors of a block step) one after the other: the nine metric arrays of the element (15.5 KB at lx1 = 8) come
+    // from HBM for the first lane and from L1 / L2 for the others
+    for (int lv = 0; lv < nl; ++lv) {
+    if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;   // this lane's PCG has converged (device-side done flag, block-uniform)
+    const double *pe = pl.p[lv] + e * NP2;
     for (int c0 = 0; c0 < 3; c0 += NC) {
-        if (c0 > 0) __syncthreads();
+        if (c0 > 0 || lv > 0) __syncthreads();
         // z stage, arrays j = 0,1 (interpolation along z)
         for (int t = tid; t < NC * 2 * NS2; t += NT) {
             const int arr = t / NS2, col = t % NS2;
@@ -1032,7 +1174,7 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(i
                 b0[i2] = sB[ci * 2 + 0][i2 + N2 * bc];
                 b1[i2] = sB[ci * 2 + 1][i2 + N2 * bc];
             }
-            double *wp = (i == 0 ? w.p[0] : (i == 1 ? w.p[1] : w.p[2])) + e * NP1;
+            double *wp = wl.p[lv][i] + e * NP1;
             const int jj = bc % N, kk = bc / N;
 #pragma unroll
             for (int a = 0; a < N; ++a) {
@@ -1043,16 +1185,15 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(i
             }
         }
     }
+    }
 }
 
 // opdiv: out = scale * sum_i sum_j g_ji o (T_j (wt_i o u_i)); wt (may hold nulls) fuses mask * binvm1 into the load
 // `pdot`/`part` (may be null): first-stage sums of the surrounding PCG, part[e] = sum_q pdot_q out_q and
 // part[E + e] = sum_q out_q over the element -- saves a separate pass over two pressure-mesh vectors.
 template <int N, int NC, bool FG>
-__global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3 u, CF3 wt, double *__restrict__ out,
-                                               double scale, const double *__restrict__ pdot, double *__restrict__ part,
-                                               const double *__restrict__ gate) {
-    if (gate && gate[0] != 0.0) return;
+__global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3L ul, CF3 wt, P4 outl,
+                                               double scale, CP4 pdotl, P4 partl, CP4 gatel, int nl) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NT = PBlock<N, NC>::NTB;
     constexpr int NP2 = N2 * N2 * N2, NP1 = N * N * N;
@@ -1063,6 +1204,12 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
     constexpr int NACC = (NP2 + NT - 1) / NT;
+    // lanes one after the other: weights (mask * binvm1) and metric arrays of the element are re-read from L1 / L2
+    for (int lv = 0; lv < nl; ++lv) {
+    if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
+    double *__restrict__ out = outl.p[lv];
+    const double *__restrict__ pdot = pdotl.p[lv];
+    double *__restrict__ part = partl.p[lv];
     double acc[NACC];
 #pragma unroll
     for (int r = 0; r < NACC; ++r) acc[r] = 0.0;
@@ -1071,7 +1218,7 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int
         // x stage from HBM: B0 = D_x u, B1 = I_x u   (columns over (j, k); N contiguous doubles per thread)
         for (int t = tid; t < NC * N * N; t += NT) {
             const int ci = t / (N * N), bc = t % (N * N), i = c0 + ci;
-            const double *up = (i == 0 ? u.p[0] : (i == 1 ? u.p[1] : u.p[2])) + e * NP1;
+            const double *up = ul.p[lv][i] + e * NP1;
             const double *wp = (i == 0 ? wt.p[0] : (i == 1 ? wt.p[1] : wt.p[2]));
             const int jj = bc % N, kk = bc / N;
             int sl[N];
@@ -1201,6 +1348,8 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int
             part[e] = a;
             part[E + e] = b;
         }
+    }
+    __syncthreads();
     }
 }
 
@@ -1397,7 +1546,7 @@ __global__ void k_conv_combine_adj(int dim, int64_t n, CF3 Ur, CF3 du, double *a
 // NTC threads: one per fine-mesh column along z (ND^2 = 324 at lx1 = 12 -> 384 threads).
 template <int N, int ND, int NTC, bool ULDS, bool DYN>
 __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
-                                                 CF3 Ur, CF9 GU, CF3 u, F3 out, int adjoint) {
+                                                 CF3 Ur, CF9 GU, CF3L ul, F3L outl, int nl, int adjoint) {
     constexpr int NP = N * N * N, NPD = ND * ND * ND;
     constexpr int NQ = N | 1, NDQ = ND | 1;          // padded (odd) leading dimensions
     constexpr int SU = NQ * N * N;                   // u:  (i | j, k), row stride NQ
@@ -1417,10 +1566,13 @@ __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const dou
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t e = blockIdx.x;
     if (e >= E) return;
+    // lanes (the vectors of a block step) one after the other: the twelve base-flow fields of the element are then served by
+    // L2 / the Infinity Cache for every lane after the first
+    for (int lv = 0; lv < nl; ++lv) {
     if (ULDS)
         for (int t = tid; t < 3 * NP; t += NT) {
             const int c = t / NP, q = t % NP;
-            sU[c][(q % N) + NQ * (q / N)] = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2]))[e * NP + q];
+            sU[c][(q % N) + NQ * (q / N)] = ul.p[lv][c][e * NP + q];
         }
     double ufr[3][ND];
     constexpr int OD = (ND + NW - 1) / NW;   // fine-index outputs per wave
@@ -1432,7 +1584,7 @@ __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const dou
         for (int col = lane; col < N * N; col += 64) {
             double v[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = ULDS ? sU[mcomp][i + NQ * col] : (mcomp == 0 ? u.p[0] : (mcomp == 1 ? u.p[1] : u.p[2]))[e * NP + i + N * col];
+            for (int i = 0; i < N; ++i) v[i] = ULDS ? sU[mcomp][i + NQ * col] : ul.p[lv][mcomp][e * NP + i + N * col];
 #pragma unroll
             for (int o = 0; o < OD; ++o) {
                 const int a = wave + NW * o;
@@ -1486,7 +1638,7 @@ __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const dou
         for (int col = lane; col < N * N; col += 64) {
             double v[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = ULDS ? sU[ic][i + NQ * col] : (ic == 0 ? u.p[0] : (ic == 1 ? u.p[1] : u.p[2]))[e * NP + i + N * col];
+            for (int i = 0; i < N; ++i) v[i] = ULDS ? sU[ic][i + NQ * col] : ul.p[lv][ic][e * NP + i + N * col];
 #pragma unroll
             for (int o = 0; o < OD; ++o) {
                 const int a = wave + NW * o;
@@ -1608,10 +1760,11 @@ __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const dou
         }
         __syncthreads();
         {
-            double *op = (ic == 0 ? out.p[0] : (ic == 1 ? out.p[1] : out.p[2])) + e * NP;
+            double *op = outl.p[lv][ic] + e * NP;
             for (int q = tid; q < NP; q += NT) op[q] = sB[(q % N) + NQ * (q / N)];
         }
         __syncthreads();
+    }
     }
 }
 
@@ -2046,6 +2199,55 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
     return 0;
 }
 
+// nl <= 4 lanes of the velocity PCG of a block step in one launch (3-D, lx1 <= 8); otherwise lane by lane.  pw[v]: E sums of
+// p . w per lane (one per element); zf / beta / done: the fused direction update and the done flag of every lane.
+int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *const *w, double h1, double h2, double *const *pw,
+                     double *const *const *zf, const double *const *beta, const double *const *done, bool xp) {
+    if (!(m->dim == 3 && m->n <= 8 && nl >= 2 && nl <= 4)) {
+        for (int v = 0; v < nl; ++v) NLG_TRY(sem_axhelm(m, u[v], w[v], m->dim, h1, h2, pw[v], zf[v], beta[v], done[v], xp));
+        return 0;
+    }
+    ProfScope ps(m->ctx, P_AXHELM);
+    HelmLanes L;
+    for (int v = 0; v < 4; ++v) {
+        for (int c = 0; c < 3; ++c) {
+            L.u[v][c] = v < nl ? u[v][c] : nullptr;
+            L.w[v][c] = v < nl ? w[v][c] : nullptr;
+            L.z[v][c] = v < nl ? zf[v][c] : nullptr;
+        }
+        L.beta[v] = v < nl ? beta[v] : nullptr;
+        L.done[v] = v < nl ? done[v] : nullptr;
+        L.pw[v] = v < nl ? pw[v] : nullptr;
+    }
+    hipStream_t s = m->ctx->stream;
+    const int *tab = xp ? (const int *)m->d_slot_xp : nullptr;
+#define AXB(N_, NL_)                                                                                                         \
+    if (xp)                                                                                                                  \
+        hipLaunchKernelGGL((k_axhelm3rb<N_, NL_, true>), dim3((unsigned)m->E), dim3(64 * 3 * NL_), 0, s, m->E, m->d_D, m->d_G[0], m->d_G[1], \
+                           m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, L, h1, h2, tab);                          \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((k_axhelm3rb<N_, NL_, false>), dim3((unsigned)m->E), dim3(64 * 3 * NL_), 0, s, m->E, m->d_D, m->d_G[0], m->d_G[1], \
+                           m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, L, h1, h2, tab);
+#define AXBN(N_)                        \
+    case N_:                            \
+        if (nl == 2) {                  \
+            AXB(N_, 2)                  \
+        } else if (nl == 3) {           \
+            AXB(N_, 3)                  \
+        } else {                        \
+            AXB(N_, 4)                  \
+        }                               \
+        break;
+    switch (m->n) {
+        AXBN(4) AXBN(5) AXBN(6) AXBN(7) AXBN(8)
+        default: set_error("sem_axhelm_lanes: lx1 = %d", m->n); return 1;
+    }
+#undef AXBN
+#undef AXB
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2) {
     hipLaunchKernelGGL(k_helm_diag, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, m->dim, m->n, m->E, m->d_D,
                        m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, out, h1, h2);
@@ -2073,35 +2275,52 @@ static CF9 rst2w_ptrs(const nlg_mesh *m) {
 }
 
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped, const double *gate) {
+    const double *pl[1] = {p}, *gl[1] = {gate};
+    double *const *wl[1] = {w};
+    return sem_opgradt_lanes(m, 1, pl, wl, face_grouped, gl);
+}
+
+// nl <= 4 pressure fields -> nl velocity-mesh field triples in one launch (block stepper); gates: per-lane done flags (may be null)
+int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate) {
     ProfScope ps(m->ctx, P_OPGRADT);
-    F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
+        CP4 pl, gl;
+        F3L wl;
+        for (int v = 0; v < 4; ++v) {
+            pl.p[v] = v < nl ? p[v] : nullptr;
+            gl.p[v] = (v < nl && gate) ? gate[v] : nullptr;
+            for (int c = 0; c < 3; ++c) wl.p[v][c] = v < nl ? w[v][c] : nullptr;
+        }
 #define GT3(N_)                                                                                                        \
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, p, cw, gate);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, p, cw, gate);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, p, cw, gate);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);   \
     }
         NLG_FOR_N(GT3)
 #undef GT3
     } else {
+        for (int v = 0; v < nl; ++v) {
+            F3 cw = {{w[v][0], w[v][1], nullptr}};
+            const double *pv = p[v];
 #define GT2(N_)                                                                                              \
     {                                                                                                        \
         constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                         \
         hipLaunchKernelGGL((k_opgradt2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
-                           m->d_I12t, m->d_D12t, g, p, cw);                                                  \
+                           m->d_I12t, m->d_D12t, g, pv, cw);                                                 \
     }
-        NLG_FOR_N(GT2)
+            NLG_FOR_N(GT2)
 #undef GT2
+        }
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -2116,36 +2335,59 @@ int sem_opdiv_blocks(const nlg_mesh *m) {
 
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts, bool face_grouped,
               const double *pdot, double *pw_part, const double *gate) {
+    double *const *ul[1] = {u};
+    double *ol[1] = {out}, *pl[1] = {pw_part};
+    const double *dl[1] = {pdot}, *gl[1] = {gate};
+    return sem_opdiv_lanes(m, 1, ul, ol, scale, wts, face_grouped, dl, pl, gl);
+}
+
+// nl <= 4 velocity-mesh field triples -> nl pressure fields in one launch (block stepper)
+int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *out, double scale, double *const *wts, bool face_grouped,
+                    const double *const *pdot, double *const *pw_part, const double *const *gate) {
     ProfScope ps(m->ctx, P_OPDIV);
-    CF3 cu = {{u[0], u[1], m->dim == 3 ? u[2] : nullptr}};
     CF3 wt = {{wts ? wts[0] : nullptr, wts ? wts[1] : nullptr, (wts && m->dim == 3) ? wts[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
+        CF3L ul;
+        P4 ol, pl;
+        CP4 dl, gl;
+        for (int v = 0; v < 4; ++v) {
+            for (int c = 0; c < 3; ++c) ul.p[v][c] = v < nl ? u[v][c] : nullptr;
+            ol.p[v] = v < nl ? out[v] : nullptr;
+            pl.p[v] = (v < nl && pw_part) ? pw_part[v] : nullptr;
+            dl.p[v] = (v < nl && pdot) ? pdot[v] : nullptr;
+            gl.p[v] = (v < nl && gate) ? gate[v] : nullptr;
+        }
 #define DV3(N_)                                                                                                        \
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, cu, wt, out, scale, pdot, pw_part, gate); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
     }
         NLG_FOR_N(DV3)
 #undef DV3
     } else {
+        for (int v = 0; v < nl; ++v) {
+            CF3 cu = {{u[v][0], u[v][1], nullptr}};
+            double *ov = out[v], *pv = pw_part ? pw_part[v] : nullptr;
+            const double *dv = pdot ? pdot[v] : nullptr, *gv = gate ? gate[v] : nullptr;
 #define DV2(N_)                                                                                            \
     {                                                                                                      \
         constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                       \
         hipLaunchKernelGGL((k_opdiv2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
-                           m->d_I12, m->d_D12, g, cu, wt, out, scale, pdot, pw_part, gate);                \
+                           m->d_I12, m->d_D12, g, cu, wt, ov, scale, dv, pv, gv);                          \
     }
-        NLG_FOR_N(DV2)
+            NLG_FOR_N(DV2)
 #undef DV2
+        }
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -2162,6 +2404,39 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
         hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn);
     NLG_HIP(hipGetLastError());
     return 0;
+}
+
+// E applied to nl <= 4 pressure fields (block stepper): gradient, gather-scatter, divergence; the two element kernels take
+// all lanes in one launch
+int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate) {
+    const bool fg = m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg);
+    double *w[4][3];
+    double *const *wl[4];
+    for (int v = 0; v < nl; ++v) {
+        for (int c = 0; c < 3; ++c) w[v][c] = c < m->dim ? sem_scratch1(m, 8 + 3 * v + c) : nullptr;
+        NLG_CHECK(w[v][0] && w[v][1], "sem_cdabdtp: scratch allocation failed");
+        wl[v] = w[v];
+    }
+    NLG_TRY(sem_opgradt_lanes(m, nl, p, wl, fg, gate));
+    for (int v = 0; v < nl; ++v) {
+        const double *gv = gate ? gate[v] : nullptr;
+        if (fg) {
+            if (m->gs.ngroups > 0) {
+                ProfScope ps(m->ctx, P_GS);
+                F3 f = {{w[v][0], w[v][1], w[v][2]}};
+                const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
+                hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gv);
+                NLG_HIP(hipGetLastError());
+            }
+            if (m->halo.active) {
+                ProfScope ps(m->ctx, P_GS);
+                NLG_TRY(halo_exchange(m, w[v], 3, true));
+            }
+        } else {
+            NLG_TRY(sem_gs(m, w[v], m->dim, gv));
+        }
+    }
+    return sem_opdiv_lanes(m, nl, wl, out, 1.0, fg ? m->d_mbinv_fg : m->d_mbinv, fg, p, pw_part, gate);
 }
 
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, const double *gate) {
@@ -2346,17 +2621,33 @@ int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, dou
 
 // out_i = weak linearised convective term (B-weighted, element-local), see oracle/sem.py lns_conv_weak
 int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
-    ProfScope ps(m->ctx, P_CONV);
+    double *const *ul[1] = {u}, *const *ol[1] = {out};
+    return sem_conv_apply_lanes(m, Ur, GU, 1, ul, ol, adjoint);
+}
+
+// nl <= 4 vectors against the same base flow (block stepper): one launch where the fused kernel exists
+int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int nl, double *const *const *ulanes, double *const *const *olanes, int adjoint) {
     const int dim = m->dim;
-    if (dim == 3 && (m->n <= 10 || m->n == 12) && m->nd == (3 * m->n) / 2) {
+    if (!(dim == 3 && (m->n <= 10 || m->n == 12) && m->nd == (3 * m->n) / 2)) {
+        for (int v = 0; v < nl; ++v) NLG_TRY(sem_conv_apply_generic(m, Ur, GU, ulanes[v], olanes[v], adjoint));
+        return 0;
+    }
+    ProfScope ps(m->ctx, P_CONV);
+    {
         // fused kernel: static LDS up to lx1 = 8, dynamic LDS (one block per CU) for lx1 = 9, 10, 12
-        CF3 cur = {{Ur[0], Ur[1], Ur[2]}}, cu = {{u[0], u[1], u[2]}};
+        CF3 cur = {{Ur[0], Ur[1], Ur[2]}};
+        CF3L cu;
+        F3L co;
+        for (int v = 0; v < 4; ++v)
+            for (int c = 0; c < 3; ++c) {
+                cu.p[v][c] = v < nl ? ulanes[v][c] : nullptr;
+                co.p[v][c] = v < nl ? olanes[v][c] : nullptr;
+            }
         CF9 cg;
         for (int q = 0; q < 9; ++q) cg.p[q] = GU[q];
-        F3 co = {{out[0], out[1], out[2]}};
 #define CV3(N_)                                                                                                       \
     hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
-                       (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, adjoint);
+                       (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);
 #define CV3D(N_, NTC_, ULDS_)                                                                                          \
     {                                                                                                                  \
         constexpr int ND_ = (3 * N_) / 2, NQ_ = N_ | 1, NDQ_ = ND_ | 1;                                                \
@@ -2368,7 +2659,7 @@ int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *co
             attr_set = true;                                                                                           \
         }                                                                                                              \
         hipLaunchKernelGGL((k_conv3<N_, ND_, NTC_, ULDS_, true>), dim3((unsigned)m->E), dim3(NTC_), lds, m->ctx->stream, m->E, \
-                           (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, adjoint);              \
+                           (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);          \
     }
         switch (m->n) {
             case 4: CV3(4); break;
@@ -2385,6 +2676,12 @@ int sem_conv_apply(nlg_mesh *m, double *const *Ur, double *const *GU, double *co
         NLG_HIP(hipGetLastError());
         return 0;
     }
+}
+
+// the generic path: tensor-product kernels and fine-mesh intermediates (2-D, lx1 = 11, non-standard lxd)
+int sem_conv_apply_generic(nlg_mesh *m, double *const *Ur, double *const *GU, double *const *u, double *const *out, int adjoint) {
+    ProfScope ps(m->ctx, P_CONV);
+    const int dim = m->dim;
     double *uf[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
     double *du[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), dim == 3 ? sem_scratchd(m, 5) : nullptr};
     double *acc = sem_scratchd(m, 6);

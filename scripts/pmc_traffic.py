@@ -65,8 +65,8 @@ def classify(rows):
     for _, k, v in rows:
         site = ""
         if k.startswith("k_gs<"):
-            if re.match(r"k_axhelm3r<.*true>", prev):
-                site = "x-planes-first (velocity PCG)"
+            if re.match(r"k_axhelm3rb?<.*true>", prev):
+                site = "slab-permuted (velocity PCG)"
             elif re.match(r"k_opgradt3<.*true>", prev) or re.match(r"k_fdm|k_sch|k_q1", prev):
                 site = "face-grouped (pressure operator / Schwarz exchange)"
             else:

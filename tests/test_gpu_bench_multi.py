@@ -24,6 +24,16 @@ def run_bench(*extra):
     return json.loads(lines[0])
 
 
+def test_bench_strong_scaling_uneven_partition():
+    """Three ranks on four element layers (2, 1, 1): the strong-scaling split of BASELINE.json's 20 layers over 8 GPUs is
+    uneven too (3, 3, 3, 3, 2, 2, 2, 2)."""
+    one = run_bench("--gpus", "1", "--scaling", "strong")
+    three = run_bench("--gpus", "3", "--transport", "shm", "--scaling", "strong")
+    assert three["n_gpus"] == 3 and three["config"]["global_elements"] == one["config"]["global_elements"] == 144
+    assert abs(three["config"]["dt"] - one["config"]["dt"]) < 1e-12 * one["config"]["dt"]
+    assert abs(three["config"]["pressure_iters_per_time_step"] - one["config"]["pressure_iters_per_time_step"]) <= 0.3 * one["config"]["pressure_iters_per_time_step"] + 2
+
+
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_starts_its_own_ranks(scaling):
     one = run_bench("--gpus", "1", "--scaling", scaling)
