@@ -8,9 +8,12 @@
 //   set-up : every rank gathers the sorted unique element-boundary labels of all ranks (ncclAllGather),
 //            intersects them with its own -> per neighbour a list of shared labels in ascending label order
 //            (the same order on both sides), see nlg_halo_plan (pure host code, unit-tested on CPU).
-//   gs_op  : local gather-scatter -> pack one representative value per (neighbour, shared label)
-//            -> grouped ncclSend/ncclRecv with every neighbour -> unpack: one thread per shared label sums
-//            the received contributions in ascending neighbour order and adds the sum to all local copies.
+//   gs_op  : local gather-scatter of the groups that hold a dof another rank shares -> pack one representative value per
+//            (neighbour, shared label) -> grouped ncclSend/ncclRecv with every neighbour  ||  local gather-scatter of all
+//            other groups -> unpack: one thread per shared label sums the received contributions in ascending neighbour
+//            order and adds the sum to all local copies.  The two local parts touch disjoint dofs, so the result does not
+//            depend on whether the exchange runs beside the second part (side stream, NLG_HALO_OVERLAP=1) or between the
+//            two (default, and always with the shared-memory validation transport).
 #include <algorithm>
 #include <numeric>
 
@@ -270,17 +273,84 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
     }
     NLG_HIP(hipMalloc(&h.d_send, sizeof(double) * (size_t)tot * 3));
     NLG_HIP(hipMalloc(&h.d_recv, sizeof(double) * (size_t)tot * 3));
+    NLG_HIP(hipEventCreateWithFlags(&h.ev_packed, hipEventDisableTiming));
+    NLG_HIP(hipEventCreateWithFlags(&h.ev_recv, hipEventDisableTiming));
+    const char *ov = getenv("NLG_HALO_OVERLAP");
+    h.overlap = ov && atoi(ov) != 0 && !ctx->shm;
     h.active = true;
+    NLG_TRY(gs_split(m));
     return 0;
 }
 
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout) {
+// ---- the local groups split by "holds a dof that another rank shares" ----------------------------------------------
+static int upload_tab(std::vector<std::vector<int>> &gl, int np1, bool partner_order, nlg_gs_tab &t) {
+    auto cls = [](size_t sz) { return sz == 2 ? 0 : (sz == 4 ? 1 : 2); };
+    std::sort(gl.begin(), gl.end(), [&](const std::vector<int> &a, const std::vector<int> &b) {
+        const int ca = cls(a.size()), cb = cls(b.size());
+        if (ca != cb) return ca < cb;
+        if (ca == 0 && partner_order) {   // as in nlg_mesh_create: pairs by (element, partner element, index)
+            const int ea = a[0] / np1, eb = b[0] / np1, pa = a[1] / np1, pb = b[1] / np1;
+            if (ea != eb) return ea < eb;
+            if (pa != pb) return pa < pb;
+        }
+        return a[0] < b[0];
+    });
+    std::vector<int> off{0}, idx;
+    t.ngroups = (int64_t)gl.size();
+    t.npairs = t.nquads = 0;
+    for (auto &v : gl) {
+        t.npairs += v.size() == 2;
+        t.nquads += v.size() == 4;
+        idx.insert(idx.end(), v.begin(), v.end());
+        off.push_back((int)idx.size());
+    }
+    NLG_HIP(hipMalloc(&t.d_off, sizeof(int) * off.size()));
+    NLG_HIP(hipMalloc(&t.d_idx, sizeof(int) * std::max<size_t>(idx.size(), 4)));
+    NLG_HIP(hipMemcpy(t.d_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
+    if (!idx.empty()) NLG_HIP(hipMemcpy(t.d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int gs_split(nlg_mesh *m) {
+    nlg_gs &g = m->gs;
+    g.split = false;
+    if (!m->halo.active || g.h_groups.empty()) {
+        g.h_groups.clear();
+        g.h_groups.shrink_to_fit();
+        return 0;
+    }
+    const int np1 = m->np1;
+    std::vector<char> shared((size_t)m->lvn, 0);
+    for (int i : m->halo.h_cidx) shared[i] = 1;
+    for (int layout = 0; layout < 3; ++layout) {
+        const std::vector<int> *slot = layout == LAYOUT_FG ? &m->h_slot : (layout == LAYOUT_XP ? &m->h_slot_xp : nullptr);
+        if (slot && slot->empty()) continue;
+        std::vector<std::vector<int>> part[2];
+        for (const auto &grp : g.h_groups) {
+            bool hal = false;
+            for (int i : grp) hal = hal || shared[i];
+            std::vector<int> v(grp);
+            if (slot) {
+                for (int &i : v) i = (i / np1) * np1 + (*slot)[i % np1];
+                std::sort(v.begin(), v.end());
+            }
+            part[hal ? 0 : 1].push_back(std::move(v));
+        }
+        NLG_TRY(upload_tab(part[0], np1, layout == LAYOUT_XP, g.tab_halo[layout]));
+        NLG_TRY(upload_tab(part[1], np1, layout == LAYOUT_XP, g.tab_rest[layout]));
+    }
+    g.split = true;
+    g.h_groups.clear();
+    g.h_groups.shrink_to_fit();
+    return 0;
+}
+
+int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout) {
     nlg_halo &h = m->halo;
     if (!h.active) return 0;
     NLG_CHECK(layout != LAYOUT_FG || h.d_send_idx_fg, "halo_exchange: no face-grouped index lists");
-    NLG_CHECK(layout != LAYOUT_XP || h.d_send_idx_xp, "halo_exchange: no x-planes-first index lists");
+    NLG_CHECK(layout != LAYOUT_XP || h.d_send_idx_xp, "halo_exchange: no slab-permuted index lists");
     const int *send_idx = layout == LAYOUT_FG ? h.d_send_idx_fg : (layout == LAYOUT_XP ? h.d_send_idx_xp : h.d_send_idx);
-    const int *cidx = layout == LAYOUT_FG ? h.d_cidx_fg : (layout == LAYOUT_XP ? h.d_cidx_xp : h.d_cidx);
     nlg_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
@@ -291,17 +361,33 @@ int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout) {
         hipLaunchKernelGGL(k_halo_pack<2>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
     else
         hipLaunchKernelGGL(k_halo_pack<3>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
-    if (ctx->shm) {
-        NLG_TRY(shm_exchange(ctx, h, nf));
-    } else {
-        NLG_NCCL(ncclGroupStart());
-        for (size_t q = 0; q < h.neigh.size(); ++q)
-            for (int c = 0; c < nf; ++c) {
-                NLG_NCCL(ncclSend(h.d_send + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
-                NLG_NCCL(ncclRecv(h.d_recv + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, st));
-            }
-        NLG_NCCL(ncclGroupEnd());
+    NLG_HIP(hipGetLastError());
+    if (ctx->shm) return shm_exchange(ctx, h, nf);
+    // the send / receive group goes to the side stream when the overlap is switched on: it starts when the pack kernel has
+    // finished and halo_finish makes the launch stream wait for it, so the communicator never sees two operations at once
+    hipStream_t sx = h.overlap ? ctx->stream2 : st;
+    if (h.overlap) {
+        NLG_HIP(hipEventRecord(h.ev_packed, st));
+        NLG_HIP(hipStreamWaitEvent(sx, h.ev_packed, 0));
     }
+    NLG_NCCL(ncclGroupStart());
+    for (size_t q = 0; q < h.neigh.size(); ++q)
+        for (int c = 0; c < nf; ++c) {
+            NLG_NCCL(ncclSend(h.d_send + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, sx));
+            NLG_NCCL(ncclRecv(h.d_recv + (size_t)c * h.ntot + h.noff[q], (size_t)h.ncnt[q], ncclDouble, h.neigh[q], ctx->comm, sx));
+        }
+    NLG_NCCL(ncclGroupEnd());
+    if (h.overlap) NLG_HIP(hipEventRecord(h.ev_recv, sx));
+    return 0;
+}
+
+int halo_finish(nlg_mesh *m, double *const *fields, int nf, int layout) {
+    nlg_halo &h = m->halo;
+    if (!h.active) return 0;
+    const int *cidx = layout == LAYOUT_FG ? h.d_cidx_fg : (layout == LAYOUT_XP ? h.d_cidx_xp : h.d_cidx);
+    hipStream_t st = m->ctx->stream;
+    if (h.overlap && !m->ctx->shm) NLG_HIP(hipStreamWaitEvent(st, h.ev_recv, 0));
+    F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
     const int g2 = (int)((h.nlab + NT - 1) / NT);
     if (nf == 1)
         hipLaunchKernelGGL(k_halo_unpack<1>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
@@ -313,6 +399,11 @@ int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout) {
     return 0;
 }
 
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout) {
+    NLG_TRY(halo_begin(m, fields, nf, layout));
+    return halo_finish(m, fields, nf, layout);
+}
+
 void halo_free(nlg_mesh *m) {
     nlg_halo &h = m->halo;
     int *ip[] = {h.d_send_idx, h.d_roff, h.d_rpos, h.d_coff, h.d_cidx, h.d_send_idx_fg, h.d_cidx_fg, h.d_send_idx_xp, h.d_cidx_xp};
@@ -320,6 +411,15 @@ void halo_free(nlg_mesh *m) {
         if (p) hipFree(p);
     if (h.d_send) hipFree(h.d_send);
     if (h.d_recv) hipFree(h.d_recv);
+    if (h.ev_packed) hipEventDestroy(h.ev_packed);
+    if (h.ev_recv) hipEventDestroy(h.ev_recv);
+    for (int l = 0; l < 3; ++l)
+        for (nlg_gs_tab *t : {&m->gs.tab_halo[l], &m->gs.tab_rest[l]}) {
+            if (t->d_off) hipFree(t->d_off);
+            if (t->d_idx) hipFree(t->d_idx);
+            *t = nlg_gs_tab();
+        }
+    m->gs.split = false;
     h = nlg_halo();
 }
 

@@ -169,6 +169,10 @@ inline int xp_slot(int N, int a, int j, int k) {
     return N * N * k + tab[a + N * j];
 }
 
+struct nlg_gs_tab {   // one table of groups as k_gs reads it: pairs first, then quads, then the rest (CSR)
+    int64_t ngroups = 0, npairs = 0, nquads = 0;
+    int *d_off = nullptr, *d_idx = nullptr;
+};
 struct nlg_gs {
     // groups of local dofs that share a global label (only groups of size >= 2 are stored)
     int64_t ngroups = 0;
@@ -185,6 +189,11 @@ struct nlg_gs {
     // ... and in the x-planes-first layout of the velocity PCG (3-D)
     int *d_offsets_xp = nullptr;
     int *d_indices_xp = nullptr;
+    // several ranks: the groups split into those holding a dof that another rank shares (summed first, so that the halo
+    // exchange can start) and all others (summed while the exchange is under way); one pair of tables per layout
+    bool split = false;
+    nlg_gs_tab tab_halo[3], tab_rest[3];
+    std::vector<std::vector<int>> h_groups;   // the groups in natural indices; kept only until halo_setup has split them
 };
 enum { LAYOUT_NAT = 0, LAYOUT_FG = 1, LAYOUT_XP = 2 };
 
@@ -200,6 +209,8 @@ struct nlg_halo {
     int *d_send_idx_xp = nullptr, *d_cidx_xp = nullptr;   // ... and for the x-planes-first layout
     double *d_send = nullptr, *d_recv = nullptr;
     std::vector<int> h_cidx;         // host copy of d_cidx: every local dof that another rank shares
+    bool overlap = false;            // send / receive on the side stream while the interior groups are summed (NLG_HALO_OVERLAP)
+    hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
 };
 
 // two-level preconditioner of the pressure operator (pprec.hip)
@@ -351,7 +362,10 @@ bool linop_can_block(const nlg_linop *op);   // the multi-vector stepper covers 
 
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout = 0);   // LAYOUT_*
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout = 0);   // LAYOUT_*; = halo_begin + halo_finish
+int gs_split(nlg_mesh *m);   // builds gs.tab_halo / tab_rest from gs.h_groups and the halo lists
+int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout);    // pack + start of the exchange
+int halo_finish(nlg_mesh *m, double *const *fields, int nf, int layout);   // end of the exchange + unpack
 void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----

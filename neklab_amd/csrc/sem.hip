@@ -2033,29 +2033,43 @@ double *sem_scratch2(nlg_mesh *m, int i) {
     return m->scratch2[i];
 }
 
+static int gs_launch(nlg_mesh *m, const int *goff, const int *gidx, int64_t ngroups, int64_t npairs, int64_t nquads, double *const *fields,
+                     int nf, const double *gate) {
+    if (ngroups == 0) return 0;
+    F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
+    const int grid = (int)((ngroups + NT - 1) / NT);
+    if (nf == 1)
+        hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate);
+    else if (nf == 2)
+        hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate);
+    else
+        hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate);
+    NLG_HIP(hipGetLastError());
+    return 0;
+}
+
 int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int layout) {
     if (m->gs.ngroups == 0 && !m->halo.active) return 0;
     // (the timed class "gs" is the dim-field kernel of the two PCGs; scalar-field calls go to "vec_ops" so that the
     //  class average is the duration of ONE kernel with ONE algorithmic byte count)
     ProfScope ps(m->ctx, nf == m->dim ? P_GS : P_VECOPS);
-    NLG_CHECK(layout == LAYOUT_NAT || (layout == LAYOUT_XP && (m->gs.d_indices_xp || m->gs.ngroups == 0)), "sem_gs: layout %d has no tables", layout);
-    const int *goff = layout == LAYOUT_XP ? m->gs.d_offsets_xp : m->gs.d_offsets;
-    const int *gidx = layout == LAYOUT_XP ? m->gs.d_indices_xp : m->gs.d_indices;
+    const int *goff = layout == LAYOUT_XP ? m->gs.d_offsets_xp : (layout == LAYOUT_FG ? m->gs.d_offsets_fg : m->gs.d_offsets);
+    const int *gidx = layout == LAYOUT_XP ? m->gs.d_indices_xp : (layout == LAYOUT_FG ? m->gs.d_indices_fg : m->gs.d_indices);
+    NLG_CHECK(layout >= LAYOUT_NAT && layout <= LAYOUT_XP && (gidx || m->gs.ngroups == 0), "sem_gs: layout %d has no tables", layout);
     if (nf < 1 || nf > 3) {
         set_error("sem_gs: nf=%d unsupported", nf);
         return 1;
     }
-    if (m->gs.ngroups > 0) {
-        F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
-        const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-        if (nf == 1)
-            hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
-        else if (nf == 2)
-            hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
-        else
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
-        NLG_HIP(hipGetLastError());
+    if (m->halo.active && m->gs.split) {
+        // several ranks: first the groups that hold a dof another rank shares, so that their sums can be packed and sent,
+        // then all other groups (disjoint dofs) while the exchange is under way, then the received sums (halo.hip)
+        const nlg_gs_tab &th = m->gs.tab_halo[layout], &tr = m->gs.tab_rest[layout];
+        NLG_TRY(gs_launch(m, th.d_off, th.d_idx, th.ngroups, th.npairs, th.nquads, fields, nf, gate));
+        NLG_TRY(halo_begin(m, fields, nf, layout));
+        NLG_TRY(gs_launch(m, tr.d_off, tr.d_idx, tr.ngroups, tr.npairs, tr.nquads, fields, nf, gate));
+        return halo_finish(m, fields, nf, layout);
     }
+    NLG_TRY(gs_launch(m, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, fields, nf, gate));
     return halo_exchange(m, fields, nf, layout);   // no-op on a single rank
 }
 
@@ -2420,21 +2434,7 @@ int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
     NLG_TRY(sem_opgradt_lanes(m, nl, p, wl, fg, gate));
     for (int v = 0; v < nl; ++v) {
         const double *gv = gate ? gate[v] : nullptr;
-        if (fg) {
-            if (m->gs.ngroups > 0) {
-                ProfScope ps(m->ctx, P_GS);
-                F3 f = {{w[v][0], w[v][1], w[v][2]}};
-                const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-                hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gv);
-                NLG_HIP(hipGetLastError());
-            }
-            if (m->halo.active) {
-                ProfScope ps(m->ctx, P_GS);
-                NLG_TRY(halo_exchange(m, w[v], 3, true));
-            }
-        } else {
-            NLG_TRY(sem_gs(m, w[v], m->dim, gv));
-        }
+        NLG_TRY(sem_gs(m, w[v], m->dim, gv, fg ? LAYOUT_FG : LAYOUT_NAT));
     }
     return sem_opdiv_lanes(m, nl, wl, out, 1.0, fg ? m->d_mbinv_fg : m->d_mbinv, fg, p, pw_part, gate);
 }
@@ -2446,17 +2446,7 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, cons
         // 3-D: the intermediate velocity-mesh fields use the face-grouped element layout, in which the copies of a
         // shared face are contiguous runs -> coalesced gather-scatter; the rank halo uses index lists in that layout
         NLG_TRY(sem_opgradt(m, p, w, true, gate));
-        if (m->gs.ngroups > 0) {
-            ProfScope ps(m->ctx, P_GS);
-            F3 f = {{w[0], w[1], w[2]}};
-            const int grid = (int)((m->gs.ngroups + NT - 1) / NT);
-            hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.ngroups, m->gs.npairs, m->gs.nquads, f, gate);
-            NLG_HIP(hipGetLastError());
-        }
-        if (m->halo.active) {
-            ProfScope ps(m->ctx, P_GS);
-            NLG_TRY(halo_exchange(m, w, 3, true));
-        }
+        NLG_TRY(sem_gs(m, w, 3, gate, LAYOUT_FG));
         NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part, gate));
         return 0;
     }
@@ -2904,6 +2894,9 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         }
         m->gs.ngroups = (int64_t)groups.size();
         m->gs.nshared = (int64_t)idx.size();
+        m->gs.h_groups.clear();
+        if (m->ctx->distributed())   // halo_setup splits them by "holds a dof another rank shares"
+            for (size_t gi = 0; gi + 1 < off.size(); ++gi) m->gs.h_groups.emplace_back(idx.begin() + off[gi], idx.begin() + off[gi + 1]);
         if (dim == 3 && !groups.empty()) {
             // the same groups in face-grouped numbering, re-sorted by their first index
             std::vector<int> slot((size_t)m->np1);
@@ -2972,6 +2965,8 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         if (!idx.empty()) NLG_HIP(hipMemcpy(m->gs.d_indices, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
     }
     NLG_TRY(halo_setup(m, d->glo_num));
+    m->gs.h_groups.clear();
+    m->gs.h_groups.shrink_to_fit();
     // ---- multiplicity, assembled inverse mass, fused opbinv weights
     {
         hipLaunchKernelGGL(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, 1.0, m->lvn);

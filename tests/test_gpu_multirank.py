@@ -49,6 +49,17 @@ def launch(world, outdir, case):
     return [np.load(os.path.join(outdir, "%s_w%d_r%d.npz" % (case, world, r))) for r in range(world)]
 
 
+def record(case, world, fields, hess, ritz):
+    """measured deviations from the single-rank run, for profiles/ (best effort: the directory may be read-only)"""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "multirank_deviation.txt"), "a") as fh:
+            fh.write("%-6s ranks=%d  fields %.2e  hessenberg %s  ritz %s\n"
+                     % (case, world, fields, "%.2e" % hess if hess is not None else "-", "%.2e" % ritz if ritz is not None else "-"))
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize("case,world", [("box3d", 2), ("per3d", 2), ("box3d", 3), ("jac3d", 2), ("box2d", 2),
                                         ("agg3d", 2), ("cyl", 2), ("cyl", 3), ("heat", 2), ("proj", 2), ("proj", 3)])
 def test_partition_independent(tmp_path, case, world):
@@ -63,24 +74,32 @@ def test_partition_independent(tmp_path, case, world):
     for p in parts:
         np.testing.assert_array_equal(p["scal"], parts[0]["scal"])
         np.testing.assert_array_equal(p["H"], parts[0]["H"])
-    np.testing.assert_allclose(parts[0]["scal"], ref["scal"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(parts[0]["scal"], ref["scal"], rtol=1e-10, atol=1e-12)
     # the two-level pressure preconditioner is global (one aggregate level over all ranks, overlap across the rank
     # boundaries): the iteration counts must stay those of the single-rank run
     assert parts[0]["stats"][0] <= 1.25 * ref["stats"][0] + 5, (parts[0]["stats"], ref["stats"])
     # fields: the slabs concatenated in rank order are the global fields
+    worst = 0.0
     for key in ref.files:
         if key in ("scal", "H", "stats"):
             continue
         got = np.concatenate([p[key].reshape(-1) for p in parts])
         want = ref[key].reshape(-1)
         assert got.shape == want.shape, key
-        tol = 1e-13 if key.startswith("v") else 2e-9      # start vector: same bits up to the global normalisation
+        # start vector: same bits up to the global normalisation; results of the solves: measured 1e-13 .. 4e-12 on the box
+        # meshes and 2e-10 on the cylinder pressure (profiles/r02_multirank_deviation.txt) at solver tolerance 1e-13
+        tol = 1e-13 if key.startswith("v") else 1e-9
         scale = np.max(np.abs(want)) + 1e-300
         assert np.max(np.abs(got - want)) <= tol * scale, (key, np.max(np.abs(got - want)) / scale)
+        worst = max(worst, np.max(np.abs(got - want)) / scale)
     # the Arnoldi factorisation: Hessenberg matrix and hence the Ritz values
     if case in ("heat", "proj"):
+        record(case, world, worst, None, None)
         return
-    np.testing.assert_allclose(parts[0]["H"], ref["H"], rtol=0, atol=2e-9 * np.max(np.abs(ref["H"])))
+    # (north_star: Ritz values to 1e-10 across partitions; measured 1e-15 .. 5e-15, Hessenberg entries 4e-15 .. 3e-14)
+    np.testing.assert_allclose(parts[0]["H"], ref["H"], rtol=0, atol=1e-11 * np.max(np.abs(ref["H"])))
     ev_p = np.sort_complex(np.linalg.eigvals(parts[0]["H"][:-1]))
     ev_r = np.sort_complex(np.linalg.eigvals(ref["H"][:-1]))
-    assert np.max(np.abs(ev_p - ev_r)) <= 1e-8 * np.max(np.abs(ev_r))
+    dev = np.max(np.abs(ev_p - ev_r)) / np.max(np.abs(ev_r))
+    record(case, world, worst, np.max(np.abs(parts[0]["H"] - ref["H"])) / np.max(np.abs(ref["H"])), dev)
+    assert dev <= 1e-12
