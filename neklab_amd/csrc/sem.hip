@@ -2296,7 +2296,9 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
 
 // nl <= 4 pressure fields -> nl velocity-mesh field triples in one launch (block stepper); gates: per-lane done flags (may be null)
 int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate) {
-    ProfScope ps(m->ctx, P_OPGRADT);
+    // (the timed class is ONE kernel instantiation -- the face-grouped variant of the pressure operator in 3-D; the natural-layout
+    //  launches of the right-hand sides, a few per time step, are booked under "vec_ops")
+    ProfScope ps(m->ctx, (m->dim == 2 || face_grouped) ? P_OPGRADT : P_VECOPS);
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
@@ -2358,7 +2360,7 @@ int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *
 // nl <= 4 velocity-mesh field triples -> nl pressure fields in one launch (block stepper)
 int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *out, double scale, double *const *wts, bool face_grouped,
                     const double *const *pdot, double *const *pw_part, const double *const *gate) {
-    ProfScope ps(m->ctx, P_OPDIV);
+    ProfScope ps(m->ctx, (m->dim == 2 || face_grouped) ? P_OPDIV : P_VECOPS);
     CF3 wt = {{wts ? wts[0] : nullptr, wts ? wts[1] : nullptr, (wts && m->dim == 3) ? wts[2] : nullptr}};
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
