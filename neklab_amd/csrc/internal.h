@@ -271,6 +271,7 @@ struct nlg_mesh {
     std::vector<int> h_slot;   // natural point -> face-grouped slot inside an element (3-D)
     std::vector<int> h_slot_xp;   // natural point -> x-planes-first slot (3-D)
     int *d_slot_xp = nullptr;
+    int *d_slot_fg = nullptr;   // device copy of h_slot (lx1 > 8 pressure kernels read it instead of computing the slot)
     double *d_vmult_xp = nullptr;
     nlg_gs gs;
     double volvm1 = 0, volvm2 = 0;

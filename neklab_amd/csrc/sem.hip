@@ -1353,6 +1353,235 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int
     }
 }
 
+// ---- lx1 > 8 variants: one velocity component at a time through ONE LDS array ------------------------------------
+// With NC = 1 the kernels above need sA (3 N2^2 N) + sB (2 N2 N^2) doubles = 52 KB at lx1 = 12: three 128-thread blocks per CU,
+// 1.5 waves per SIMD, nothing to hide the global-load -> LDS -> barrier chain behind (14 - 31 % of the HBM roofline measured).
+// Here the y stage runs IN PLACE: the LDS array is organised in regions, one per (i2, k) column of the y stage, of 3 N2 slots
+// (+1 pad).  The z stage of opgradt fills slots [j N2 + j2] (arrays A0 | A1 | A2); the thread that owns the region reads its
+// 3 N2 values into registers and overwrites them with the 2 N <= 3 N2 values B0 | B1 (slots [j], [N + j]); the x stage gathers
+// its columns across regions.  opdiv runs the same three stages backwards and keeps the sum over arrays and components of a
+// pressure point in the registers of the thread that owns its z column, so the per-array products never go through LDS.
+// 30 KB (lx1 = 12) / 16 KB (lx1 = 10) per block: 5 / 10 blocks per CU.  The 1-D matrices come from global memory through
+// wave-uniform scalar loads (compile-time indices on `const __restrict__` kernel arguments): as by-value arguments the 4 x 120
+// doubles of lx1 = 12 need 960 SGPRs, i.e. 500 of them spilled to VGPR lanes and one v_readlane per FMA.
+template <int N>
+struct PBlockN {
+    static constexpr int NTB = (N * N <= 128) ? 128 : 192;
+    static constexpr int RS = (3 * (N - 2)) | 1;   // odd region stride: the columns of a stage fall on different banks
+};
+
+template <int N, bool FG>
+__global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl) {
+    constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
+    constexpr int RS = PBlockN<N>::RS;
+    static_assert(2 * N <= 3 * N2, "in-place y stage needs 2 N <= 3 N2");
+    __shared__ double sR[N2 * N * RS];
+    const int tid = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    for (int lv = 0; lv < nl; ++lv) {
+        if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
+        const double *pe = pl.p[lv] + e * NP2;
+        double pv[N2];
+        if (tid < NS2) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) pv[k2] = pe[tid + NS2 * k2];
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (i > 0 || lv > 0) __syncthreads();   // the x stage of the previous pass has read its columns
+            // z stage: thread = (i2, j2) column, all three arrays
+            if (tid < NS2) {
+                const int i2 = tid % N2, j2 = tid / N2;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double *gp = g.p[j * 3 + i] + e * NP2;
+                    double q[N2];
+#pragma unroll
+                    for (int k2 = 0; k2 < N2; ++k2) q[k2] = gp[tid + NS2 * k2] * pv[k2];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int k2 = 0; k2 < N2; ++k2) a += (j < 2 ? mIt[k * N2 + k2] : mDt[k * N2 + k2]) * q[k2];
+                        sR[(i2 + N2 * k) * RS + j * N2 + j2] = a;
+                    }
+                }
+            }
+            __syncthreads();
+            // y stage in place: B0 = I^T_y A0 ; B1 = D^T_y A1 + I^T_y A2
+            if (tid < N2 * N) {
+                double *r = sR + tid * RS;
+                double a0[N2], a1[N2], a2[N2];
+#pragma unroll
+                for (int j2 = 0; j2 < N2; ++j2) {
+                    a0[j2] = r[j2];
+                    a1[j2] = r[N2 + j2];
+                    a2[j2] = r[2 * N2 + j2];
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                    for (int j2 = 0; j2 < N2; ++j2) {
+                        b0 += mIt[j * N2 + j2] * a0[j2];
+                        b1 += mDt[j * N2 + j2] * a1[j2] + mIt[j * N2 + j2] * a2[j2];
+                    }
+                    r[j] = b0;
+                    r[N + j] = b1;
+                }
+            }
+            __syncthreads();
+            // x stage: w = D^T_x B0 + I^T_x B1, straight to HBM
+            if (tid < N * N) {
+                const int jj = tid % N, kk = tid / N;
+                double b0[N2], b1[N2];
+#pragma unroll
+                for (int i2 = 0; i2 < N2; ++i2) {
+                    b0[i2] = sR[(i2 + N2 * kk) * RS + jj];
+                    b1[i2] = sR[(i2 + N2 * kk) * RS + N + jj];
+                }
+                double *wp = wl.p[lv][i] + e * NP1;
+                int sl[N];   // face-grouped slots from a table: computing them branches on the boundary class of every point
+#pragma unroll
+                for (int a = 0; a < N; ++a) sl[a] = FG ? fgtab[a + N * tid] : a + N * tid;
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int i2 = 0; i2 < N2; ++i2) v += mDt[a * N2 + i2] * b0[i2] + mIt[a * N2 + i2] * b1[i2];
+                    wp[sl[a]] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int N, bool FG>
+__global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const double *__restrict__ mIm, const double *__restrict__ mDm, const int *__restrict__ fgtab, CF9 g, CF3L ul, CF3 wt, P4 outl, double scale,
+                                                             CP4 pdotl, P4 partl, CP4 gatel, int nl) {
+    constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
+    constexpr int RS = PBlockN<N>::RS, NTB = PBlockN<N>::NTB;
+    __shared__ double sR[N2 * N * RS];
+    __shared__ double red[2 * (NTB / 64)];
+    const int tid = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    for (int lv = 0; lv < nl; ++lv) {
+        if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
+        double acc[N2];
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) acc[k2] = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            if (i > 0 || lv > 0) __syncthreads();   // the z stage of the previous pass has read its columns
+            // x stage from HBM: B0 = D_x u, B1 = I_x u
+            if (tid < N * N) {
+                const int jj = tid % N, kk = tid / N;
+                const double *up = ul.p[lv][i] + e * NP1;
+                const double *wp = wt.p[i];
+                int sl[N];
+#pragma unroll
+                for (int a = 0; a < N; ++a) sl[a] = FG ? fgtab[a + N * tid] : a + N * tid;
+                double uu[N];
+#pragma unroll
+                for (int a = 0; a < N; ++a) uu[a] = up[sl[a]];
+                if (wp) {
+                    wp += e * NP1;
+#pragma unroll
+                    for (int a = 0; a < N; ++a) uu[a] *= wp[sl[a]];
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < N2; ++i2) {
+                    double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                    for (int a = 0; a < N; ++a) {
+                        b0 += mDm[i2 * N + a] * uu[a];
+                        b1 += mIm[i2 * N + a] * uu[a];
+                    }
+                    sR[(i2 + N2 * kk) * RS + jj] = b0;
+                    sR[(i2 + N2 * kk) * RS + N + jj] = b1;
+                }
+            }
+            __syncthreads();
+            // y stage in place: C0 = I_y B0 ; C1 = D_y B1 ; C2 = I_y B1
+            if (tid < N2 * N) {
+                double *r = sR + tid * RS;
+                double b0[N], b1[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    b0[j] = r[j];
+                    b1[j] = r[N + j];
+                }
+#pragma unroll
+                for (int j2 = 0; j2 < N2; ++j2) {
+                    double c0v = 0.0, c1v = 0.0, c2v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        c0v += mIm[j2 * N + j] * b0[j];
+                        c1v += mDm[j2 * N + j] * b1[j];
+                        c2v += mIm[j2 * N + j] * b1[j];
+                    }
+                    r[j2] = c0v;
+                    r[N2 + j2] = c1v;
+                    r[2 * N2 + j2] = c2v;
+                }
+            }
+            __syncthreads();
+            // z stage: thread = (i2, j2) column; the metric products of the three arrays are summed in registers
+            if (tid < NS2) {
+                const int i2 = tid % N2, j2 = tid / N2;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double *gp = g.p[j * 3 + i] + e * NP2;
+                    double cc[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) cc[k] = sR[(i2 + N2 * k) * RS + j * N2 + j2];
+#pragma unroll
+                    for (int k2 = 0; k2 < N2; ++k2) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) a += (j < 2 ? mIm[k2 * N + k] : mDm[k2 * N + k]) * cc[k];
+                        acc[k2] += gp[tid + NS2 * k2] * a;
+                    }
+                }
+            }
+        }
+        double *__restrict__ out = outl.p[lv];
+        const double *__restrict__ pdot = pdotl.p[lv];
+        double *__restrict__ part = partl.p[lv];
+        double spw = 0.0, sw = 0.0;
+        if (tid < NS2) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const double v = scale * acc[k2];
+                out[e * NP2 + tid + NS2 * k2] = v;
+                if (part) {
+                    spw += pdot[e * NP2 + tid + NS2 * k2] * v;
+                    sw += v;
+                }
+            }
+        }
+        if (part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                spw += __shfl_down(spw, o, 64);
+                sw += __shfl_down(sw, o, 64);
+            }
+            if ((tid & 63) == 0) {
+                red[tid >> 6] = spw;
+                red[NTB / 64 + (tid >> 6)] = sw;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double a = 0.0, b = 0.0;
+                for (int q = 0; q < NTB / 64; ++q) {
+                    a += red[q];
+                    b += red[NTB / 64 + q];
+                }
+                part[e] = a;
+                part[E + e] = b;
+            }
+        }
+    }
+}
+
 // ---- 2-D versions (several elements per block would be faster; correctness first) -------------------
 template <int N>
 __global__ __launch_bounds__(NT) void k_opgradt2(int64_t E, const double *__restrict__ Itg,
@@ -2269,6 +2498,11 @@ int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2) {
     return 0;
 }
 
+static bool pkern_old() {   // NLG_PKERN_OLD=1: the two-array kernels k_opgradt3 / k_opdiv3<N, 1> for lx1 > 8 (A/B runs)
+    static const bool v = getenv("NLG_PKERN_OLD") && atoi(getenv("NLG_PKERN_OLD")) != 0;
+    return v;
+}
+
 template <int N>
 static void fill_pmats(const nlg_mesh *m, PMats<N> &M) {
     const int n2 = N - 2;
@@ -2302,6 +2536,7 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
+        const bool old_big = pkern_old();
         CP4 pl, gl;
         F3L wl;
         for (int v = 0; v < 4; ++v) {
@@ -2317,6 +2552,10 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
             hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else if (N_ <= 8)                                                                                              \
             hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
+        else if (!old_big && face_grouped)                                                                             \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);    \
+        else if (!old_big)                                                                                             \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);   \
         else if (face_grouped)                                                                                         \
             hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
@@ -2365,6 +2604,7 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
     CF9 g = rst2w_ptrs(m);
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
+        const bool old_big = pkern_old();
         CF3L ul;
         P4 ol, pl;
         CP4 dl, gl;
@@ -2383,6 +2623,10 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
             hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (N_ <= 8)                                                                                              \
             hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+        else if (!old_big && face_grouped)                                                                             \
+            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+        else if (!old_big)                                                                                             \
+            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (face_grouped)                                                                                         \
             hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else                                                                                                           \
@@ -2904,6 +3148,8 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
             std::vector<int> slot((size_t)m->np1);
             for (int p = 0; p < m->np1; ++p) slot[p] = fg_slot(n, p % n, (p / n) % n, p / (n * n));
             m->h_slot = slot;
+            NLG_HIP(hipMalloc(&m->d_slot_fg, sizeof(int) * slot.size()));
+            NLG_HIP(hipMemcpy(m->d_slot_fg, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
             std::vector<std::vector<int>> gl(groups.size());
             for (size_t gi = 0; gi + 1 < off.size(); ++gi) {
                 for (int q = off[gi]; q < off[gi + 1]; ++q) gl[gi].push_back((idx[q] / m->np1) * m->np1 + slot[idx[q] % m->np1]);
@@ -3092,6 +3338,7 @@ int nlg_mesh_destroy(nlg_mesh *m) {
     if (m->d_lglel) hipFree(m->d_lglel);
     halo_free(m);
     pprec_free(m);
+    if (m->d_slot_fg) hipFree(m->d_slot_fg);
     if (m->gs.d_offsets_fg) hipFree(m->gs.d_offsets_fg);
     if (m->gs.d_indices_fg) hipFree(m->gs.d_indices_fg);
     if (m->gs.d_offsets_xp) hipFree(m->gs.d_offsets_xp);
