@@ -3,7 +3,7 @@
 // Role in the reference: `preconditioner = semg_xxt` of the pressure solve inside nek_advance
 // (/root/reference/examples/cylinder/stability/direct/1cyl.par:21); Nek5000's implementation is not in the
 // reference tree.  This is a restatement of the published idea (Fischer 1997; Lottes & Fischer 2005) in its
-// simplest robust form, chosen from a numpy prototype (scripts/precond_proto.py: Jacobi 680 iterations,
+// simplest robust form, chosen from a numpy prototype (docs/prototypes/precond_proto.py: Jacobi 680 iterations,
 // element-wise FDM 192, FDM + exact piecewise-constant coarse grid 81, FDM + the V-cycle below 110, all at
 // E = 512, independent of E for the two-level variants):
 //   M^-1 r = sum_e R_e^T Etilde_e^-1 R_e r                     (element-wise fast diagonalisation, additive)
@@ -13,7 +13,7 @@
 //              eigen-decompositions (n2 x n2 per direction).
 //   R_1     : columns = the trilinear (bilinear in 2-D) hat functions of the element vertices evaluated at the GL
 //             pressure points; continuous across elements although the pressure space is not.  Prototype
-//             (scripts/precond_proto2.py, precond_proto3.py, explicit sparse E): against the piecewise-constant
+//             (docs/prototypes/precond_proto2.py, precond_proto3.py, explicit sparse E): against the piecewise-constant
 //             space used first (R_0) the vertex space halves the iteration count (73 -> 37 at lx1 = 8 with exact
 //             element blocks; 30 at lx1 = 6), mesh-independent, and one V-cycle is as good as the exact solve.
 //   A_c = R_1^T E R_1 : Galerkin, sparse nvert x nvert (125-point on structured meshes).  Assembled by probing E on
@@ -986,7 +986,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         std::vector<double> Bl((size_t)3 * n), bq((size_t)3 * n), Ae((size_t)mx * mx), Be((size_t)mx * mx), Sx, lx;
         std::vector<double> Dl((size_t)mx * 3 * n), Il((size_t)mx * 3 * n);   // rows: the mx extended pressure points
         // symmetric weighting D M D, D = diag(count^-1/2), count = number of extended subdomains that contain the point
-        // (1 + one per face neighbour whose ghost layer it is).  Prototype (scripts/precond_proto5.py, 6^3 elements,
+        // (1 + one per face neighbour whose ghost layer it is).  Prototype (docs/prototypes/precond_proto5.py, 6^3 elements,
         // lx1 = 6): unweighted 21 / 29 iterations with the exact / approximate coarse solve, weighted 14 / 18;
         // without overlap 29.
         std::vector<double> hwq((size_t)E * np2, 1.0);
