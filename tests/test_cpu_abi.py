@@ -107,7 +107,11 @@ def test_fortran_shim_compiles_against_the_abstract_types():
     r = subprocess.run(["make", "-s", "-C", fdir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.exists(os.path.join(fdir, "_build", "arnoldi_driver"))
+    assert os.path.exists(os.path.join(fdir, "_build", "stability_driver"))
+    # the modules carry the reference's names (src/neklab_analysis.f90:16-18 `use`s them unchanged)
+    for mod in ("neklab_vectors", "neklab_linops", "neklab_utils", "neklab_analysis", "neklab"):
+        assert re.search(r"^\s*module\s+%s\b" % mod, open(os.path.join(fdir, mod + ".f90")).read(), re.M | re.I), mod
     # every C symbol the shim binds is declared in the header
-    txt = open(os.path.join(fdir, "neklab_gpu.f90")).read()
+    txt = open(os.path.join(fdir, "neklab_gpu_capi.f90")).read()
     bound = set(re.findall(r'name="(nlg_[a-z0-9_A-Z]+)"', txt))
-    assert bound and bound <= set(declared_symbols())
+    assert len(bound) > 40 and bound <= set(declared_symbols()), bound - set(declared_symbols())
