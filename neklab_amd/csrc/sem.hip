@@ -1091,7 +1091,7 @@ struct PBlock {
 };
 
 // opgradt: w_i = sum_j T_j^T (g_ji o p),  T_j = (D12 along r_j, I12 otherwise)
-template <int N, int NC, bool FG>
+template <int N, int NC, bool FG, bool ML = true>
 __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(int64_t E, PMats<N> M, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
     constexpr int NT = PBlock<N, NC>::NTB;   // (shadows the file-level block size: 128 threads when one component is in flight)
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(i
     const int64_t e = blockIdx.x;
     // lanes (the vectors of a block step) one after the other: the nine metric arrays of the element (15.5 KB at lx1 = 8) come
     // from HBM for the first lane and from L1 / L2 for the others
-    for (int lv = 0; lv < nl; ++lv) {
+    for (int lv = 0; lv < (ML ? nl : 1); ++lv) {   // ML = false: the single-vector kernel (a runtime lane loop costs it 25 - 30 %)
     if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;   // this lane's PCG has converged (device-side done flag, block-uniform)
     const double *pe = pl.p[lv] + e * NP2;
     for (int c0 = 0; c0 < 3; c0 += NC) {
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opgradt3(i
 // opdiv: out = scale * sum_i sum_j g_ji o (T_j (wt_i o u_i)); wt (may hold nulls) fuses mask * binvm1 into the load
 // `pdot`/`part` (may be null): first-stage sums of the surrounding PCG, part[e] = sum_q pdot_q out_q and
 // part[E + e] = sum_q out_q over the element -- saves a separate pass over two pressure-mesh vectors.
-template <int N, int NC, bool FG>
+template <int N, int NC, bool FG, bool ML = true>
 __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int64_t E, PMats<N> M, CF9 g, CF3L ul, CF3 wt, P4 outl,
                                                double scale, CP4 pdotl, P4 partl, CP4 gatel, int nl) {
     constexpr int N2 = N - 2, NS2 = N2 * N2;
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int
     const int64_t e = blockIdx.x;
     constexpr int NACC = (NP2 + NT - 1) / NT;
     // lanes one after the other: weights (mask * binvm1) and metric arrays of the element are re-read from L1 / L2
-    for (int lv = 0; lv < nl; ++lv) {
+    for (int lv = 0; lv < (ML ? nl : 1); ++lv) {   // ML = false: the single-vector kernel (a runtime lane loop costs it 25 - 30 %)
     if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
     double *__restrict__ out = outl.p[lv];
     const double *__restrict__ pdot = pdotl.p[lv];
@@ -1370,7 +1370,7 @@ struct PBlockN {
     static constexpr int RS = (3 * (N - 2)) | 1;   // odd region stride: the columns of a stage fall on different banks
 };
 
-template <int N, bool FG>
+template <int N, bool FG, bool ML = true>
 __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl) {
     constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
     constexpr int RS = PBlockN<N>::RS;
@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
     __shared__ double sR[N2 * N * RS];
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
-    for (int lv = 0; lv < nl; ++lv) {
+    for (int lv = 0; lv < (ML ? nl : 1); ++lv) {   // ML = false: the single-vector kernel (a runtime lane loop costs it 25 - 30 %)
         if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
         const double *pe = pl.p[lv] + e * NP2;
         double pv[N2];
@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
     }
 }
 
-template <int N, bool FG>
+template <int N, bool FG, bool ML = true>
 __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const double *__restrict__ mIm, const double *__restrict__ mDm, const int *__restrict__ fgtab, CF9 g, CF3L ul, CF3 wt, P4 outl, double scale,
                                                              CP4 pdotl, P4 partl, CP4 gatel, int nl) {
     constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
     __shared__ double red[2 * (NTB / 64)];
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
-    for (int lv = 0; lv < nl; ++lv) {
+    for (int lv = 0; lv < (ML ? nl : 1); ++lv) {   // ML = false: the single-vector kernel (a runtime lane loop costs it 25 - 30 %)
         if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
         double acc[N2];
 #pragma unroll
@@ -1773,7 +1773,7 @@ __global__ void k_conv_combine_adj(int dim, int64_t n, CF3 Ur, CF3 du, double *a
 // 160 KB per workgroup on gfx950: one block per CU): lx1 = 9, 10 keep u in LDS as before (104 KB at lx1 = 10); at lx1 = 12
 // (ULDS = false) the stage arrays alone take 134 KB and the x stages read u from global memory (41 KB per element, L2).
 // NTC threads: one per fine-mesh column along z (ND^2 = 324 at lx1 = 12 -> 384 threads).
-template <int N, int ND, int NTC, bool ULDS, bool DYN>
+template <int N, int ND, int NTC, bool ULDS, bool DYN, bool ML = true>
 __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
                                                  CF3 Ur, CF9 GU, CF3L ul, F3L outl, int nl, int adjoint) {
     constexpr int NP = N * N * N, NPD = ND * ND * ND;
@@ -1797,7 +1797,7 @@ __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const dou
     if (e >= E) return;
     // lanes (the vectors of a block step) one after the other: the twelve base-flow fields of the element are then served by
     // L2 / the Infinity Cache for every lane after the first
-    for (int lv = 0; lv < nl; ++lv) {
+    for (int lv = 0; lv < (ML ? nl : 1); ++lv) {   // ML = false: the single-vector kernel (a runtime lane loop costs it 25 - 30 %)
     if (ULDS)
         for (int t = tid; t < 3 * NP; t += NT) {
             const int c = t / NP, q = t % NP;
@@ -2544,25 +2544,31 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
             gl.p[v] = (v < nl && gate) ? gate[v] : nullptr;
             for (int c = 0; c < 3; ++c) wl.p[v][c] = v < nl ? w[v][c] : nullptr;
         }
-#define GT3(N_)                                                                                                        \
+#define GT3_(N_, ML_)                                                                                                        \
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);    \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);    \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);   \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);   \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);   \
+            hipLaunchKernelGGL((k_opgradt3<N_, 1, false, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);   \
     }
+#define GT3(N_)           \
+    if (nl == 1)          \
+        GT3_(N_, false)   \
+    else                  \
+        GT3_(N_, true)
         NLG_FOR_N(GT3)
 #undef GT3
+#undef GT3_
     } else {
         for (int v = 0; v < nl; ++v) {
             F3 cw = {{w[v][0], w[v][1], nullptr}};
@@ -2615,25 +2621,31 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
             dl.p[v] = (v < nl && pdot) ? pdot[v] : nullptr;
             gl.p[v] = (v < nl && gate) ? gate[v] : nullptr;
         }
-#define DV3(N_)                                                                                                        \
+#define DV3_(N_, ML_)                                                                                                        \
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped)                                                                                   \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, true>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (N_ <= 8)                                                                                              \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, false>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, true>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, false>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            hipLaunchKernelGGL((k_opdiv3<N_, 1, false, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
     }
+#define DV3(N_)           \
+    if (nl == 1)          \
+        DV3_(N_, false)   \
+    else                  \
+        DV3_(N_, true)
         NLG_FOR_N(DV3)
 #undef DV3
+#undef DV3_
     } else {
         for (int v = 0; v < nl; ++v) {
             CF3 cu = {{u[v][0], u[v][1], nullptr}};
@@ -2882,8 +2894,12 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
         CF9 cg;
         for (int q = 0; q < 9; ++q) cg.p[q] = GU[q];
 #define CV3(N_)                                                                                                       \
-    hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
-                       (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);
+    if (nl == 1)                                                                                                      \
+        hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false, false>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
+                           (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);          \
+    else                                                                                                              \
+        hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false, true>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
+                           (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);
 #define CV3D(N_, NTC_, ULDS_)                                                                                          \
     {                                                                                                                  \
         constexpr int ND_ = (3 * N_) / 2, NQ_ = N_ | 1, NDQ_ = ND_ | 1;                                                \
