@@ -47,7 +47,10 @@ int nlg_ctx_destroy(nlg_ctx *ctx);
 int nlg_ctx_sync(nlg_ctx *ctx);
 /* RCCL communicator over xGMI: rank 0 calls nlg_comm_unique_id, the 128 bytes are broadcast by the
  * host program (MPI_Bcast in a Nek5000 host, torch.distributed in bench.py), every rank then calls
- * nlg_ctx_comm_init.  Replaces the MPI_Allreduce inside glsc3 (src/vectors/real_vectors.f90:217-224). */
+ * nlg_ctx_comm_init.  Replaces the MPI_Allreduce inside glsc3 (src/vectors/real_vectors.f90:217-224) and gslib's gs_op
+ * behind opdssum (real_vectors.f90:100-104): per gather-scatter the library sums the groups that hold a dof another rank
+ * shares, packs, exchanges (grouped ncclSend / ncclRecv), sums the interior groups and unpacks; with NLG_HALO_OVERLAP=1 in
+ * the environment the exchange runs on a side stream beside the interior groups. */
 int nlg_comm_unique_id(void *out128);
 int nlg_ctx_comm_init(nlg_ctx *ctx, int rank, int nranks, const void *unique_id128);
 int nlg_ctx_rank(const nlg_ctx *ctx, int *rank, int *nranks);

@@ -1398,7 +1398,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
 
     if (!multi) {
         NLG_TRY(up(Acc, &P.d_Ainv));
-        NLG_TRY(gj_inverse(P.d_Ainv, na));
+        NLG_TRY(spd_inverse_dev(P.d_Ainv, na));   // (library Cholesky above NLG_LIB_INVERSE_MIN unknowns, else Gauss-Jordan)
         P.na_max = P.ncols = na;
         NLG_HIP(hipMalloc(&P.d_ra, sizeof(double) * (size_t)std::max(na, 1)));
         P.ready = true;
