@@ -27,7 +27,7 @@ import statistics
 import sys
 
 CLASSES = {      # bench.py kernel class -> regex on the demangled kernel name
-    "gs": r"^k_gs<3>", "axhelm": r"^k_axhelm3[rc]?<", "opgradt": r"^k_opgradt3n?<.*true>", "opdiv": r"^k_opdiv3n?<.*true>",
+    "gs": r"^k_gs<3>", "axhelm": r"^k_axhelm3[rc]?<", "opgradt": r"^k_opgradt3(<\d+, \d+|n<\d+), true", "opdiv": r"^k_opdiv3(<\d+, \d+|n<\d+), true",
     "block_dot": r"^k_block_dot<", "axpy_dot": r"^k_block_axpy_dot<", "block_axpy": r"^k_block_axpy$", "cg_vec": r"^k_cg_update<3>",
     "conv": r"^k_conv3<", "fdm": r"^k_fdm_ext<",
 }
@@ -65,9 +65,9 @@ def classify(rows):
     for _, k, v in rows:
         site = ""
         if k.startswith("k_gs<"):
-            if re.match(r"k_axhelm3rb?<.*true>", prev):
+            if re.match(r"k_axhelm3rb?<\d+, \d+, true", prev):
                 site = "slab-permuted (velocity PCG)"
-            elif re.match(r"k_opgradt3n?<.*true>", prev) or re.match(r"k_fdm|k_sch|k_q1", prev):
+            elif re.match(r"k_opgradt3(<\d+, \d+|n<\d+), true", prev) or re.match(r"k_fdm|k_sch|k_q1", prev):
                 site = "face-grouped (pressure operator / Schwarz exchange)"
             else:
                 site = "natural"
