@@ -1361,12 +1361,14 @@ __global__ __launch_bounds__(((NC == 1 && N > 8) ? 128 : 256)) void k_opdiv3(int
 // 3 N2 values into registers and overwrites them with the 2 N <= 3 N2 values B0 | B1 (slots [j], [N + j]); the x stage gathers
 // its columns across regions.  opdiv runs the same three stages backwards and keeps the sum over arrays and components of a
 // pressure point in the registers of the thread that owns its z column, so the per-array products never go through LDS.
-// 30 KB (lx1 = 12) / 16 KB (lx1 = 10) per block: 5 / 10 blocks per CU.  The 1-D matrices come from global memory through
+// 30 KB (lx1 = 12) / 16 KB (lx1 = 10) per block: 5 / 10 blocks per CU.  Also used at lx1 = 8 with ONE wave per element
+// (64 x-stage columns = 64 lanes, 7.3 KB, 77 VGPRs: 21 waves per CU, no cross-wave barrier): 81 / 87 us instead of 86 / 93 us
+// for k_opgradt3 / k_opdiv3<8, 3> with their 256-thread blocks.  The 1-D matrices come from global memory through
 // wave-uniform scalar loads (compile-time indices on `const __restrict__` kernel arguments): as by-value arguments the 4 x 120
 // doubles of lx1 = 12 need 960 SGPRs, i.e. 500 of them spilled to VGPR lanes and one v_readlane per FMA.
 template <int N>
 struct PBlockN {
-    static constexpr int NTB = (N * N <= 128) ? 128 : 192;
+    static constexpr int NTB = (N * N <= 64) ? 64 : ((N * N <= 128) ? 128 : 192);
     static constexpr int RS = (3 * (N - 2)) | 1;   // odd region stride: the columns of a stage fall on different banks
 };
 
@@ -2537,6 +2539,7 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
         const bool old_big = pkern_old();
+        static const bool n8new = !(getenv("NLG_PKERN_N8") && atoi(getenv("NLG_PKERN_N8")) == 0);   // lx1 = 8: one wave per element through the in-place kernels (5 - 6 % faster than <8, 3>; NLG_PKERN_N8=0 for A/B)
         CP4 pl, gl;
         F3L wl;
         for (int v = 0; v < 4; ++v) {
@@ -2548,14 +2551,14 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
-        if (N_ <= 8 && face_grouped)                                                                                   \
+        if (N_ <= 8 && face_grouped && !(N_ == 8 && n8new))                                                            \
             hipLaunchKernelGGL((k_opgradt3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
-        else if (N_ <= 8)                                                                                              \
+        else if (N_ <= 8 && !(N_ == 8 && n8new))                                                                       \
             hipLaunchKernelGGL((k_opgradt3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);    \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);    \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ > 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);   \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);   \
         else if (face_grouped)                                                                                         \
             hipLaunchKernelGGL((k_opgradt3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
@@ -2611,6 +2614,7 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
     hipStream_t s = m->ctx->stream;
     if (m->dim == 3) {
         const bool old_big = pkern_old();
+        static const bool n8new = !(getenv("NLG_PKERN_N8") && atoi(getenv("NLG_PKERN_N8")) == 0);   // lx1 = 8: one wave per element through the in-place kernels (5 - 6 % faster than <8, 3>; NLG_PKERN_N8=0 for A/B)
         CF3L ul;
         P4 ol, pl;
         CP4 dl, gl;
@@ -2625,14 +2629,14 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
     {                                                                                                                  \
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
-        if (N_ <= 8 && face_grouped)                                                                                   \
+        if (N_ <= 8 && face_grouped && !(N_ == 8 && n8new))                                                            \
             hipLaunchKernelGGL((k_opdiv3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
-        else if (N_ <= 8)                                                                                              \
+        else if (N_ <= 8 && !(N_ == 8 && n8new))                                                                       \
             hipLaunchKernelGGL((k_opdiv3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            hipLaunchKernelGGL((k_opdiv3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opdiv3n<(N_ > 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            hipLaunchKernelGGL((k_opdiv3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (face_grouped)                                                                                         \
             hipLaunchKernelGGL((k_opdiv3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else                                                                                                           \
