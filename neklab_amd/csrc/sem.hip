@@ -1388,6 +1388,16 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) pv[k2] = pe[tid + NS2 * k2];
         }
+        // lx1 <= 8 (one wave per element, registers to spare): the metric columns of the NEXT component are requested before
+        // the y and x stages of the current one, so that their latency is hidden behind two LDS stages
+        constexpr bool PF = N <= 8;
+        double gq[PF ? 3 : 1][PF ? N2 : 1];
+        if (PF && tid < NS2) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) gq[PF ? j : 0][PF ? k2 : 0] = g.p[j * 3 + 0][e * NP2 + tid + NS2 * k2];
+        }
         for (int i = 0; i < 3; ++i) {
             if (i > 0 || lv > 0) __syncthreads();   // the x stage of the previous pass has read its columns
             // z stage: thread = (i2, j2) column, all three arrays
@@ -1398,7 +1408,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                     const double *gp = g.p[j * 3 + i] + e * NP2;
                     double q[N2];
 #pragma unroll
-                    for (int k2 = 0; k2 < N2; ++k2) q[k2] = gp[tid + NS2 * k2] * pv[k2];
+                    for (int k2 = 0; k2 < N2; ++k2) q[k2] = (PF ? gq[PF ? j : 0][PF ? k2 : 0] : gp[tid + NS2 * k2]) * pv[k2];
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
                         double a = 0.0;
@@ -1406,6 +1416,12 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                         for (int k2 = 0; k2 < N2; ++k2) a += (j < 2 ? mIt[k * N2 + k2] : mDt[k * N2 + k2]) * q[k2];
                         sR[(i2 + N2 * k) * RS + j * N2 + j2] = a;
                     }
+                }
+                if (PF && i < 2) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int k2 = 0; k2 < N2; ++k2) gq[PF ? j : 0][PF ? k2 : 0] = g.p[j * 3 + i + 1][e * NP2 + tid + NS2 * k2];
                 }
             }
             __syncthreads();
@@ -1471,8 +1487,16 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
         double acc[N2];
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) acc[k2] = 0.0;
+        constexpr bool PF = N <= 8;   // lx1 <= 8: the metric columns of a pass are requested at its start, two LDS stages before their use
         for (int i = 0; i < 3; ++i) {
             if (i > 0 || lv > 0) __syncthreads();   // the z stage of the previous pass has read its columns
+            double gq[PF ? 3 : 1][PF ? N2 : 1];
+            if (PF && tid < NS2) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int k2 = 0; k2 < N2; ++k2) gq[PF ? j : 0][PF ? k2 : 0] = g.p[j * 3 + i][e * NP2 + tid + NS2 * k2];
+            }
             // x stage from HBM: B0 = D_x u, B1 = I_x u
             if (tid < N * N) {
                 const int jj = tid % N, kk = tid / N;
@@ -1540,7 +1564,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
                         double a = 0.0;
 #pragma unroll
                         for (int k = 0; k < N; ++k) a += (j < 2 ? mIm[k2 * N + k] : mDm[k2 * N + k]) * cc[k];
-                        acc[k2] += gp[tid + NS2 * k2] * a;
+                        acc[k2] += (PF ? gq[PF ? j : 0][PF ? k2 : 0] : gp[tid + NS2 * k2]) * a;
                     }
                 }
             }
