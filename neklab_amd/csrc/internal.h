@@ -228,6 +228,7 @@ struct nlg_pprec {
     // velocity-shaped exchange array (face-grouped layout) and the zero-denominator threshold
     bool overlap = false;
     int *d_exttab = nullptr;                     // [n^3] packed per-point constants of the extended grid (k_fdm_ext)
+    int *d_wslot = nullptr;                      // [n2^3][3] face slot of W next to a pressure point per direction, -1 = none
     double *d_Sx = nullptr, *d_lamx = nullptr, *d_W = nullptr, *d_wq = nullptr;   // d_wq: count^-1/2 weights [E][n2^3]
     double thrx = 0.0;
     int *d_agg = nullptr, *d_ap = nullptr, *d_am = nullptr;

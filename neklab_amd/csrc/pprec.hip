@@ -591,6 +591,92 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restri
     }
 }
 
+// The same for 3-D with the pressure-mesh size known at compile time (lx1 = 8, 10, 12): the point loop is unrolled, so all loads
+// of a wave are in flight at once, the index arithmetic is constant-folded, and the face slots of W come from a table
+// (wslot[q][d]: slot of the face point next to pressure point q in direction d, -1 if q is not in that boundary layer)
+// instead of fg_slot's branches.  Same summation order as the generic kernel: bit-identical results.
+template <int N2>
+__global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__restrict__ flag, int64_t E, Hat hat, double *__restrict__ r,
+                                                            double *__restrict__ t, double *__restrict__ W, const double *__restrict__ wq,
+                                                            const int *__restrict__ wslot, nlg_pcg_upd u) {
+    __shared__ double srr[4];
+    if (flag && flag[0] != 0.0) return;
+    constexpr int NP2 = N2 * N2 * N2, N = N2 + 2, NIT = (NP2 + 63) / 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 4 + wid;
+    const bool act = e < E;
+    const bool upd = u.alpha != nullptr;
+    const double alpha = upd ? u.alpha[0] : 0.0, wmean = upd ? u.wmean[0] : 0.0;
+    double rr = 0.0;
+    double a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = 0.0;
+    double v[NIT], pv[NIT], wv[NIT], xv[NIT], nv[NIT], qv[NIT];
+    int sl[NIT][3];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = lane + 64 * it;
+        const bool on = act && q < NP2;
+        const int64_t i = e * NP2 + (on ? q : 0);
+        v[it] = on ? r[i] : 0.0;
+        if (upd) {
+            pv[it] = on ? u.p[i] : 0.0;
+            wv[it] = on ? u.w[i] : 0.0;
+            xv[it] = on ? u.x[i] : 0.0;
+            nv[it] = on ? u.nw[i] : 0.0;
+        }
+        if (W) {
+            qv[it] = on ? wq[i] : 0.0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sl[it][d] = on ? wslot[3 * q + d] : -1;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = lane + 64 * it;
+        if (!(act && q < NP2)) continue;
+        const int64_t i = e * NP2 + q;
+        double vv = v[it];
+        if (upd) {
+            u.x[i] = xv[it] + alpha * pv[it];
+            vv -= alpha * (wv[it] - wmean);
+            r[i] = vv;
+            rr += vv * vv * nv[it];
+        }
+        const int qa = q % N2, qb = (q / N2) % N2, qc = q / (N2 * N2);
+        const double ha = hat.h1[qa], hb = hat.h1[qb], hc = hat.h1[qc];
+        if (W) {
+            double *We = W + e * (int64_t)(N * N * N);
+            const double vw = vv * qv[it];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (sl[it][d] >= 0) We[sl[it][d]] = vw;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double w = ((c & 1) ? ha : 1.0 - ha) * ((c & 2) ? hb : 1.0 - hb);
+            w *= (c & 4) ? hc : 1.0 - hc;
+            a[c] += w * vv;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[c] += __shfl_down(a[c], o, 64);
+    }
+    if (lane == 0 && act) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) t[e * 8 + c] = a[c];
+    }
+    if (upd) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rr += __shfl_down(rr, o, 64);
+        if (lane == 0) srr[wid] = rr;
+        __syncthreads();
+        if (threadIdx.x == 0) u.rr_part[blockIdx.x] = (srr[0] + srr[1]) + (srr[2] + srr[3]);
+    }
+}
+
 // rc[v] = sum of t over the (element, corner) entries incident to vertex v (fixed order), and the first damped-Jacobi
 // sweep from a zero guess
 __global__ __launch_bounds__(NT) void k_q1_gather(const double *__restrict__ flag, int nvert, const int *__restrict__ vp,
@@ -1078,6 +1164,21 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
                         tab[(size_t)a + n * (b + n * c)] = nb | (fg_slot(n, a, b, c) << 2) | (q2 << 13) | (fl << 23);
                     }
             NLG_TRY(up(tab, &P.d_exttab));
+            // face slots of the exchange array W next to every pressure point (k_q1_restrict_local3s)
+            {
+                const int n2 = m->n2, N = n2 + 2;
+                std::vector<int> ws((size_t)n2 * n2 * n2 * 3, -1);
+                for (int q = 0; q < n2 * n2 * n2; ++q) {
+                    const int a = q % n2, b = (q / n2) % n2, c = q / (n2 * n2);
+                    if (a == 0) ws[3 * q + 0] = fg_slot(N, 0, b + 1, c + 1);
+                    if (a == n2 - 1) ws[3 * q + 0] = fg_slot(N, N - 1, b + 1, c + 1);
+                    if (b == 0) ws[3 * q + 1] = fg_slot(N, a + 1, 0, c + 1);
+                    if (b == n2 - 1) ws[3 * q + 1] = fg_slot(N, a + 1, N - 1, c + 1);
+                    if (c == 0) ws[3 * q + 2] = fg_slot(N, a + 1, b + 1, 0);
+                    if (c == n2 - 1) ws[3 * q + 2] = fg_slot(N, a + 1, b + 1, N - 1);
+                }
+                NLG_TRY(up(ws, &P.d_wslot));
+            }
         }
         NLG_TRY(up(hlx, &P.d_lamx));
         NLG_HIP(hipMalloc(&P.d_W, sizeof(double) * (size_t)m->lvs));
@@ -1551,8 +1652,16 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
     for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
     if (m->dim == 3) {
         NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
-        hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq,
-                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq, uu);
+        double *Wp = overlap ? P.d_W : (double *)nullptr;
+        const dim3 gq((unsigned)((E + 3) / 4));
+        if (P.d_wslot && m->n2 == 6)
+            hipLaunchKernelGGL(k_q1_restrict_local3s<6>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu);
+        else if (P.d_wslot && m->n2 == 8)
+            hipLaunchKernelGGL(k_q1_restrict_local3s<8>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu);
+        else if (P.d_wslot && m->n2 == 10)
+            hipLaunchKernelGGL(k_q1_restrict_local3s<10>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu);
+        else
+            hipLaunchKernelGGL(k_q1_restrict_local<3>, gq, dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, uu);
     } else {
         NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
         hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq,
@@ -1679,7 +1788,7 @@ void pprec_free(nlg_mesh *m) {
     double *dp[] = {P.d_S, P.d_invden, P.d_dinv, P.d_Ainv, P.d_rc, P.d_x, P.d_ra, P.d_xa, P.d_rag, P.d_tq, P.d_Sx, P.d_lamx, P.d_W, P.d_wq};
     for (double *p : dp)
         if (p) hipFree(p);
-    int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i, P.d_exttab};
+    int *ip[] = {P.d_agg, P.d_ap, P.d_am, P.d_vg, P.d_v2e_p, P.d_v2e_i, P.d_exttab, P.d_wslot};
     for (int *p : ip)
         if (p) hipFree(p);
     if (P.d_Ainv32) hipFree(P.d_Ainv32);
