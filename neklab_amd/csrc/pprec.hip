@@ -266,18 +266,27 @@ __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__rest
         const int q = lane + ST * u;
         te[u] = q < NP ? tab[q] : 3;
     }
+    // branch-free: every lane issues all its loads (clamped to valid addresses) before the first use, so a wave pays ONE
+    // global-memory latency here; with the loads inside `if (nb <= 1)` / `nb == 0 ? :` the compiler emitted, per point, branch ->
+    // two loads -> wait -> branch -> load -> wait: sixteen serialised round trips per wave
+    {
+        double own[NQL], gw[NQL];
 #pragma unroll
-    for (int u = 0; u < NQL; ++u) {
-        const int q = lane + ST * u;
-        if (q >= NP) break;
-        const int nb = te[u] & 3;
-        double v = 0.0;
-        if (nb <= 1) {
-            const int q2 = (te[u] >> 13) & 1023;
-            const double own = re[q2] * wq[ee * NP2 + q2];
-            v = nb == 0 ? own : We[(te[u] >> 2) & 2047] - own;
+        for (int u = 0; u < NQL; ++u) {
+            const int nb = te[u] & 3;
+            const int q2 = nb <= 1 ? ((te[u] >> 13) & 1023) : 0;
+            const int sl = nb == 1 ? ((te[u] >> 2) & 2047) : 0;
+            own[u] = re[q2] * wq[ee * NP2 + q2];
+            gw[u] = We[sl];
         }
-        sA[wv][q] = v;
+#pragma unroll
+        for (int u = 0; u < NQL; ++u) {
+            const int q = lane + ST * u;
+            if (q >= NP) break;
+            const int nb = te[u] & 3;
+            const double v = nb == 0 ? own[u] : (nb == 1 ? gw[u] - own[u] : 0.0);
+            sA[wv][q] = v;
+        }
     }
     __syncthreads();
     fdm_stage_inplace3<N, true, 0, ST>(sA[wv], Sg + 0 * N * N, lane);
@@ -303,19 +312,23 @@ __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__rest
             const int q = lane + ST * u;
             if (q >= NP) break;
             const int nb = te[u] & 3;
-            if (nb == 1) {
-                We[(te[u] >> 2) & 2047] = sA[wv][q];   // ghost value: belongs to the neighbour's adjacent layer
-            } else if (nb == 0) {
-                const int fl = te[u] >> 23;
-                double v = sA[wv][q];
-                if (fl & 1) v -= sA[wv][q - 1];
-                if (fl & 2) v -= sA[wv][q + 1];
-                if (fl & 4) v -= sA[wv][q - N];
-                if (fl & 8) v -= sA[wv][q + N];
-                if (fl & 16) v -= sA[wv][q - N * N];
-                if (fl & 32) v -= sA[wv][q + N * N];
+            // (LDS reads unconditional with clamped indices, selected afterwards: no divergent branches around them)
+            const int fl = nb == 0 ? (te[u] >> 23) : 0;
+            const double c0 = sA[wv][q];
+            const double m1 = sA[wv][q >= 1 ? q - 1 : q], p1 = sA[wv][q + 1 < NP ? q + 1 : q];
+            const double mN = sA[wv][q >= N ? q - N : q], pN = sA[wv][q + N < NP ? q + N : q];
+            const double mM = sA[wv][q >= N * N ? q - N * N : q], pM = sA[wv][q + N * N < NP ? q + N * N : q];
+            double v = c0;
+            v -= (fl & 1) ? m1 : 0.0;
+            v -= (fl & 2) ? p1 : 0.0;
+            v -= (fl & 4) ? mN : 0.0;
+            v -= (fl & 8) ? pN : 0.0;
+            v -= (fl & 16) ? mM : 0.0;
+            v -= (fl & 32) ? pM : 0.0;
+            if (nb == 1)
+                We[(te[u] >> 2) & 2047] = c0;   // ghost value: belongs to the neighbour's adjacent layer
+            else if (nb == 0)
                 z[e * NP2 + ((te[u] >> 13) & 1023)] = v;
-            }
         }
     }
 }
