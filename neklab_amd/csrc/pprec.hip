@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ fl
                                                    const double *__restrict__ r, const double *__restrict__ wq,
                                                    const double *__restrict__ xc, const double *__restrict__ xa,
                                                    const int *__restrict__ agg, const int *__restrict__ vg, Hat hat,
-                                                   double *__restrict__ z, double *__restrict__ part) {
+                                                   double *__restrict__ z, double *__restrict__ part, const int *__restrict__ wslot) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
     __shared__ double sred[8];
     if (flag && flag[0] != 0.0) return;
@@ -348,32 +348,61 @@ __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ fl
     const bool act = e < E;
     double srz = 0.0, sz = 0.0;
     if (act) {
+        // all loads of a group of points first, unconditional and with clamped indices (the face slots of W come from the
+        // table of k_q1_restrict_local3s; a conditional load inside the point loop costs a branch and a full wait per point),
+        // then the arithmetic with selects
+        constexpr int NIT = 4;   // points per lane in flight (lx1 = 8: the whole element)
+        const double *We = W + e * NP;
         double cv[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int v = xc ? vg[e * 8 + c] : 0;
-            cv[c] = xc ? xc[v] + xa[agg[v]] : 0.0;
-        }
-        const double *We = W + e * NP;
-        for (int q = lane; q < NP2; q += 64) {
-            const int a = q % N2, b = (q / N2) % N2, c = q / (N2 * N2);
-            double v = z[e * NP2 + q];
-            if (a == 0) v += We[ext_slot(N, 0, b + 1, c + 1)];
-            if (a == N2 - 1) v += We[ext_slot(N, N - 1, b + 1, c + 1)];
-            if (b == 0) v += We[ext_slot(N, a + 1, 0, c + 1)];
-            if (b == N2 - 1) v += We[ext_slot(N, a + 1, N - 1, c + 1)];
-            if (c == 0) v += We[ext_slot(N, a + 1, b + 1, 0)];
-            if (c == N2 - 1) v += We[ext_slot(N, a + 1, b + 1, N - 1)];
-            v *= wq[e * NP2 + q];
-            const double ha = hat.h1[a], hb = hat.h1[b], hc = hat.h1[c];
-            const double c0 = cv[0] + ha * (cv[1] - cv[0]), c1 = cv[2] + ha * (cv[3] - cv[2]);
-            const double d0 = cv[4] + ha * (cv[5] - cv[4]), d1 = cv[6] + ha * (cv[7] - cv[6]);
-            double cc = c0 + hb * (c1 - c0);
-            cc += hc * ((d0 + hb * (d1 - d0)) - cc);
-            v += cc;
-            z[e * NP2 + q] = v;
-            srz += r[e * NP2 + q] * v;
-            sz += v;
+        for (int c = 0; c < 8; ++c) cv[c] = 0.0;
+        for (int q0 = 0; q0 < NP2; q0 += 64 * NIT) {
+            double zv[NIT], qv[NIT], rv[NIT], gh[NIT][3];
+            int sl[NIT][3];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = q0 + lane + 64 * it;
+                const int qc = q < NP2 ? q : 0;
+                const int64_t i = e * NP2 + qc;
+                zv[it] = z[i];
+                qv[it] = wq[i];
+                rv[it] = r[i];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) sl[it][d] = wslot[3 * qc + d];
+            }
+            if (q0 == 0 && xc) {
+                int vv[8], av[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) vv[c] = vg[e * 8 + c];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) av[c] = agg[vv[c]];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cv[c] = xc[vv[c]] + xa[av[c]];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) gh[it][d] = We[sl[it][d] >= 0 ? sl[it][d] : 0];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = q0 + lane + 64 * it;
+                if (q >= NP2) continue;
+                const int a = q % N2, b = (q / N2) % N2, c = q / (N2 * N2);
+                double v = zv[it];
+                v += sl[it][0] >= 0 ? gh[it][0] : 0.0;
+                v += sl[it][1] >= 0 ? gh[it][1] : 0.0;
+                v += sl[it][2] >= 0 ? gh[it][2] : 0.0;
+                v *= qv[it];
+                const double ha = hat.h1[a], hb = hat.h1[b], hc = hat.h1[c];
+                const double c0 = cv[0] + ha * (cv[1] - cv[0]), c1 = cv[2] + ha * (cv[3] - cv[2]);
+                const double d0 = cv[4] + ha * (cv[5] - cv[4]), d1 = cv[6] + ha * (cv[7] - cv[6]);
+                double cc = c0 + hb * (c1 - c0);
+                cc += hc * ((d0 + hb * (d1 - d0)) - cc);
+                v += cc;
+                z[e * NP2 + q] = v;
+                srz += rv[it] * v;
+                sz += v;
+            }
         }
     }
     if (part) {
@@ -629,19 +658,19 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = lane + 64 * it;
-        const bool on = act && q < NP2;
-        const int64_t i = e * NP2 + (on ? q : 0);
-        v[it] = on ? r[i] : 0.0;
+        const int qc = q < NP2 ? q : 0;                 // (unconditional loads at clamped addresses: no branch, no wait per point)
+        const int64_t i = (act ? e : 0) * NP2 + qc;
+        v[it] = r[i];
         if (upd) {
-            pv[it] = on ? u.p[i] : 0.0;
-            wv[it] = on ? u.w[i] : 0.0;
-            xv[it] = on ? u.x[i] : 0.0;
-            nv[it] = on ? u.nw[i] : 0.0;
+            pv[it] = u.p[i];
+            wv[it] = u.w[i];
+            xv[it] = u.x[i];
+            nv[it] = u.nw[i];
         }
         if (W) {
-            qv[it] = on ? wq[i] : 0.0;
+            qv[it] = wq[i];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) sl[it][d] = on ? wslot[3 * q + d] : -1;
+            for (int d = 0; d < 3; ++d) sl[it][d] = wslot[3 * qc + d];
         }
     }
 #pragma unroll
@@ -1765,7 +1794,7 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         NLG_TRY(overlap_halo(m, st, true));
 #define FF_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_sch_finish<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
+        hipLaunchKernelGGL((k_sch_finish<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part, (const int *)P.d_wslot); \
         break;
         switch (m->n) {
             FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10) FF_CASE(12)
