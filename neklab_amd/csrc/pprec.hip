@@ -831,8 +831,22 @@ __global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, i
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     if (row >= na) return;
+    // eight loads of the row in flight per lane (same summation order as the plain loop: the products are added one after the
+    // other); a wave per row gives only ~1.3 waves per SIMD at 1300 rows, so the loads of one wave must overlap themselves
     double s = 0.0;
-    for (int j = lane; j < ncols; j += 64) s += (double)Ainv[(size_t)row * ncols + j] * ra[j];
+    const T *__restrict__ Ar = Ainv + (size_t)row * ncols;
+    int j = lane;
+    for (; j + 7 * 64 < ncols; j += 8 * 64) {
+        double av[8], rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = (double)Ar[j + 64 * u];
+            rv[u] = ra[j + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += av[u] * rv[u];
+    }
+    for (; j < ncols; j += 64) s += (double)Ar[j] * ra[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) xa[row] = s;
