@@ -383,13 +383,22 @@ int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const
 int sem_opdiv_blocks(const nlg_mesh *m);
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
-int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false, const double *gate = nullptr);
+struct nlg_pupd;
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false, const double *gate = nullptr, const nlg_pupd *upd = nullptr);
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false,
               const double *pdot = nullptr, double *pw_part = nullptr, const double *gate = nullptr);
 int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
-int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr, const double *gate = nullptr);
-int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate);
-int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate);
+// direction update of a PCG performed by the operator while it loads p:  p <- (z - zmean[0]) + beta[0] p   (device scalars)
+struct nlg_pupd {
+    const double *z = nullptr, *beta = nullptr, *zmean = nullptr;
+    double *p = nullptr;
+};
+bool sem_opgradt_fuses_pupdate(const nlg_mesh *m);
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr, const double *gate = nullptr, const nlg_pupd *upd = nullptr);
+int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate,
+                      const nlg_pupd *upd = nullptr);
+int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate,
+                      const nlg_pupd *upd = nullptr);
 int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *out, double scale, double *const *wts, bool face_grouped,
                     const double *const *pdot, double *const *pw_part, const double *const *gate);
 int sem_ediag(nlg_mesh *m, double *out);

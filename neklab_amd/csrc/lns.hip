@@ -1159,6 +1159,10 @@ int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
     Q.pw_part = op->d_part;
     P.pw_part = Q.pw_part;
     P.pw_n = sem_opdiv_blocks(m);
+    {
+        static const bool fuse = !(getenv("NLG_FUSE_PPUPDATE") && atoi(getenv("NLG_FUSE_PPUPDATE")) == 0);
+        P.fused_pupdate = fuse && sem_opgradt_fuses_pupdate(m);
+    }
     if (P.precond && (m->dim == 3 || (c.pprecond == 0 && m->pprec.overlap))) {
         P.rz_part = op->d_part + 2 * m->E;
         P.rz_n = m->dim == 3 ? (int)((m->E + 3) / 4) : (int)((m->E * m->np2 + NT - 1) / NT);
@@ -1188,7 +1192,14 @@ int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
 }
 
 // gated: launches past convergence (the host only looks at the flag once per chunk) return at once
-int pres_apply(nlg_linop *op, const PresSolve &Q) { return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE); }
+int pres_apply(nlg_linop *op, const PresSolve &Q) {
+    if (Q.P.fused_pupdate) {   // p <- (z - zmean) + beta p while the gradient kernel loads p
+        nlg_pupd u;
+        u.z = op->pr_z, u.beta = op->d_s + S_N + S_BETA, u.zmean = op->d_s + S_N + S_ZMEAN, u.p = op->pr_p;
+        return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE, &u);
+    }
+    return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE);
+}
 
 int pres_finish(nlg_linop *op, const PresSolve &Q, int iters) {
     nlg_mesh *m = op->mesh;
@@ -1722,7 +1733,11 @@ int advance_block(nlg_linop *const *ops, int s) {
         const double *pp[4], *gg[4];
         double *ww[4], *pw[4];
         for (int v = 0; v < s; ++v) pp[v] = ops[v]->pr_p, ww[v] = ops[v]->pr_w, pw[v] = Q[v].pw_part, gg[v] = ops[v]->d_s + S_N + S_DONE;
-        auto apply_all = [&]() -> int { return sem_cdabdtp_lanes(ops[0]->mesh, s, pp, ww, pw, gg); };
+        nlg_pupd pu[4];
+        const bool fused = Q[0].P.fused_pupdate;
+        for (int v = 0; v < s; ++v)
+            if (fused) pu[v].z = ops[v]->pr_z, pu[v].beta = ops[v]->d_s + S_N + S_BETA, pu[v].zmean = ops[v]->d_s + S_N + S_ZMEAN, pu[v].p = ops[v]->pr_p;
+        auto apply_all = [&]() -> int { return sem_cdabdtp_lanes(ops[0]->mesh, s, pp, ww, pw, gg, fused ? pu : nullptr); };
         NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
         for (int v = 0; v < s; ++v) NLG_TRY(pres_finish(ops[v], Q[v], iters[v]));
     }

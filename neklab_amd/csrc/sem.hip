@@ -1372,8 +1372,14 @@ struct PBlockN {
     static constexpr int RS = (3 * (N - 2)) | 1;   // odd region stride: the columns of a stage fall on different banks
 };
 
+// PUpd: the direction update of the surrounding PCG, p <- (z - zmean) + beta p, performed while the kernel loads p (per lane;
+// z == null: none).  The threads that own the z columns are the only readers of p, so they also write it back.
+struct PUpd {
+    const double *z[4], *beta[4], *zmean[4];
+    double *p[4];
+};
 template <int N, bool FG, bool ML = true>
-__global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl) {
+__global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl, PUpd pu) {
     constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
     constexpr int RS = PBlockN<N>::RS;
     static_assert(2 * N <= 3 * N2, "in-place y stage needs 2 N <= 3 N2");
@@ -1387,6 +1393,16 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
         if (tid < NS2) {
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) pv[k2] = pe[tid + NS2 * k2];
+            if (pu.z[lv]) {
+                const double beta = pu.beta[lv][0], zmean = pu.zmean[lv][0];
+                const double *ze = pu.z[lv] + e * NP2;
+                double *po = pu.p[lv] + e * NP2;
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) {
+                    pv[k2] = (ze[tid + NS2 * k2] - zmean) + beta * pv[k2];
+                    po[tid + NS2 * k2] = pv[k2];
+                }
+            }
         }
         // lx1 <= 8 (one wave per element, registers to spare): the metric columns of the NEXT component are requested before
         // the y and x stages of the current one, so that their latency is hidden behind two LDS stages
@@ -2548,14 +2564,27 @@ static CF9 rst2w_ptrs(const nlg_mesh *m) {
     return g;
 }
 
-int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped, const double *gate) {
+int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped, const double *gate, const nlg_pupd *upd) {
     const double *pl[1] = {p}, *gl[1] = {gate};
     double *const *wl[1] = {w};
-    return sem_opgradt_lanes(m, 1, pl, wl, face_grouped, gl);
+    return sem_opgradt_lanes(m, 1, pl, wl, face_grouped, gl, upd);
 }
 
+// does sem_opgradt perform the PCG direction update itself when asked to (nlg_pupd)?  3-D, lx1 >= 8: the in-place kernels
+bool sem_opgradt_fuses_pupdate(const nlg_mesh *m) { return m->dim == 3 && m->n >= 8 && !pkern_old(); }
+
 // nl <= 4 pressure fields -> nl velocity-mesh field triples in one launch (block stepper); gates: per-lane done flags (may be null)
-int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate) {
+int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate,
+                      const nlg_pupd *upd) {
+    NLG_CHECK(!upd || sem_opgradt_fuses_pupdate(m), "sem_opgradt: the fused direction update exists for 3-D, lx1 >= 8 only");
+    PUpd pu;
+    for (int v = 0; v < 4; ++v) {
+        const bool on = upd && v < nl && upd[v].z;
+        pu.z[v] = on ? upd[v].z : nullptr;
+        pu.beta[v] = on ? upd[v].beta : nullptr;
+        pu.zmean[v] = on ? upd[v].zmean : nullptr;
+        pu.p[v] = on ? upd[v].p : nullptr;
+    }
     // (the timed class is ONE kernel instantiation -- the face-grouped variant of the pressure operator in 3-D; the natural-layout
     //  launches of the right-hand sides, a few per time step, are booked under "vec_ops")
     ProfScope ps(m->ctx, (m->dim == 2 || face_grouped) ? P_OPGRADT : P_VECOPS);
@@ -2580,9 +2609,9 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
         else if (N_ <= 8 && !(N_ == 8 && n8new))                                                                       \
             hipLaunchKernelGGL((k_opgradt3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);    \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);    \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl);   \
+            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);   \
         else if (face_grouped)                                                                                         \
             hipLaunchKernelGGL((k_opgradt3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
@@ -2708,7 +2737,8 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
 
 // E applied to nl <= 4 pressure fields (block stepper): gradient, gather-scatter, divergence; the two element kernels take
 // all lanes in one launch
-int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate) {
+int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate,
+                      const nlg_pupd *upd) {
     const bool fg = m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg);
     double *w[4][3];
     double *const *wl[4];
@@ -2717,7 +2747,7 @@ int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
         NLG_CHECK(w[v][0] && w[v][1], "sem_cdabdtp: scratch allocation failed");
         wl[v] = w[v];
     }
-    NLG_TRY(sem_opgradt_lanes(m, nl, p, wl, fg, gate));
+    NLG_TRY(sem_opgradt_lanes(m, nl, p, wl, fg, gate, upd));
     for (int v = 0; v < nl; ++v) {
         const double *gv = gate ? gate[v] : nullptr;
         NLG_TRY(sem_gs(m, w[v], m->dim, gv, fg ? LAYOUT_FG : LAYOUT_NAT));
@@ -2725,18 +2755,18 @@ int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
     return sem_opdiv_lanes(m, nl, wl, out, 1.0, fg ? m->d_mbinv_fg : m->d_mbinv, fg, p, pw_part, gate);
 }
 
-int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, const double *gate) {
+int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, const double *gate, const nlg_pupd *upd) {
     double *w[3] = {sem_scratch1(m, 0), sem_scratch1(m, 1), m->dim == 3 ? sem_scratch1(m, 2) : nullptr};
     NLG_CHECK(w[0] && w[1], "sem_cdabdtp: scratch allocation failed");
     if (m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg)) {
         // 3-D: the intermediate velocity-mesh fields use the face-grouped element layout, in which the copies of a
         // shared face are contiguous runs -> coalesced gather-scatter; the rank halo uses index lists in that layout
-        NLG_TRY(sem_opgradt(m, p, w, true, gate));
+        NLG_TRY(sem_opgradt(m, p, w, true, gate, upd));
         NLG_TRY(sem_gs(m, w, 3, gate, LAYOUT_FG));
         NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part, gate));
         return 0;
     }
-    NLG_TRY(sem_opgradt(m, p, w, false, gate));
+    NLG_TRY(sem_opgradt(m, p, w, false, gate, upd));
     NLG_TRY(sem_gs(m, w, m->dim, gate));
     NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv, false, p, pw_part, gate));   // mask * binvm1 fused into the load
     return 0;
