@@ -16,6 +16,8 @@
 #include <cmath>
 #include <numeric>
 
+#include <type_traits>
+
 #include "internal.h"
 
 using namespace nlg;
@@ -1378,8 +1380,10 @@ struct PUpd {
     const double *z[4], *beta[4], *zmean[4];
     double *p[4];
 };
-template <int N, bool FG, bool ML = true>
-__global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl, PUpd pu) {
+struct NoPUpd {};   // PU = false: the kernel has no trace of the update (its mere presence cost k_opgradt3n<12> 40 %)
+template <int N, bool FG, bool ML = true, bool PU = false>
+__global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g, CP4 pl, F3L wl, CP4 gatel, int nl,
+                                                               std::conditional_t<PU, PUpd, NoPUpd> pu) {
     constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
     constexpr int RS = PBlockN<N>::RS;
     static_assert(2 * N <= 3 * N2, "in-place y stage needs 2 N <= 3 N2");
@@ -1393,7 +1397,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
         if (tid < NS2) {
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) pv[k2] = pe[tid + NS2 * k2];
-            if (pu.z[lv]) {
+            if constexpr (PU) if (pu.z[lv]) {
                 const double beta = pu.beta[lv][0], zmean = pu.zmean[lv][0];
                 const double *ze = pu.z[lv] + e * NP2;
                 double *po = pu.p[lv] + e * NP2;
@@ -2571,7 +2575,9 @@ int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_groupe
 }
 
 // does sem_opgradt perform the PCG direction update itself when asked to (nlg_pupd)?  3-D, lx1 >= 8: the in-place kernels
-bool sem_opgradt_fuses_pupdate(const nlg_mesh *m) { return m->dim == 3 && m->n >= 8 && !pkern_old(); }
+// (lx1 = 12: the extra 2 x 10 memory operations per z column push k_opgradt3n<12> from 354 to 550 us -- more than the separate
+//  update kernel costs -- so the fusion stops at lx1 = 10)
+bool sem_opgradt_fuses_pupdate(const nlg_mesh *m) { return m->dim == 3 && m->n >= 8 && m->n <= 10 && !pkern_old(); }
 
 // nl <= 4 pressure fields -> nl velocity-mesh field triples in one launch (block stepper); gates: per-lane done flags (may be null)
 int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *const *w, bool face_grouped, const double *const *gate,
@@ -2609,9 +2615,19 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
         else if (N_ <= 8 && !(N_ == 8 && n8new))                                                                       \
             hipLaunchKernelGGL((k_opgradt3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);    \
+            {                                                                                                          \
+                if (upd)                                                                                               \
+                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 && N_ <= 10 ? N_ : 9), true, ML_, true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);    \
+                else                                                                                                   \
+                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_, false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, NoPUpd{});    \
+            }                                                                                                          \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);   \
+            {                                                                                                          \
+                if (upd)                                                                                               \
+                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 && N_ <= 10 ? N_ : 9), false, ML_, true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);   \
+                else                                                                                                   \
+                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_, false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, NoPUpd{});   \
+            }                                                                                                          \
         else if (face_grouped)                                                                                         \
             hipLaunchKernelGGL((k_opgradt3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
