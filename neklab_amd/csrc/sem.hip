@@ -1975,21 +1975,33 @@ __global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const dou
             const double *g0 = adjoint ? GU.p[0 * 3 + ic] : GU.p[ic * 3 + 0];
             const double *g1 = adjoint ? GU.p[1 * 3 + ic] : GU.p[ic * 3 + 1];
             const double *g2 = adjoint ? GU.p[2 * 3 + ic] : GU.p[ic * 3 + 2];
+            // the six base-flow values of CB fine levels are requested together (6 CB loads in flight per lane); level by level
+            // the compiler issued six loads and waited for them, i.e. ND serialised round trips to HBM per component
+            constexpr int CB = ND % 4 == 0 ? 4 : (ND % 5 == 0 ? 5 : (ND % 3 == 0 ? 3 : 1));
 #pragma unroll
-            for (int c = 0; c < ND; ++c) {
-                const int64_t q = qb + (int64_t)NCOLZ * c;
-                const double b0 = Ur.p[0][q], b1 = Ur.p[1][q], b2 = Ur.p[2][q];
-                const double h0 = g0[q], h1 = g1[q], h2 = g2[q];
-                double ut = 0.0, us = 0.0, ur = 0.0;
+            for (int c0 = 0; c0 < ND; c0 += CB) {
+                double bb[CB][6];
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    ut += DJg[c * N + k] * v0[k];
-                    us += Jg[c * N + k] * v1[k];
-                    ur += Jg[c * N + k] * v2[k];
+                for (int cc = 0; cc < CB; ++cc) {
+                    const int64_t q = qb + (int64_t)NCOLZ * (c0 + cc);
+                    bb[cc][0] = Ur.p[0][q], bb[cc][1] = Ur.p[1][q], bb[cc][2] = Ur.p[2][q];
+                    bb[cc][3] = g0[q], bb[cc][4] = g1[q], bb[cc][5] = g2[q];
                 }
-                const double acc = sgn * (b0 * ur + b1 * us + b2 * ut) + (ufr[0][c] * h0 + ufr[1][c] * h1 + ufr[2][c] * h2);
 #pragma unroll
-                for (int k = 0; k < N; ++k) T[k] += Jg[c * N + k] * acc;
+                for (int cc = 0; cc < CB; ++cc) {
+                    const int c = c0 + cc;
+                    double ut = 0.0, us = 0.0, ur = 0.0;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        ut += DJg[c * N + k] * v0[k];
+                        us += Jg[c * N + k] * v1[k];
+                        ur += Jg[c * N + k] * v2[k];
+                    }
+                    const double acc = sgn * (bb[cc][0] * ur + bb[cc][1] * us + bb[cc][2] * ut) +
+                                       (ufr[0][c] * bb[cc][3] + ufr[1][c] * bb[cc][4] + ufr[2][c] * bb[cc][5]);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) T[k] += Jg[c * N + k] * acc;
+                }
             }
         }
         __syncthreads();   // every thread is done with sAA/sAD/sBA and sA/sB
