@@ -616,15 +616,23 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     const bool upd = beta_p != nullptr && done_p[0] == 0.0;
     const double beta = upd ? beta_p[0] : 0.0;
     double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
+    // all loads of the column first, then the stores of the fused direction update: with load / store alternating per point the
+    // compiler cannot hoist the later loads over the earlier stores (same array) and the wave pays N serialised round trips
+    {
+        double zk[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double v = act ? uc[vb + k * vs] : 0.0;
-        if (upd && act) {
-            v = zc[vb + k * vs] + beta * v;
-            const_cast<double *>(uc)[vb + k * vs] = v;
+        for (int k = 0; k < N; ++k) {
+            uk[k] = act ? uc[vb + k * vs] : 0.0;
+            zk[k] = (upd && act) ? zc[vb + k * vs] : 0.0;
+            wk[k] = 0.0;
         }
-        uk[k] = v;
-        wk[k] = 0.0;
+        if (upd && act) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                uk[k] = zk[k] + beta * uk[k];
+                const_cast<double *>(uc)[vb + k * vs] = uk[k];
+            }
+        }
     }
 #pragma unroll
     for (int l = 0; l < N; ++l) {
@@ -748,15 +756,23 @@ __global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const doub
     double pw = 0.0;
     if (!gated) {   // (a converged lane skips the work; its waves still take part in the block reduction below)
     double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
+    // all loads of the column first, then the stores of the fused direction update: with load / store alternating per point the
+    // compiler cannot hoist the later loads over the earlier stores (same array) and the wave pays N serialised round trips
+    {
+        double zk[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double v = act ? uc[vb + k * vs] : 0.0;
-        if (upd && act) {
-            v = zc[vb + k * vs] + beta * v;
-            const_cast<double *>(uc)[vb + k * vs] = v;
+        for (int k = 0; k < N; ++k) {
+            uk[k] = act ? uc[vb + k * vs] : 0.0;
+            zk[k] = (upd && act) ? zc[vb + k * vs] : 0.0;
+            wk[k] = 0.0;
         }
-        uk[k] = v;
-        wk[k] = 0.0;
+        if (upd && act) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                uk[k] = zk[k] + beta * uk[k];
+                const_cast<double *>(uc)[vb + k * vs] = uk[k];
+            }
+        }
     }
 #pragma unroll
     for (int l = 0; l < N; ++l) {
@@ -861,15 +877,21 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
     const bool upd = beta_p != nullptr && done_p[0] == 0.0;
     const double beta = upd ? beta_p[0] : 0.0;
     double uk[N], wk[N], di[N], dj[N], dti[N], dtj[N];
+    {   // loads first, then the stores of the fused direction update (see k_axhelm3r)
+        double zk[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double v = act ? uc[ij + k * NS] : 0.0;
-        if (upd && act) {
-            v = zc[ij + k * NS] + beta * v;
-            const_cast<double *>(uc)[ij + k * NS] = v;
+        for (int k = 0; k < N; ++k) {
+            uk[k] = act ? uc[ij + k * NS] : 0.0;
+            zk[k] = (upd && act) ? zc[ij + k * NS] : 0.0;
+            wk[k] = 0.0;
         }
-        uk[k] = v;
-        wk[k] = 0.0;
+        if (upd && act) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                uk[k] = zk[k] + beta * uk[k];
+                const_cast<double *>(uc)[ij + k * NS] = uk[k];
+            }
+        }
     }
 #pragma unroll
     for (int l = 0; l < N; ++l) {
