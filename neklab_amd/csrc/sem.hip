@@ -1423,9 +1423,12 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                 const double beta = pu.beta[lv][0], zmean = pu.zmean[lv][0];
                 const double *ze = pu.z[lv] + e * NP2;
                 double *po = pu.p[lv] + e * NP2;
+                double zv[N2];   // loads first, stores afterwards (alternating, they serialise: the compiler must assume aliasing)
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) zv[k2] = ze[tid + NS2 * k2];
 #pragma unroll
                 for (int k2 = 0; k2 < N2; ++k2) {
-                    pv[k2] = (ze[tid + NS2 * k2] - zmean) + beta * pv[k2];
+                    pv[k2] = (zv[k2] - zmean) + beta * pv[k2];
                     po[tid + NS2 * k2] = pv[k2];
                 }
             }
@@ -1616,12 +1619,15 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
         double *__restrict__ part = partl.p[lv];
         double spw = 0.0, sw = 0.0;
         if (tid < NS2) {
+            double pd[N2];   // loads before the stores (see k_axhelm3r)
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) pd[k2] = part ? pdot[e * NP2 + tid + NS2 * k2] : 0.0;
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) {
                 const double v = scale * acc[k2];
                 out[e * NP2 + tid + NS2 * k2] = v;
                 if (part) {
-                    spw += pdot[e * NP2 + tid + NS2 * k2] * v;
+                    spw += pd[k2] * v;
                     sw += v;
                 }
             }
