@@ -380,26 +380,36 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
     const int64_t np2 = npairs >> 1;
     if (t < np2) {
         const int4 q = reinterpret_cast<const int4 *>(idx)[t];
+        // (all fields are loaded before the first store: field by field, the compiler has to keep every later load behind the
+        //  earlier stores -- the field pointers may alias -- and a thread pays NF serialised round trips)
         if (q.z == q.x + 1 && q.w == q.y + 1 && !((q.x | q.y) & 1)) {
+            double2 a[NF], b[NF];
 #pragma unroll
             for (int c = 0; c < NF; ++c) {
-                double2 *pa = reinterpret_cast<double2 *>(f.p[c] + q.x), *pb = reinterpret_cast<double2 *>(f.p[c] + q.y);
-                const double2 a = *pa, b = *pb;
+                a[c] = *reinterpret_cast<const double2 *>(f.p[c] + q.x);
+                b[c] = *reinterpret_cast<const double2 *>(f.p[c] + q.y);
+            }
+#pragma unroll
+            for (int c = 0; c < NF; ++c) {
                 double2 s;
-                s.x = a.x + b.x;
-                s.y = a.y + b.y;
-                *pa = s;
-                *pb = s;
+                s.x = a[c].x + b[c].x;
+                s.y = a[c].y + b[c].y;
+                *reinterpret_cast<double2 *>(f.p[c] + q.x) = s;
+                *reinterpret_cast<double2 *>(f.p[c] + q.y) = s;
             }
         } else {
+            double s0[NF], s1[NF];
 #pragma unroll
             for (int c = 0; c < NF; ++c) {
-                const double s0 = f.p[c][q.x] + f.p[c][q.y];
-                const double s1 = f.p[c][q.z] + f.p[c][q.w];
-                f.p[c][q.x] = s0;
-                f.p[c][q.y] = s0;
-                f.p[c][q.z] = s1;
-                f.p[c][q.w] = s1;
+                s0[c] = f.p[c][q.x] + f.p[c][q.y];
+                s1[c] = f.p[c][q.z] + f.p[c][q.w];
+            }
+#pragma unroll
+            for (int c = 0; c < NF; ++c) {
+                f.p[c][q.x] = s0[c];
+                f.p[c][q.y] = s0[c];
+                f.p[c][q.z] = s1[c];
+                f.p[c][q.w] = s1[c];
             }
         }
         return;
@@ -408,11 +418,13 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
     if (g >= ngroups) return;
     if (g < npairs) {
         const int2 ab = reinterpret_cast<const int2 *>(idx)[g];
+        double s[NF];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) s[c] = f.p[c][ab.x] + f.p[c][ab.y];
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
-            const double s = f.p[c][ab.x] + f.p[c][ab.y];
-            f.p[c][ab.x] = s;
-            f.p[c][ab.y] = s;
+            f.p[c][ab.x] = s[c];
+            f.p[c][ab.y] = s[c];
         }
         return;
     }
@@ -420,13 +432,15 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
         // 2 * npairs is even, so the quad block starts 8-byte aligned; read it as two int2
         const int2 *q2 = reinterpret_cast<const int2 *>(idx + 2 * npairs) + 2 * (g - npairs);
         const int2 ab = q2[0], cd = q2[1];
+        double s[NF];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) s[c] = ((f.p[c][ab.x] + f.p[c][ab.y]) + f.p[c][cd.x]) + f.p[c][cd.y];
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
-            const double s = ((f.p[c][ab.x] + f.p[c][ab.y]) + f.p[c][cd.x]) + f.p[c][cd.y];
-            f.p[c][ab.x] = s;
-            f.p[c][ab.y] = s;
-            f.p[c][cd.x] = s;
-            f.p[c][cd.y] = s;
+            f.p[c][ab.x] = s[c];
+            f.p[c][ab.y] = s[c];
+            f.p[c][cd.x] = s[c];
+            f.p[c][cd.y] = s[c];
         }
         return;
     }
