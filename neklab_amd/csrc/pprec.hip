@@ -670,7 +670,7 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
 #pragma unroll
     for (int c = 0; c < 8; ++c) a[c] = 0.0;
     for (int q0 = 0; q0 < NP2; q0 += 64 * NIT) {
-        double v[NIT], pv[NIT], wv[NIT], xv[NIT], nv[NIT], qv[NIT];
+        double v[NIT], pv[NIT], wv[NIT], xv[NIT], nv[NIT], qv[NIT], hh[NIT][3];
         int sl[NIT][3];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -689,6 +689,7 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
 #pragma unroll
                 for (int d = 0; d < 3; ++d) sl[it][d] = wslot[3 * qc + d];
             }
+            hh[it][0] = hat.h1[qc % N2], hh[it][1] = hat.h1[(qc / N2) % N2], hh[it][2] = hat.h1[qc / (N2 * N2)];   // (a load too)
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -702,8 +703,7 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
                 r[i] = vv;
                 rr += vv * vv * nv[it];
             }
-            const int qa = q % N2, qb = (q / N2) % N2, qc = q / (N2 * N2);
-            const double ha = hat.h1[qa], hb = hat.h1[qb], hc = hat.h1[qc];
+            const double ha = hh[it][0], hb = hh[it][1], hc = hh[it][2];
             if (W) {
                 double *We = W + e * (int64_t)(N * N * N);
                 const double vw = vv * qv[it];
