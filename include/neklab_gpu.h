@@ -80,6 +80,10 @@ int64_t nlg_halo_lists(int n, int dim, int64_t E, const int64_t *glo, int rank, 
  * is LightKrylov's timer object, src/neklab_analysis.f90:66-67, :98-101).  Classes: "axhelm", "gs",
  * "opgradt", "opdiv", "colmul", "block_dot", "block_axpy", "cg_vec", "conv", "vec_ops". */
 int nlg_prof_enable(nlg_ctx *ctx, int class_mask); /* bit i = class i in the order above; -1 = all; 0 = off */
+/* time only every stride-th launch of an enabled class (default 1): a pair of events around a 50-us kernel costs ~12 us of
+ * stream time, so timing every launch of the dominant class would slow the run it measures by 2 %; nlg_prof_get then returns
+ * the number of TIMED launches and their total */
+int nlg_prof_sample(nlg_ctx *ctx, int stride);
 int nlg_prof_reset(nlg_ctx *ctx);
 int nlg_prof_get(nlg_ctx *ctx, const char *name, int64_t *count, double *total_ms);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.c_int64, c_int64_p]),
     "nlg_prof_enable": (C.c_int, [vp, C.c_int]),
+    "nlg_prof_sample": (C.c_int, [vp, C.c_int]),
     "nlg_prof_reset": (C.c_int, [vp]),
     "nlg_prof_get": (C.c_int, [vp, C.c_char_p, c_int64_p, c_double_p]),
     "nlg_mesh_create": (C.c_int, [vp, C.POINTER(MeshDesc), C.POINTER(vp)]),

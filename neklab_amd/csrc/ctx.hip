@@ -108,6 +108,14 @@ extern "C" int nlg_prof_enable(nlg_ctx *ctx, int on) {
     return 0;
 }
 
+extern "C" int nlg_prof_sample(nlg_ctx *ctx, int stride) {
+    NLG_CHECK(ctx && stride >= 1, "nlg_prof_sample: NULL ctx or stride < 1");
+    prof_flush(ctx);
+    ctx->prof_stride = stride;
+    for (int id = 0; id < P_COUNT; ++id) ctx->prof_seq[id] = 0;
+    return 0;
+}
+
 extern "C" int nlg_prof_reset(nlg_ctx *ctx) {
     NLG_CHECK(ctx, "nlg_prof_reset: NULL ctx");
     prof_flush(ctx);

@@ -806,14 +806,15 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
     auto body = [&]() -> int {
         NLG_TRY(apply(s));
-        if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
+        const bool prof_cg = prof_want(ctx, P_CGVEC);
+        if (prof_cg) prof_begin(ctx, P_CGVEC);
         if (!P.pw_part)
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
         NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
         if (!P.rr_part)
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
                       pc, P.ipw, P.nw, partial);
-        if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
+        if (prof_cg) prof_end(ctx, P_CGVEC);
         if (P.precond) {
             NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
             if (!P.rz_part)
@@ -1618,12 +1619,13 @@ int pcg_after_apply(nlg_linop *op, const CGProblem &P, PcgState &S) {
     double *partial = ctx->d_partial;
     F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
     CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf), cr = cf3(P.r, nf);
-    if (ctx->prof_on & (1 << P_CGVEC)) prof_begin(ctx, P_CGVEC);
+    const bool prof_cg = prof_want(ctx, P_CGVEC);
+        if (prof_cg) prof_begin(ctx, P_CGVEC);
     if (!P.pw_part) launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)P.s, P.n, cp, cw, P.ipw, partial);
     NLG_TRY(pcg_reduce_post(op, P, S.rd_pw, 2, 1, 1));
     if (!P.rr_part)
         launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)P.s, P.n, x, r, z, cp, cw, pc, P.ipw, P.nw, partial);
-    if (ctx->prof_on & (1 << P_CGVEC)) prof_end(ctx, P_CGVEC);
+    if (prof_cg) prof_end(ctx, P_CGVEC);
     if (P.precond) {
         NLG_TRY(P.precond(P.s + S_DONE, P.r[0], P.z[0], &S.xc));
         if (!P.rz_part)
