@@ -68,7 +68,7 @@ __device__ __forceinline__ void contract(const double *__restrict__ in, double *
 // columns of one stage are disjoint, so one LDS array serves as input and output (half the LDS per element -> twice
 // the resident elements per CU for a kernel that mostly waits).
 template <int N2, bool FWD, int AX, int ST = 64>
-__device__ __forceinline__ void fdm_stage_inplace3(double *buf, const double *__restrict__ S, int lane) {
+__device__ __forceinline__ void fdm_stage_inplace3(double *buf, const double *S, int lane) {
     constexpr int NCOL = N2 * N2;
     for (int col = lane; col < NCOL; col += ST) {
         int base, stride;
@@ -253,7 +253,15 @@ __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__rest
     // the element index is wave-uniform: with the pointer made provably uniform the 1-D eigenvector matrices are read by
     // scalar loads straight into FMA operands instead of 384 broadcast LDS reads per lane
     const int eu = __builtin_amdgcn_readfirstlane((int)ee);
-    const double *__restrict__ Sg = S + (int64_t)eu * (3 * N * N);
+    const double *__restrict__ Sgg = S + (int64_t)eu * (3 * N * N);
+    // lx1 <= 8: the three N x N matrices of the element go to LDS (three coalesced loads per lane) and are read from there at
+    // wave-uniform addresses (broadcast).  As scalar-load operands they need 384 SGPRs: 100 of them were spilled to VGPR lanes
+    // and a quarter of the kernel's instructions were v_readlane / v_writelane moves on the (saturated) vector pipe.
+    constexpr bool SLDS = (N <= 8 && WPE == 1);
+    __shared__ double sS[SLDS ? WPB : 1][SLDS ? 3 * N * N : 1];
+    if (SLDS)
+        for (int q = lane; q < 3 * N * N; q += ST) sS[wv][q] = Sgg[q];
+    const double *Sg = SLDS ? sS[wv] : Sgg;
     for (int q = lane; q < 3 * N; q += ST) sL[wv][q / N][q % N] = lam[ee * (3 * N) + q];
     const double *re = r + ee * NP2;
     double *We = W + ee * NP;
