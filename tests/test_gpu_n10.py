@@ -49,7 +49,7 @@ def cmp_vec(gv, ov, tol, what):
     assert errp < 10 * tol * max(np.abs(ov.pr).max(), sc), "%s pr err %.3e" % (what, errp)
 
 
-@pytest.mark.parametrize("n", [10, 12])
+@pytest.mark.parametrize("n", [9, 10, 12])
 @pytest.mark.parametrize("fixed,pprecond,adjoint", [(False, 0, False), (True, 1, True)])
 def test_matvec_large_lx1(gpu_ctx, n, fixed, pprecond, adjoint):
     sem, gm, oA, gA, ov, gv = case(gpu_ctx, n, fixed, pprecond)

@@ -17,6 +17,8 @@ CASES = [
     dict(nel=(2, 2, 2), n=5, periodic=(False, False, False)),
     dict(nel=(2, 2, 2), n=10, periodic=(False, False, True)),     # lx1 > 8: the LDS-cube Helmholtz kernel, generic convection,
     dict(nel=(2, 1, 2), n=12, periodic=(False, False, False)),    # NC = 1 pressure kernels, non-overlapping local solves
+    dict(nel=(2, 2, 2), n=9, periodic=(True, False, False)),      # odd sizes: lx1 = 9 (in-place pressure kernels, dynamic-LDS convection)
+    dict(nel=(2, 2, 2), n=7, periodic=(False, True, False)),      # ... and lx1 = 7 (the 256-thread kernels of lx1 <= 7)
 ]
 
 
