@@ -2009,7 +2009,7 @@ int nlg_linop_init(nlg_linop *op) {
     }
     if (op->use_xp < 0) {
         const char *ev = getenv("NLG_XP");
-        op->use_xp = (dim == 3 && m->n <= 8 && m->d_slot_xp && (m->gs.d_indices_xp || m->gs.ngroups == 0) && !(ev && atoi(ev) == 0)) ? 1 : 0;
+        op->use_xp = (dim == 3 && !(m->n > 8 && getenv("NLG_AXHELM_CUBE") && atoi(getenv("NLG_AXHELM_CUBE")) != 0) && m->d_slot_xp && (m->gs.d_indices_xp || m->gs.ngroups == 0) && !(ev && atoi(ev) == 0)) ? 1 : 0;
     }
     if (op->use_xp > 0) {
         for (int k = 1; k <= op->cfg.torder; ++k) {

@@ -862,14 +862,14 @@ __global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const doub
 // hand-overs per slab are block barriers (two or three waves: cheap) instead of the wave-level LDS ordering.  Row k of D
 // comes from LDS at a block-uniform address (broadcast).  Replaces the LDS-cube kernel k_axhelm3, which ran at 25 % of
 // the HBM roofline at lx1 = 10 (452 us for 912 MB at 6000 elements) against 58 % for k_axhelm3r at lx1 = 8.
-template <int N>
+template <int N, bool XP = false>
 __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E, int nf, const double *__restrict__ Dg,
                                                                         const double *__restrict__ G0, const double *__restrict__ G1,
                                                                         const double *__restrict__ G2, const double *__restrict__ G3,
                                                                         const double *__restrict__ G4, const double *__restrict__ G5,
                                                                         const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                                         double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                                        const double *__restrict__ done_p) {
+                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab) {
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((NS + 63) / 64) * 64, NWB = NTB / 64;
     __shared__ double sD[NS];
     __shared__ double mU[N * NQ], mR[N * NQ], mS[N * NQ];
@@ -883,6 +883,7 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
     const bool act = tid < NS;
     const int ij = act ? tid : 0;
     const int i = ij % N, j = ij / N;
+    const int pij = XP ? xptab[ij] : ij;   // slab-permuted layout: the vectors of the PCG; the metric arrays stay natural
     const int64_t eoff = e * NP;
     const double *uc = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2])) + eoff;
     double *wc = (c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2])) + eoff;
@@ -895,15 +896,15 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
         double zk[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            uk[k] = act ? uc[ij + k * NS] : 0.0;
-            zk[k] = (upd && act) ? zc[ij + k * NS] : 0.0;
+            uk[k] = act ? uc[pij + k * NS] : 0.0;
+            zk[k] = (upd && act) ? zc[pij + k * NS] : 0.0;
             wk[k] = 0.0;
         }
         if (upd && act) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 uk[k] = zk[k] + beta * uk[k];
-                const_cast<double *>(uc)[ij + k * NS] = uk[k];
+                const_cast<double *>(uc)[pij + k * NS] = uk[k];
             }
         }
     }
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
     if (act) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            wc[ij + k * NS] = wk[k];
+            wc[pij + k * NS] = wk[k];
             pw += wk[k] * uk[k];
         }
     }
@@ -2489,7 +2490,7 @@ int sem_axhelm_blocks(nlg_mesh *m, int nf) {
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part,
                double *const *zf, const double *beta_p, const double *done_p, bool xp) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
-    NLG_CHECK(!xp || (m->dim == 3 && m->n <= 8), "sem_axhelm: the x-planes-first layout exists for 3-D, lx1 <= 8 only");
+    NLG_CHECK(!xp || (m->dim == 3 && m->d_slot_xp), "sem_axhelm: the slab-permuted layout exists in 3-D only");
     ProfScope ps(m->ctx, P_AXHELM);
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
     F3 cw = {{w[0], nf > 1 ? w[1] : nullptr, nf > 2 ? w[2] : nullptr}};
@@ -2515,8 +2516,12 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
                            m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
         else                                                                                                          \
-        hipLaunchKernelGGL((k_axhelm3c<N_>), dim3((unsigned)tot), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+        { if (xp)                                                                                                     \
+        hipLaunchKernelGGL((k_axhelm3c<N_, true>), dim3((unsigned)tot), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp); \
+        else                                                                                                          \
+        hipLaunchKernelGGL((k_axhelm3c<N_, false>), dim3((unsigned)tot), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr); } \
     }
         NLG_FOR_N(AX3)
 #undef AX3
