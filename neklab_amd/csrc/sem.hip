@@ -3053,7 +3053,7 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
             case 7: CV3(7); break;
             case 8: CV3(8); break;
             case 9: CV3D(9, 256, true); break;
-            case 10: CV3D(10, 256, true); break;
+            case 10: CV3D(10, 256, false); break;   // u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU
             default: CV3D(12, 384, false); break;
         }
 #undef CV3
