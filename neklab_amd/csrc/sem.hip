@@ -1862,8 +1862,11 @@ __global__ void k_conv_combine_adj(int dim, int64_t n, CF3 Ur, CF3 du, double *a
 // 160 KB per workgroup on gfx950: one block per CU): lx1 = 9, 10 keep u in LDS as before (104 KB at lx1 = 10); at lx1 = 12
 // (ULDS = false) the stage arrays alone take 134 KB and the x stages read u from global memory (41 KB per element, L2).
 // NTC threads: one per fine-mesh column along z (ND^2 = 324 at lx1 = 12 -> 384 threads).
+// Two blocks per CU wherever the LDS image allows it (lx1 <= 10: 78 KB at lx1 = 10 with u read from global memory): the launch
+// bound caps the registers at 256 -- 289 were allocated at lx1 = 10 without it, i.e. ONE block per CU -- at the price of 140 bytes
+// of scratch per lane; 17.2 -> 11.0 ms per step at lx1 = 10.
 template <int N, int ND, int NTC, bool ULDS, bool DYN, bool ML = true>
-__global__ __launch_bounds__(NTC, DYN ? 1 : 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
+__global__ __launch_bounds__(NTC, (DYN && N > 10) ? 1 : 2) void k_conv3(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg,
                                                  CF3 Ur, CF9 GU, CF3L ul, F3L outl, int nl, int adjoint) {
     constexpr int NP = N * N * N, NPD = ND * ND * ND;
     constexpr int NQ = N | 1, NDQ = ND | 1;          // padded (odd) leading dimensions
