@@ -192,3 +192,32 @@ def test_cgs2_fused_sweep_matches_separate_kernels(gpu_ctx, k):
             a, b = ra.get_field(f), rb.get_field(f)
             assert np.max(np.abs(a - b)) < 1e-11 * max(np.max(np.abs(b)), 1e-300), (irst, f)
     assert np.max(np.abs(B.block_dot(k, w1))) < 1e-12
+
+
+def test_sampled_kernel_timing(gpu_ctx):
+    """nlg_prof_sample: only every stride-th launch of an enabled class carries a pair of events (bench.py times every 8th launch of
+    the dominant class, because timing every launch costs 12 us of stream time per launch); counts and totals follow."""
+    import ctypes as C
+    hm = box_mesh((2, 2, 2), 6)
+    gm = host.Mesh(gpu_ctx, hm)
+    lib = gpu_ctx.lib
+    v, out = host.nek_dvector(gm), host.nek_dvector(gm)
+    v.rand(False, seed=3)
+
+    def timed(stride, calls):
+        host.check(lib.nlg_prof_enable(gpu_ctx.h, -1))
+        host.check(lib.nlg_prof_sample(gpu_ctx.h, stride))
+        host.check(lib.nlg_prof_reset(gpu_ctx.h))
+        for _ in range(calls):
+            host.check(lib.nlg_op_helmholtz(gm.h, v.h, out.h, 0.3, 2.0, 0))
+        cnt, ms = C.c_int64(), C.c_double()
+        host.check(lib.nlg_prof_get(gpu_ctx.h, b"axhelm", C.byref(cnt), C.byref(ms)))
+        host.check(lib.nlg_prof_enable(gpu_ctx.h, 0))
+        host.check(lib.nlg_prof_sample(gpu_ctx.h, 1))
+        return cnt.value, ms.value
+
+    n1, t1 = timed(1, 8)
+    n4, t4 = timed(4, 8)
+    assert n1 == 8 and n4 == 2 and t1 > 0 and t4 > 0
+    assert host.check(lib.nlg_prof_sample(gpu_ctx.h, 1)) is None
+    assert lib.nlg_prof_sample(gpu_ctx.h, 0) != 0          # stride < 1 is an error
