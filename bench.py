@@ -385,6 +385,12 @@ def main():
                        "value_definition": "exptA matvecs (+ CGS2 at k = m) of the global %d-element operator per second"
                                            % E_global,
                        "operator_applies_per_s_per_field_per_gpu": None if u12_per_s is None else round(u12_per_s, 1),
+                       # the figures that carry over to the reference's tau = 1 cases (one matvec there = 100 + 2 time steps): the cost
+                       # of ONE time step of the propagator inside the timed region (orthogonalisation at k = m, history blocks
+                       # included, taken off: the block kernels' share of the step from the class timing)
+                       "ms_per_time_step": round((1e3 * elapsed / args.steps)
+                                                 * (1.0 - sum(prof[k][1] for k in ("block_dot", "block_axpy", "axpy_dot")) / max(sum(v[1] for v in prof.values()), 1e-30))
+                                                 / max(steps_per_mv / sblk, 1e-30), 3),
                        "arnoldi_orthogonalisation_ms_at_k=m": None if u3_ms is None else round(u3_ms, 3),
                        "arnoldi_orthogonalisation_ms_vs_k": u3_vs_k,
                        "block_arnoldi": blk,
