@@ -3,7 +3,8 @@
  *
  * Drop-in boundary: the reference consumes this path through Fortran 2008 type-bound
  * procedures of LightKrylov's abstract_vector_rdp / abstract_exptA_linop_rdp.  A Fortran shim
- * (neklab_amd/fortran/neklab_gpu.f90) extends those abstract types and forwards every binding to one
+ * (neklab_amd/fortran/neklab_vectors.f90, neklab_linops.f90, neklab_utils.f90; bind(C) interfaces in neklab_gpu_capi.f90) extends
+ * those abstract types under the reference's module and type names and forwards every binding to one
  * entry point of this header through ISO_C_BINDING.  Each declaration cites the reference interface
  * (file:line under /root/reference) it replaces.
  *
