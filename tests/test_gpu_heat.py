@@ -13,12 +13,12 @@ from oracle.vectors import NekDVector
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dim", [2, 3])
-def test_boussinesq_matvec_matches_oracle(gpu_ctx, dim):
+@pytest.mark.parametrize("dim,n", [(2, 6), (3, 6), (3, 8)])   # lx1 = 8: the kernel instantiations of the benchmark, with the scalar
+def test_boussinesq_matvec_matches_oracle(gpu_ctx, dim, n):
     if dim == 2:
-        hm = box_mesh((3, 2), 6, lengths=(2.0, 1.0), periodic=(True, False), deform=0.03)
+        hm = box_mesh((3, 2), n, lengths=(2.0, 1.0), periodic=(True, False), deform=0.03)
     else:
-        hm = box_mesh((2, 2, 2), 6, lengths=(2.0, 1.0, 1.0), periodic=(True, False, True), deform=0.03)
+        hm = box_mesh((2, 2, 2), n, lengths=(2.0, 1.0, 1.0), periodic=(True, False, True), deform=0.03)
     sem = SEM(hm)
     gm = host.Mesh(gpu_ctx, hm)
     U = [sem.mask[0] * (4 * sem.X[1] * (1 - sem.X[1]))] + [np.zeros(sem.shape1) for _ in range(dim - 1)]
