@@ -381,7 +381,7 @@ def main():
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
                        "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
                        "global_elements": E_global,
-                       "element_matvecs_per_s": E_global * args.steps / elapsed,
+                       "element_matvecs_per_s": E_global * sblk * args.steps / elapsed,
                        "value_definition": "exptA matvecs (+ CGS2 at k = m) of the global %d-element operator per second"
                                            % E_global,
                        "operator_applies_per_s_per_field_per_gpu": None if u12_per_s is None else round(u12_per_s, 1),

@@ -101,7 +101,7 @@ def read_re2_bcs(path):
     first (velocity) boundary-condition section of a "#v002" .re2 file."""
     raw = open(path, "rb").read()
     hdr = raw[:80].decode().split()
-    if hdr[0] != "#v002":
+    if hdr[0] not in ("#v002", "#v003"):   # v003 = v002 layout, velocity BC section only (Nek5000 reader_re2.f)
         raise ValueError("unsupported .re2 version %r" % hdr[0])
     nel, dim = int(hdr[1]), int(hdr[2])
     if abs(np.frombuffer(raw[80:84], dtype=np.float32)[0] - 6.54321) > 1e-5:
@@ -140,7 +140,7 @@ def read_re2(path):
     (element 1-based, edge 1-based, params[5], type), bcs = list of (element, face, tag) of the velocity section)."""
     raw = open(path, "rb").read()
     hdr = raw[:80].decode().split()
-    if hdr[0] != "#v002":
+    if hdr[0] not in ("#v002", "#v003"):   # v003 = v002 layout, velocity BC section only (Nek5000 reader_re2.f)
         raise ValueError("unsupported .re2 version %r" % hdr[0])
     nel, dim = int(hdr[1]), int(hdr[2])
     if abs(np.frombuffer(raw[80:84], dtype=np.float32)[0] - 6.54321) > 1e-5:
@@ -200,8 +200,34 @@ def re2_gll_coords(xc, yc, curves, n, zc=None):
         lo = [sum(S[q][None] * c[:, q, None, None] for q in range(4)) for c in (xc, yc, zc)]
         hi = [sum(S[q][None] * c[:, 4 + q, None, None] for q in range(4)) for c in (xc, yc, zc)]
         X, Y, Z = [lo[d][:, None] * h0[None, :, None, None] + hi[d][:, None] * h1[None, :, None, None] for d in range(3)]
+    # 'm' (midside node) edges: the element is the biquadratic image of its 3 x 3 Lagrangian nodes (Nek5000 `xyzquad`): vertices,
+    # edge midpoints (the curve record's point on an 'm' edge, the mean of the end points otherwise), centre node by
+    # transfinite blending of the edges (Nek5000 `gh_face_extend`), interpolated from (-1, 0, 1) to the GLL points
+    mids = {}
+    for ie, isid, par, typ in curves:
+        if typ == "m":
+            if dim == 3:
+                raise NotImplementedError("midside-node edges of 3-D elements")
+            mids.setdefault(ie - 1, {})[isid] = (par[0], par[1])
+    if mids:
+        q0, q1, q2 = 0.5 * z * (z - 1.0), 1.0 - z * z, 0.5 * z * (z + 1.0)      # quadratic Lagrange basis on (-1, 0, 1)
+        Q = np.stack([q0, q1, q2], axis=0)                                        # [node, gll point]
+        for e, em in mids.items():
+            for c, C in ((xc, X), (yc, Y)):
+                k = 0 if c is xc else 1
+                g = np.zeros((3, 3))                                              # [j, i]
+                g[0, 0], g[0, 2], g[2, 2], g[2, 0] = c[e, 0], c[e, 1], c[e, 2], c[e, 3]
+                ends = {1: (0, 1), 2: (1, 2), 3: (2, 3), 4: (3, 0)}
+                pos = {1: (0, 1), 2: (1, 2), 3: (2, 1), 4: (1, 0)}
+                for sd in (1, 2, 3, 4):
+                    a, b = ends[sd]
+                    g[pos[sd]] = em[sd][k] if sd in em else 0.5 * (c[e, a] + c[e, b])
+                g[1, 1] = 0.5 * (g[0, 1] + g[1, 2] + g[2, 1] + g[1, 0]) - 0.25 * (g[0, 0] + g[0, 2] + g[2, 2] + g[2, 0])
+                C[e] = Q.T @ g @ Q
     for ie, isid, par, typ in curves:
         e = ie - 1
+        if typ == "m":
+            continue
         if typ != "C":
             raise NotImplementedError("curve type %r (only circular arcs 'C' are built)" % typ)
         if isid > 8:

@@ -6,6 +6,13 @@
 Navier-Stokes solution at Re = 50 on the curved cylinder mesh.  tests/test_cpu_reference_data.py checks the
 oracle's operators against it (discrete divergence ~1e-11, steady momentum residual ~1e-7).
 
+Round 3 adds the two other base-flow files the reference ships next to a case that uses the hot path:
+  examples/back_fstep/transient_growth/BF_bfs0.f00001 (+ bfs.re2: midside-node edges 'm', boundary ids; the tags the ids stand
+      for are the four setbc calls of bfs.usr:112-115) -- the base flow of the reference's transient-growth (svds) case,
+      E = 2760, lx1 = 6, Re = 600 (bfs.par:31), run with an explicit filter of weight 0.01 (bfs.par:16-18);
+  examples/rayBen/baseflow/BF_rayBen0.f00001 (+ rayBen.re2) -- fields XUPT on a 10 x 4 box, lx1 = 10.
+-> reference_bfs_baseflow.npz, reference_rayben_baseflow.npz (numbers only: coordinates, fields, element map, boundary records).
+
 Run from the repo root (needs /root/reference):  python tests/golden/make_reference_fixture.py
 """
 import os
@@ -60,3 +67,40 @@ if __name__ == "__main__":
                         curve_edge=np.array([c[1] for c in r["curves"]]), curve_par=np.array([c[2] for c in r["curves"]]),
                         vert=m["vert"], pmap=m["pmap"])
     print(out2, os.path.getsize(out2), "bytes")
+
+    # ---- backward-facing step (transient growth) ------------------------------------------------------------------------
+    from neklab_amd.nekio import re2_gll_coords
+    bdir = "/root/reference/examples/back_fstep/transient_growth/"
+    fb = rf(bdir + "BF_bfs0.f00001")
+    rb = read_re2(bdir + "bfs.re2")
+    raw = open(bdir + "bfs.re2", "rb").read()
+    off = 84 + 8 * (1 + 2 * 4) * rb["nel"]
+    nc = int(np.frombuffer(raw[off: off + 8], dtype=np.float64)[0])
+    off += 8 + 64 * nc
+    nbc = int(np.frombuffer(raw[off: off + 8], dtype=np.float64)[0])
+    off += 8
+    bid = []                       # gmsh boundary id of every record (fifth parameter; the tag in the file is 'MSH')
+    for _ in range(nbc):
+        bid.append(int(np.frombuffer(raw[off: off + 56], dtype=np.float64)[6]))
+        off += 64
+    assert all(np.array_equal(fb[k].astype(np.float32).astype(np.float64), fb[k]) for k in ("ux", "uy"))
+    out3 = OUT.replace("reference_cyl_baseflow", "reference_bfs_baseflow")
+    np.savez_compressed(out3, n=np.array(6), x=fb["x"], y=fb["y"], ux=fb["ux"].astype(np.float32), uy=fb["uy"].astype(np.float32),
+                        p=fb["p"], re=np.array(600.0), lxd=np.array(9), elmap=fb["elmap"],
+                        bc_elem=np.array([b[0] for b in rb["bcs"]]), bc_face=np.array([b[1] for b in rb["bcs"]]), bc_id=np.array(bid),
+                        # bfs.usr:112-115  setbc(5,1,'W  '), setbc(2,1,'v  '), setbc(3,1,'v  '), setbc(4,1,'SYM')
+                        id_list=np.array([5, 2, 3, 4]), id_tag=np.array(["W", "v", "v", "SYM"]),
+                        xc=rb["xc"], yc=rb["yc"], curve_elem=np.array([c[0] for c in rb["curves"]]),
+                        curve_edge=np.array([c[1] for c in rb["curves"]]), curve_par=np.array([c[2] for c in rb["curves"]]))
+    print(out3, os.path.getsize(out3), "bytes")
+    # ---- Rayleigh-Benard box ----------------------------------------------------------------------------------------------
+    rdir = "/root/reference/examples/rayBen/baseflow/"
+    fr = rf(rdir + "BF_rayBen0.f00001")
+    rr = read_re2(rdir + "rayBen.re2")
+    out4 = OUT.replace("reference_cyl_baseflow", "reference_rayben_baseflow")
+    np.savez_compressed(out4, n=np.array(10), x=fr["x"], y=fr["y"], ux=fr["ux"], uy=fr["uy"], p=fr["p"], t=fr["t"], lxd=np.array(15),
+                        elmap=fr["elmap"], bc_elem=np.array([b[0] for b in rr["bcs"]]), bc_face=np.array([b[1] for b in rr["bcs"]]),
+                        bc_tag=np.array([b[2] for b in rr["bcs"]]),
+                        # rayBen.par:5-6 userParam05 = Pr, userParam06 = Ra; rayBen.usr:98 ffy = temp * Ra * Pr
+                        prandtl=np.array(1.0), rayleigh=np.array(1900.0))
+    print(out4, os.path.getsize(out4), "bytes")

@@ -56,3 +56,68 @@ def load_cylinder(with_bcs=False, dirichlet_tags=("v", "W"), geometry="fld"):
     rr = np.hypot(x, y)
     interior = (x > -16 + 1e-6) & (x < 50 - 1e-6) & (np.abs(y) < 16 - 1e-6) & (rr > 0.5 + 1e-6)
     return hm, d["ux"].copy(), d["uy"].copy(), d["p"].copy(), float(d["re"]), int(d["lxd"]), interior
+
+
+def _glo_from_coords(x, y, tol=1e-7):
+    key = np.round(np.stack([x.ravel(), y.ravel()], 1) / tol).astype(np.int64)
+    _, glo = np.unique(key, axis=0, return_inverse=True)
+    return glo.reshape(x.shape).astype(np.int64)
+
+
+def load_bfs(with_bcs=False):
+    """The base flow of the reference's transient-growth case (tests/golden/reference_bfs_baseflow.npz; rounded backward-facing
+    step, E = 2760, lx1 = 6, Re = 600).  with_bcs: the boundary ids of bfs.re2 with the tags bfs.usr:112-115 gives them --
+    'W' and 'v' faces Dirichlet for every component, 'SYM' faces (the horizontal lines y = 20 and y = 1, x < -2) Dirichlet
+    for the normal component uy only; no outflow face, so the pressure level is free.
+    -> (mesh, ux, uy, p, re, lxd, interior mask)"""
+    from neklab_amd.nekio import face_nodes
+    d = np.load(os.path.join(HERE, "golden", "reference_bfs_baseflow.npz"))
+    n = int(d["n"])
+    x, y = d["x"].copy(), d["y"].copy()
+    E = x.shape[0]
+    glo = _glo_from_coords(x, y)
+    ones = np.ones((E, n * n))
+    mask = [ones.copy(), ones.copy()]
+    onb = np.zeros((E, n * n))
+    pos = {int(g): k for k, g in enumerate(d["elmap"])}
+    tag_of = {int(i): str(t) for i, t in zip(d["id_list"], d["id_tag"])}
+    for ge, fc, bid in zip(d["bc_elem"], d["bc_face"], d["bc_id"]):
+        nodes = face_nodes(n, 2, int(fc))
+        e = pos[int(ge)]
+        onb[e, nodes] = 1.0
+        if with_bcs:
+            tag = tag_of[int(bid)]
+            if tag in ("W", "v"):
+                mask[0][e, nodes] = 0.0
+                mask[1][e, nodes] = 0.0
+            elif tag == "SYM":
+                assert np.ptp(y[e, nodes]) < 1e-9          # horizontal: the normal component is uy
+                mask[1][e, nodes] = 0.0
+            else:
+                raise ValueError(tag)
+    # a mask (and "lies on the boundary") is a property of the global dof: it holds for every copy of the point
+    def spread(arr, op, init):
+        acc = np.full(int(glo.max()) + 1, init)
+        op.at(acc, glo.ravel(), arr.ravel())
+        return acc[glo]
+    mask = [spread(m, np.minimum, 1.0) for m in mask]
+    onb = spread(onb, np.maximum, 0.0)
+    hm = BoxMesh(dim=2, n=n, nel=(E, 1), x=x, y=y, z=None, glo_num=glo, mask=mask, tmask=ones.copy(), has_outflow=False,
+                 elem_gid=np.arange(E, dtype=np.int64))
+    return hm, d["ux"].astype(np.float64), d["uy"].astype(np.float64), d["p"].copy(), float(d["re"]), int(d["lxd"]), onb < 0.5
+
+
+def load_rayben():
+    """The field file the reference ships for its Rayleigh-Benard case (tests/golden/reference_rayben_baseflow.npz; 10 x 4 box,
+    lx1 = 10, periodic in x, walls at y = 0, 1; fields X U P T).  -> (mesh, ux, uy, p, t, lxd, prandtl, rayleigh)"""
+    d = np.load(os.path.join(HERE, "golden", "reference_rayben_baseflow.npz"))
+    n = int(d["n"])
+    x, y = d["x"].copy(), d["y"].copy()
+    E = x.shape[0]
+    xk = np.where(np.abs(x - x.max()) < 1e-9, x.min(), x)      # 'P' faces: x = 0 <-> x = 2.0158
+    glo = _glo_from_coords(xk, y)
+    wall = (np.abs(y) < 1e-9) | (np.abs(y - 1.0) < 1e-9)       # 'W' / 't' faces of rayBen.re2 (rayBen.box)
+    m = np.where(wall, 0.0, 1.0)
+    hm = BoxMesh(dim=2, n=n, nel=(E, 1), x=x, y=y, z=None, glo_num=glo, mask=[m.copy(), m.copy()], tmask=m.copy(), has_outflow=False,
+                 elem_gid=np.arange(E, dtype=np.int64))
+    return hm, d["ux"].copy(), d["uy"].copy(), d["p"].copy(), d["t"].copy(), int(d["lxd"]), float(d["prandtl"]), float(d["rayleigh"])

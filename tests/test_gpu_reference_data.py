@@ -41,3 +41,68 @@ def test_gpu_operators_on_reference_base_flow(gpu_ctx):
     for i in range(2):
         r = res.get_field(i) * binv
         assert np.sqrt(np.mean(r[inter] ** 2)) < 1e-6 and np.abs(r[inter]).max() < 1e-5
+
+
+def test_gpu_operators_on_bfs_base_flow(gpu_ctx):
+    """tests/test_cpu_reference_data.py::test_bfs_base_flow_divergence_and_steady_residual through the HIP kernels (lx1 = 6, lxd = 9,
+    midside-node elements): the same filter-sized bounds."""
+    from refdata import load_bfs
+    hm, ux, uy, p, re, lxd, interior = load_bfs()
+    gm = host.Mesh(gpu_ctx, hm, lxd=lxd)
+    lib = gm.lib
+    n, E = hm.n, hm.E
+    bm2 = gm.get("bm2", 2)
+    binv = gm.get("binvm1")
+    U = host.nek_dvector(gm)
+    U.set_field(host.VX, ux)
+    U.set_field(host.VY, uy)
+    out = host.nek_dvector(gm)
+    host.check(lib.nlg_op_opdiv(gm.h, U.h, out.h))
+    div = out.get_field(host.PR) / bm2
+    l2 = np.sqrt(np.sum(div ** 2 * bm2) / np.sum(bm2))
+    assert l2 < 6e-7 and np.abs(div).max() < 1e-5, (l2, np.abs(div).max())
+    from oracle.sem import gl, gll, interp_matrix
+    I12 = interp_matrix(gll(n)[0], gl(n - 2)[0])
+    U.set_field(host.PR, np.einsum("by,ax,eyx->eba", I12, I12, p.reshape(E, n, n)))
+    conv, hel, gpt, res = (host.nek_dvector(gm) for _ in range(4))
+    host.check(lib.nlg_op_conv(gm.h, U.h, U.h, conv.h, 0))
+    host.check(lib.nlg_op_helmholtz(gm.h, U.h, hel.h, 1.0 / re, 0.0, 0))
+    host.check(lib.nlg_op_opgradt(gm.h, U.h, gpt.h))
+    for i in range(2):
+        res.set_field(i, 0.5 * conv.get_field(i) + hel.get_field(i) - gpt.get_field(i))
+    host.check(lib.nlg_op_dssum(gm.h, res.h))
+    inter = interior.ravel()
+    for i in range(2):
+        r = res.get_field(i) * binv
+        assert np.sqrt(np.mean(r[inter] ** 2)) < 8e-6 and np.abs(r[inter]).max() < 1.2e-4
+
+
+def test_gpu_hydrostatic_balance_on_rayben_field(gpu_ctx):
+    """tests/test_cpu_reference_data.py::test_rayben_field_file_conduction_state_and_hydrostatic_balance, check (b), through the
+    library's temperature-coupled nonlinear step (nlg_linop_nonlinear_map, cfg.ifheat): with the file's temperature, the case's
+    buoyancy Ra Pr T and the hydrostatic pressure Ra Pr (2 y - y^2) the state stays at rest; with the sign flipped it does not."""
+    from refdata import load_rayben
+    from oracle.sem import gl, gll, interp_matrix
+    hm, ux, uy, p, t, lxd, pr, ra = load_rayben()
+    gm = host.Mesh(gpu_ctx, hm, lxd=lxd)
+    n, E = hm.n, hm.E
+    I12 = interp_matrix(gll(n)[0], gl(n - 2)[0])
+    y2 = np.einsum("by,ax,eyx->eba", I12, I12, hm.y.reshape(E, n, n))
+    bm2 = gm.get("bm2", 2).reshape(y2.shape)
+    ph = ra * pr * (2.0 * y2 - y2 ** 2)
+    ph = ph - np.sum(ph * bm2) / np.sum(bm2)
+    out = {}
+    for sgn in (1.0, -1.0):
+        X = host.nek_dvector(gm, 1)
+        X.set_field(host.THETA, t)
+        X.set_field(host.PR, ph)
+        A = host.exptA_linop(2e-3, X, re=1.0 / pr, torder=1, dt=1e-3, vtol=1e-13, ptol=1e-13, maxit_v=2000, maxit_p=6000, ifheat=1,
+                             conductivity=1.0, rhocp=1.0, buoy=(0.0, sgn * ra * pr, 0.0))
+        A.init()
+        F = host.nek_dvector(gm, 1)
+        host.check(gpu_ctx.lib.nlg_linop_nonlinear_map(A.h, X.h, F.h))
+        dp = F.get_field(host.PR).reshape(y2.shape)
+        dp = dp - np.sum(dp * bm2) / np.sum(bm2)
+        out[sgn] = (max(np.abs(F.get_field(i)).max() for i in range(2)), np.abs(dp).max() / np.abs(ph).max(), np.abs(F.get_field(host.THETA)).max())
+    assert out[1.0][0] < 2e-5 and out[1.0][1] < 5e-6 and out[1.0][2] < 1e-6, out
+    assert out[-1.0][0] > 100 * out[1.0][0] and out[-1.0][1] > 1.0, out
