@@ -240,6 +240,8 @@ def main():
     PROF_STRIDE = 8
     host.check(lib.nlg_prof_sample(ctx.h, PROF_STRIDE))
     st1 = A.stats()
+    nlaunch0, ncoll0 = C.c_int64(), C.c_int64()
+    host.check(lib.nlg_counters(C.byref(nlaunch0), C.byref(ncoll0)))
 
     # ---- timed region: exactly K steps
     barrier()
@@ -254,6 +256,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st2 = A.stats()
+    nlaunch1, ncoll1 = C.c_int64(), C.c_int64()
+    host.check(lib.nlg_counters(C.byref(nlaunch1), C.byref(ncoll1)))
+    launches_per_step = (nlaunch1.value - nlaunch0.value) / max(args.steps, 1)
+    coll_per_step = (ncoll1.value - ncoll0.value) / max(args.steps, 1)
     cnt, ms = C.c_int64(), C.c_double()
     host.check(lib.nlg_prof_get(ctx.h, dominant.encode(), C.byref(cnt), C.byref(ms)))
     host.check(lib.nlg_prof_enable(ctx.h, 0))
@@ -379,6 +385,10 @@ def main():
                        "vectors_per_step": sblk,
                        "elements_per_gpu": E_global / world, "time_steps_per_matvec": steps_per_mv / sblk,
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
+                       # kernel launches and collective sites (all-reduce, all-gather, gather-scatter / Schwarz halo exchanges; counted on
+                       # one rank too) per step, and per vector of a block step
+                       "launches_per_step": round(launches_per_step, 1), "collectives_per_step": round(coll_per_step, 1),
+                       "launches_per_vector": round(launches_per_step / sblk, 1), "collectives_per_vector": round(coll_per_step / sblk, 1),
                        "dt": info["dt"], "tau": info["tau"], "setup_s": round(setup_s, 2),
                        "global_elements": E_global,
                        "element_matvecs_per_s": E_global * sblk * args.steps / elapsed,

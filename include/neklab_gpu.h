@@ -87,6 +87,11 @@ int nlg_prof_enable(nlg_ctx *ctx, int class_mask); /* bit i = class i in the ord
 int nlg_prof_sample(nlg_ctx *ctx, int stride);
 int nlg_prof_reset(nlg_ctx *ctx);
 int nlg_prof_get(nlg_ctx *ctx, const char *name, int64_t *count, double *total_ms);
+/* Running totals since the library was loaded: kernel launches issued, and collective sites passed (all-reduce, all-gather and
+ * gather-scatter / Schwarz halo exchanges -- counted on one rank too, where they move nothing: what a partitioned run of the same
+ * calls issues).  bench.py reports the difference over its timed region per step.  The reference's counterpart: every glsc3 /
+ * gs_op / nekgsync inside nek_advance, which it does not count. */
+int nlg_counters(int64_t *launches, int64_t *collectives);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* mesh: replaces the Nek5000 commons the reference reads through include "SIZE"/"TOTAL"            */
@@ -124,6 +129,19 @@ int nlg_mesh_get(const nlg_mesh *mesh, const char *name, double *out, int64_t co
  * ifpsco), lorder as in SIZE (restart history holds lorder-1 slots). */
 int nlg_vec_create(nlg_mesh *mesh, int nscal, int lorder, nlg_vec **out);
 int nlg_vec_destroy(nlg_vec *v);
+/* Handle lifetimes for host languages whose objects are copied bit by bit behind the type's back (the reference's vectors are
+ * plain static arrays: src/vectors/neklab_vectors.f90:26-36; Fortran intrinsic assignment / sourced allocation / reallocation on
+ * assignment duplicate a shim object together with its handle).  The owner's finaliser RELEASES instead of destroying; a copy
+ * that is used later ADOPTS: *status = 1 -- the handle had been released and now belongs to the caller (nothing copied, nothing
+ * leaked); *status = 0 -- it is still owned by a live object: the caller clones.  `gen` is the generation number the caller read
+ * when it last owned or copied the handle (nlg_vec_generation): a handle that was freed in between is an error, not a crash.
+ * Released buffers are freed oldest first above nlg_vec_pool_limit bytes (default 32 GiB), when an allocation fails, and by
+ * nlg_vec_pool_trim.  nlg_vec_destroy frees at once, as before (hosts with reference semantics: the Python mirror). */
+int nlg_vec_generation(const nlg_vec *v, int64_t *gen);
+int nlg_vec_release(nlg_vec *v);
+int nlg_vec_adopt(nlg_vec *v, int64_t gen, int *status);
+int nlg_vec_pool_limit(int64_t bytes);
+int nlg_vec_pool_trim(int64_t *freed_bytes);
 /* Fortran intrinsic assignment / sourced allocation of a nek_dvector */
 int nlg_vec_clone(const nlg_vec *src, nlg_vec **out);
 int nlg_vec_copy(nlg_vec *dst, const nlg_vec *src);
@@ -150,6 +168,8 @@ int nlg_vec_size(const nlg_vec *self, int64_t *out);
 /* the same as a plain function value (-1: NULL handle): the reference declares nek_dsize `pure`
  * (neklab_vectors.f90:91-93), and a pure Fortran function can only call interfaces that are themselves pure */
 int64_t nlg_vec_size_value(const nlg_vec *self);
+/* dhas_rst_fields as a plain function value for the same reason: the reference declares it `pure` (neklab_vectors.f90:107-110) */
+int nlg_vec_has_rst_value(const nlg_vec *self);
 /* outpost_dnek  src/neklab_utils.f90:305-333 (Nek5000 `outpost(vx, vy, vz, pr, t, prefix)`): one vector -> one Nek5000
  * field file at `path` ("#std" header, fp64): GLL coordinates when with_coords != 0 (Nek5000 writes them into the first
  * file of a series only), velocity, the pressure mapped to the velocity mesh (Nek5000's `mappr` for a Pn-Pn-2 run), the

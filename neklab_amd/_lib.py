@@ -67,6 +67,12 @@ SIGNATURES = {
     "nlg_prof_sample": (C.c_int, [vp, C.c_int]),
     "nlg_prof_reset": (C.c_int, [vp]),
     "nlg_prof_get": (C.c_int, [vp, C.c_char_p, c_int64_p, c_double_p]),
+    "nlg_counters": (C.c_int, [c_int64_p, c_int64_p]),
+    "nlg_vec_generation": (C.c_int, [vp, c_int64_p]),
+    "nlg_vec_release": (C.c_int, [vp]),
+    "nlg_vec_adopt": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int)]),
+    "nlg_vec_pool_limit": (C.c_int, [C.c_int64]),
+    "nlg_vec_pool_trim": (C.c_int, [c_int64_p]),
     "nlg_mesh_create": (C.c_int, [vp, C.POINTER(MeshDesc), C.POINTER(vp)]),
     "nlg_mesh_destroy": (C.c_int, [vp]),
     "nlg_mesh_sizes": (C.c_int, [vp, c_int64_p, c_int64_p, c_int_p, c_int_p]),
@@ -79,6 +85,7 @@ SIGNATURES = {
     "nlg_vec_rand": (C.c_int, [vp, C.c_int, C.c_uint64]),
     "nlg_vec_rand_noise": (C.c_int, [vp, C.c_uint64]),
     "nlg_vec_size_value": (C.c_int64, [vp]),
+    "nlg_vec_has_rst_value": (C.c_int, [vp]),
     "nlg_basis_block_cgs2": (C.c_int, [vp, C.c_int, C.c_int, c_double_p]),
     "nlg_linop_matvec_block": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int]),
     "nlg_block_arnoldi_step": (C.c_int, [vp, vp, C.c_int, C.c_int, c_double_p, C.c_int, C.c_int]),

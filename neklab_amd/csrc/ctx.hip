@@ -15,19 +15,24 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int64_t g_launches = 0, g_collectives = 0;
+
 int allreduce_sum(nlg_ctx *ctx, double *d_buf, int count) {
+    ++g_collectives;   // counted whether or not a communicator exists: a one-rank run reports what several ranks would issue
     if (ctx->shm) return shm_allreduce(ctx, d_buf, count, false);
     if (ctx->comm) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
     return 0;
 }
 
 int allreduce_max(nlg_ctx *ctx, double *d_buf, int count) {
+    ++g_collectives;
     if (ctx->shm) return shm_allreduce(ctx, d_buf, count, true);
     if (ctx->comm) NLG_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
     return 0;
 }
 
 int allgather_f64(nlg_ctx *ctx, const double *d_in, double *d_out, int64_t count) {
+    ++g_collectives;
     if (ctx->shm)
         return shm_allgather_i64(ctx, reinterpret_cast<const int64_t *>(d_in), reinterpret_cast<int64_t *>(d_out), count);
     if (ctx->comm) {
@@ -137,6 +142,12 @@ extern "C" int nlg_prof_get(nlg_ctx *ctx, const char *name, int64_t *count, doub
         }
     set_error("nlg_prof_get: unknown kernel class '%s'", name);
     return 1;
+}
+
+extern "C" int nlg_counters(int64_t *launches, int64_t *collectives) {
+    if (launches) *launches = nlg::g_launches;
+    if (collectives) *collectives = nlg::g_collectives;
+    return 0;
 }
 
 extern "C" {

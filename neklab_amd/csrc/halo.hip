@@ -31,21 +31,26 @@ struct F3 {
 
 template <int NF>
 __global__ __launch_bounds__(NT) void k_halo_pack(const int *__restrict__ send_idx, int64_t ntot, F3 f,
-                                                  double *__restrict__ buf) {
+                                                  double *__restrict__ buf, int64_t ld) {
+    // blockIdx.y = lane of a block step: fields ld doubles behind lane 0's, buffer rows lane * NF + c (one exchange for all lanes)
     const int64_t e = blockIdx.x * (int64_t)NT + threadIdx.x;
     if (e >= ntot) return;
     const int i = send_idx[e];
+    const int64_t lo = (int64_t)blockIdx.y * ld;
 #pragma unroll
-    for (int c = 0; c < NF; ++c) buf[c * ntot + e] = f.p[c][i];
+    for (int c = 0; c < NF; ++c) buf[((int64_t)blockIdx.y * NF + c) * ntot + e] = f.p[c][lo + i];
 }
 
 template <int NF>
 __global__ __launch_bounds__(NT) void k_halo_unpack(int64_t nlab, const int *__restrict__ roff,
                                                     const int *__restrict__ rpos, const int *__restrict__ coff,
                                                     const int *__restrict__ cidx, int64_t ntot,
-                                                    const double *__restrict__ buf, F3 f) {
+                                                    const double *__restrict__ buf, F3 f, int64_t ld) {
     const int64_t l = blockIdx.x * (int64_t)NT + threadIdx.x;
     if (l >= nlab) return;
+    buf += (int64_t)blockIdx.y * NF * ntot;
+#pragma unroll
+    for (int c = 0; c < NF; ++c) f.p[c] += (int64_t)blockIdx.y * ld;
     double s[NF];
 #pragma unroll
     for (int c = 0; c < NF; ++c) s[c] = 0.0;
@@ -271,12 +276,12 @@ int halo_setup(nlg_mesh *m, const int64_t *glo) {
         NLG_TRY(up(to_xp(send_idx), &h.d_send_idx_xp));
         NLG_TRY(up(to_xp(cidx), &h.d_cidx_xp));
     }
-    NLG_HIP(hipMalloc(&h.d_send, sizeof(double) * (size_t)tot * 3));
-    NLG_HIP(hipMalloc(&h.d_recv, sizeof(double) * (size_t)tot * 3));
+    NLG_HIP(hipMalloc(&h.d_send, sizeof(double) * (size_t)tot * 3 * kMaxLanes));   // up to three fields of every lane of a block step
+    NLG_HIP(hipMalloc(&h.d_recv, sizeof(double) * (size_t)tot * 3 * kMaxLanes));
     NLG_HIP(hipEventCreateWithFlags(&h.ev_packed, hipEventDisableTiming));
     NLG_HIP(hipEventCreateWithFlags(&h.ev_recv, hipEventDisableTiming));
     const char *ov = getenv("NLG_HALO_OVERLAP");
-    h.overlap = ov && atoi(ov) != 0 && !ctx->shm;
+    h.overlap = ov && atoi(ov) != 0;   // (also under the shm validation transport: the event choreography is the same)
     h.active = true;
     NLG_TRY(gs_split(m));
     return 0;
@@ -345,24 +350,37 @@ int gs_split(nlg_mesh *m) {
     return 0;
 }
 
-int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout) {
+int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout, int nl, int64_t ld) {
     nlg_halo &h = m->halo;
     if (!h.active) return 0;
+    NLG_CHECK(nl >= 1 && nl <= kMaxLanes, "halo_exchange: %d lanes", nl);
     NLG_CHECK(layout != LAYOUT_FG || h.d_send_idx_fg, "halo_exchange: no face-grouped index lists");
     NLG_CHECK(layout != LAYOUT_XP || h.d_send_idx_xp, "halo_exchange: no slab-permuted index lists");
     const int *send_idx = layout == LAYOUT_FG ? h.d_send_idx_fg : (layout == LAYOUT_XP ? h.d_send_idx_xp : h.d_send_idx);
     nlg_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
-    const int g1 = (int)((h.ntot + NT - 1) / NT);
+    const dim3 g1((unsigned)((h.ntot + NT - 1) / NT), (unsigned)nl);
     if (nf == 1)
-        hipLaunchKernelGGL(k_halo_pack<1>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
+        NLG_LAUNCH(k_halo_pack<1>, g1, dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send, ld);
     else if (nf == 2)
-        hipLaunchKernelGGL(k_halo_pack<2>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
+        NLG_LAUNCH(k_halo_pack<2>, g1, dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send, ld);
     else
-        hipLaunchKernelGGL(k_halo_pack<3>, dim3(g1), dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send);
+        NLG_LAUNCH(k_halo_pack<3>, g1, dim3(NT), 0, st, send_idx, h.ntot, f, h.d_send, ld);
     NLG_HIP(hipGetLastError());
-    if (ctx->shm) return shm_exchange(ctx, h, nf);
+    nf *= nl;   // rows of the packed buffers from here on: one send / receive group carries every lane
+    if (ctx->shm) {
+        if (h.overlap) {
+            // validation transport with NLG_HALO_OVERLAP=1: the staging copy and the host-side exchange are ordered on the side stream
+            // by the same two events the RCCL path uses, so that the fork / join choreography itself runs on one GPU
+            NLG_HIP(hipEventRecord(h.ev_packed, st));
+            NLG_HIP(hipStreamWaitEvent(ctx->stream2, h.ev_packed, 0));
+            NLG_TRY(shm_exchange(ctx, h, nf, ctx->stream2));
+            NLG_HIP(hipEventRecord(h.ev_recv, ctx->stream2));
+            return 0;
+        }
+        return shm_exchange(ctx, h, nf, st);
+    }
     // the send / receive group goes to the side stream when the overlap is switched on: it starts when the pack kernel has
     // finished and halo_finish makes the launch stream wait for it, so the communicator never sees two operations at once
     hipStream_t sx = h.overlap ? ctx->stream2 : st;
@@ -381,27 +399,27 @@ int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout) {
     return 0;
 }
 
-int halo_finish(nlg_mesh *m, double *const *fields, int nf, int layout) {
+int halo_finish(nlg_mesh *m, double *const *fields, int nf, int layout, int nl, int64_t ld) {
     nlg_halo &h = m->halo;
     if (!h.active) return 0;
     const int *cidx = layout == LAYOUT_FG ? h.d_cidx_fg : (layout == LAYOUT_XP ? h.d_cidx_xp : h.d_cidx);
     hipStream_t st = m->ctx->stream;
-    if (h.overlap && !m->ctx->shm) NLG_HIP(hipStreamWaitEvent(st, h.ev_recv, 0));
+    if (h.overlap) NLG_HIP(hipStreamWaitEvent(st, h.ev_recv, 0));
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
-    const int g2 = (int)((h.nlab + NT - 1) / NT);
+    const dim3 g2((unsigned)((h.nlab + NT - 1) / NT), (unsigned)nl);
     if (nf == 1)
-        hipLaunchKernelGGL(k_halo_unpack<1>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
+        NLG_LAUNCH(k_halo_unpack<1>, g2, dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f, ld);
     else if (nf == 2)
-        hipLaunchKernelGGL(k_halo_unpack<2>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
+        NLG_LAUNCH(k_halo_unpack<2>, g2, dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f, ld);
     else
-        hipLaunchKernelGGL(k_halo_unpack<3>, dim3(g2), dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f);
+        NLG_LAUNCH(k_halo_unpack<3>, g2, dim3(NT), 0, st, h.nlab, h.d_roff, h.d_rpos, h.d_coff, cidx, h.ntot, h.d_recv, f, ld);
     NLG_HIP(hipGetLastError());
     return 0;
 }
 
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout) {
-    NLG_TRY(halo_begin(m, fields, nf, layout));
-    return halo_finish(m, fields, nf, layout);
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout, int nl, int64_t ld) {
+    NLG_TRY(halo_begin(m, fields, nf, layout, nl, ld));
+    return halo_finish(m, fields, nf, layout, nl, ld);
 }
 
 void halo_free(nlg_mesh *m) {

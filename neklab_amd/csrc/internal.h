@@ -48,6 +48,15 @@ void set_error(const char *fmt, ...);
         if (rc_) return rc_;    \
     } while (0)
 
+// every kernel launch of the library goes through this macro: the count is what bench.py reports as launches per step
+extern int64_t g_launches, g_collectives;
+#define NLG_LAUNCH(...)                     \
+    do {                                    \
+        ++nlg::g_launches;                  \
+        hipLaunchKernelGGL(__VA_ARGS__);    \
+    } while (0)
+
+constexpr int kMaxLanes = 4;            // vectors advanced together by the block stepper
 constexpr int kMaxBlocksReduce = 1024;  // fixed first-stage grid => run-to-run deterministic sums
 constexpr int kAlign = 32;              // field starts aligned to 32 doubles (256 B)
 
@@ -239,6 +248,9 @@ struct nlg_pprec {
     int na_max = 0, ncols = 0;                   // several ranks: ncols = nranks * na_max columns (global aggregate level)
     double *d_rag = nullptr;                     // [ncols] aggregate residuals of all ranks (all-gather of d_ra)
     double *d_rc = nullptr, *d_x = nullptr, *d_ra = nullptr, *d_xa = nullptr;
+    // lanes of a block step: `lanes_cap` copies of W, tq, rc / x, ra, xa at these strides (pprec_reserve_lanes)
+    int lanes_cap = 1;
+    int64_t lW = 0, lt = 0, lv = 0, la = 0, la_x = 0;
 };
 
 struct nlg_mesh {
@@ -276,6 +288,7 @@ struct nlg_mesh {
     int *d_slot_xp = nullptr;
     int *d_slot_fg = nullptr;   // device copy of h_slot (lx1 > 8 pressure kernels read it instead of computing the slot)
     double *d_vmult_xp = nullptr;
+    double *d_wlanes = nullptr;   // [kMaxLanes][3][lvs] intermediate fields of the pressure operator of a block step (lazy)
     nlg_gs gs;
     double volvm1 = 0, volvm2 = 0;
     int64_t lpn_global = 0;   // global pressure dof count (ortho)
@@ -345,7 +358,7 @@ int allreduce_max(nlg_ctx *ctx, double *d_buf, int count);
 int allgather_f64(nlg_ctx *ctx, const double *d_in, double *d_out, int64_t count);   // count doubles per rank
 int shm_allreduce(nlg_ctx *ctx, double *d_buf, int count, bool is_max);
 int shm_allgather_i64(nlg_ctx *ctx, const int64_t *d_in, int64_t *d_out, int64_t count);
-int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf);
+int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf, hipStream_t st);   // st: the stream the staging copies are ordered on
 void shm_close(nlg_ctx *ctx);
 
 int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_out, double *d_acc);
@@ -364,9 +377,10 @@ struct nlg_pcg_upd {
     double *rr_part = nullptr;   // [(E + 3) / 4]
 };
 int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap = false,
-                 const nlg_pcg_upd *upd = nullptr);
+                 const nlg_pcg_upd *upd = nullptr, int nl = 1, int64_t ld = 0);
 int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
-               double *rz_part = nullptr, bool overlap = false);
+               double *rz_part = nullptr, bool overlap = false, int nl = 1, int64_t ld = 0);
+int pprec_reserve_lanes(nlg_mesh *m, int nl);
 void pprec_free(nlg_mesh *m);
 
 // ---- lns.hip
@@ -374,20 +388,22 @@ bool linop_can_block(const nlg_linop *op);   // the multi-vector stepper covers 
 
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);
-int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout = 0);   // LAYOUT_*; = halo_begin + halo_finish
+int halo_exchange(nlg_mesh *m, double *const *fields, int nf, int layout = 0, int nl = 1, int64_t ld = 0);   // LAYOUT_*; = halo_begin + halo_finish
 int gs_split(nlg_mesh *m);   // builds gs.tab_halo / tab_rest from gs.h_groups and the halo lists
-int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout);    // pack + start of the exchange
-int halo_finish(nlg_mesh *m, double *const *fields, int nf, int layout);   // end of the exchange + unpack
+int halo_begin(nlg_mesh *m, double *const *fields, int nf, int layout, int nl = 1, int64_t ld = 0);    // pack + start of the exchange
+int halo_finish(nlg_mesh *m, double *const *fields, int nf, int layout, int nl = 1, int64_t ld = 0);   // end of the exchange + unpack
 void halo_free(nlg_mesh *m);
 
 // ---- sem.hip (device-pointer level operators; all on ctx->stream) ----
-int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr, int layout = 0);   // in place QQ^T; gate: device flag, non-zero = skip; layout: LAYOUT_NAT or LAYOUT_XP
-int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf);     // natural -> x-planes-first (out of place)
-int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf);
-int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr);
-int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
+// nl / ld / ldg (everywhere below): nl lanes of a block step in ONE launch (gridDim.y = nl): lane v's fields sit v * ld doubles
+// behind the given (lane-0) pointers, its gate v * ldg doubles behind `gate`
+int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr, int layout = 0, int nl = 1, int64_t ld = 0, int64_t ldg = 0);   // in place QQ^T; gate: device flag, non-zero = skip; layout: LAYOUT_NAT or LAYOUT_XP
+int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl = 1, int64_t ld = 0);     // natural -> x-planes-first (out of place)
+int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl = 1, int64_t ld = 0);
+int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr, int nl = 1, int64_t ld = 0, int64_t ldg = 0);
+int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr, int nl = 1, int64_t ld = 0, int64_t ldg = 0);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
-               double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr, bool xp = false);   // zf: fused u <- zf + beta u; xp: u, zf, w in the x-planes-first layout (3-D, lx1 <= 8)
+               double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr, bool xp = false, int nl = 1, int64_t ld = 0);   // zf: fused u <- zf + beta u; xp: u, zf, w in the x-planes-first layout (3-D, lx1 <= 8)
 int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *const *w, double h1, double h2, double *const *pw,
                      double *const *const *zf, const double *const *beta, const double *const *done, bool xp);
 int sem_opdiv_blocks(const nlg_mesh *m);
@@ -397,7 +413,7 @@ struct nlg_pupd;
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false, const double *gate = nullptr, const nlg_pupd *upd = nullptr);
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false,
               const double *pdot = nullptr, double *pw_part = nullptr, const double *gate = nullptr);
-int sem_opbinv(nlg_mesh *m, double *const *w);                       // w_i <- mask_i binv QQ^T w_i
+int sem_opbinv(nlg_mesh *m, double *const *w, int nl = 1, int64_t ld = 0);                       // w_i <- mask_i binv QQ^T w_i
 // direction update of a PCG performed by the operator while it loads p:  p <- (z - zmean[0]) + beta[0] p   (device scalars)
 struct nlg_pupd {
     const double *z = nullptr, *beta = nullptr, *zmean = nullptr;
@@ -422,7 +438,7 @@ int sem_conv_scalar_setup(nlg_mesh *m, const double *Theta, double **GT);
 int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, double *const *u, const double *theta, double *out, int adjoint = 0);
 int sem_scalar_grad_apply(nlg_mesh *m, double *const *GT, const double *theta, double *const *out, double sgn);
 int sem_cfl(nlg_mesh *m, double *const *U, double dt, double *cfl_host);
-int sem_ortho(nlg_mesh *m, double *p);
+int sem_ortho(nlg_mesh *m, double *p, int nl = 1, int64_t ld = 0);
 double *sem_scratch1(nlg_mesh *m, int i);
 double *sem_scratchd(nlg_mesh *m, int i);
 double *sem_scratch2(nlg_mesh *m, int i);

@@ -31,6 +31,23 @@ struct F3 {
 struct CF3 {
     const double *p[3];
 };
+// Lane batching (block stepper): the per-lane work buffers of all lanes live in ONE slab at a constant stride `ld` doubles, so a
+// kernel launched with gridDim.y = lanes reaches lane v's copy of every per-lane argument at `lane-0 pointer + v * ld`
+// (blockIdx.y is wave-uniform: the offset is scalar arithmetic, no lane loop in the kernel body).  Single-vector launches pass
+// gridDim.y = 1.  Arrays that belong to the mesh or to the base flow (weights, preconditioners, masks) are not offset.
+__device__ __forceinline__ int64_t lane_lo(int64_t ld) { return (int64_t)blockIdx.y * ld; }
+__device__ __forceinline__ F3 lane_f3(F3 a, int64_t lo) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (a.p[c]) a.p[c] += lo;
+    return a;
+}
+__device__ __forceinline__ CF3 lane_f3(CF3 a, int64_t lo) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (a.p[c]) a.p[c] += lo;
+    return a;
+}
 
 // solver scalar slots (doubles) inside a per-solver device block
 enum { S_RZ = 0, S_PW = 1, S_RZN = 2, S_RN2 = 3, S_DONE = 4, S_ITERS = 5, S_ALPHA = 6, S_BETA = 7, S_T0 = 8, S_T1 = 9, S_T2 = 10,
@@ -85,8 +102,10 @@ __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, doub
 // x = 0, r = b (in place), z = pc*r ; partial sums of (r,z)_ipw, (r,r)_nw and sum(z)
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3 pc, const double *ipw,
-                                                const double *nw, double *partial) {
+                                                const double *nw, double *partial, int64_t ld) {
     __shared__ double sm[12];
+    const int64_t lo = lane_lo(ld);
+    x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), partial += lo;
     double a = 0.0, b = 0.0, c3 = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
@@ -112,8 +131,10 @@ __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3
 }
 
 template <int NF>
-__global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p, CF3 w, const double *ipw, double *partial) {
+__global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p, CF3 w, const double *ipw, double *partial, int64_t ld) {
     __shared__ double sm[8];
+    const int64_t lo = lane_lo(ld);
+    s += lo, p = lane_f3(p, lo), w = lane_f3(w, lo), partial += lo;
     if (s[S_DONE] != 0.0) return;
     double a = 0.0, b = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -137,8 +158,10 @@ __global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p,
 // what this kernel is, so the width of an access is its efficiency.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3 x, F3 r, F3 z, CF3 p, CF3 w, CF3 pc,
-                                                  const double *ipw, const double *nw, double *partial) {
+                                                  const double *ipw, const double *nw, double *partial, int64_t ld) {
     __shared__ double sm[12];
+    const int64_t lo = lane_lo(ld);
+    s += lo, x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), p = lane_f3(p, lo), w = lane_f3(w, lo), partial += lo;
     if (s[S_DONE] != 0.0) return;
     const double alpha = s[S_ALPHA], wmean = s[S_WMEAN];
     double a = 0.0, b = 0.0, c3 = 0.0;
@@ -203,8 +226,10 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
 // that the coarse branch can run concurrently with the element-wise solves: z_total = z + xc[i / npe]
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_rz(const double *s, int gate, int64_t n, CF3 r, CF3 z, const double *ipw,
-                                              const double *xc, int npe, double *partial) {
+                                              const double *xc, int npe, double *partial, int64_t ld) {
     __shared__ double sm[8];
+    const int64_t lo = lane_lo(ld);
+    s += lo, r = lane_f3(r, lo), z = lane_f3(z, lo), partial += lo;
     if (gate && s[S_DONE] != 0.0) return;
     double a = 0.0, b = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -225,7 +250,9 @@ __global__ __launch_bounds__(NT) void k_cg_rz(const double *s, int gate, int64_t
 }
 
 template <int NF>
-__global__ __launch_bounds__(NT) void k_cg_pupdate(const double *s, int64_t n, F3 p, CF3 z, const double *xc, int npe) {
+__global__ __launch_bounds__(NT) void k_cg_pupdate(const double *s, int64_t n, F3 p, CF3 z, const double *xc, int npe, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    s += lo, p = lane_f3(p, lo), z = lane_f3(z, lo);
     if (s[S_DONE] != 0.0) return;
     const double beta = s[S_BETA], zmean = s[S_ZMEAN];
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -270,7 +297,11 @@ __device__ __forceinline__ void cg_post_logic(double *s, int mode, double tol2, 
     }
 }
 
-__global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n) {
+// `red` (several ranks): the all-reduced sums of all lanes, [lane][3]; copied into the lane's S_T slots first
+__global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int maxit, double inv_n, int64_t ld, const double *red, int nsums) {
+    s += lane_lo(ld);
+    if (red)
+        for (int q = 0; q < nsums; ++q) s[S_T0 + q] = red[3 * blockIdx.y + q];
     cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);
 }
 
@@ -279,9 +310,18 @@ __global__ void k_cg_post(double *s, int mode, double tol2, int use_tol, int max
 // loop is unrolled four-fold for the same reason: the kernel is pure load latency.
 constexpr int NTF = 1024;
 __global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int nsums, int gate, int mode, double tol2,
-                                                       int use_tol, int maxit, double inv_n, int post) {
+                                                       int use_tol, int maxit, double inv_n, int post, int64_t ld, double *red) {
     __shared__ double sm[3][NTF / 64];
-    if (gate && s[S_DONE] != 0.0) return;
+    const int64_t lo = lane_lo(ld);
+    s += lo;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (rd.p[q]) rd.p[q] += lo;
+    if (gate && s[S_DONE] != 0.0) {
+        // several ranks: a finished lane still takes part in the all-reduce of the lanes that are not; it contributes zeros
+        if (red && threadIdx.x < 3) red[3 * blockIdx.y + threadIdx.x] = 0.0;
+        return;
+    }
     double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -313,6 +353,7 @@ __global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int ns
             double a = 0.0;
             for (int w = 0; w < NTF / 64; ++w) a += sm[q][w];
             s[S_T0 + q] = a;
+            if (red) red[3 * blockIdx.y + q] = a;
         }
         if (post) cg_post_logic(s, mode, tol2, use_tol, maxit, inv_n);   // several ranks: the all-reduce comes first
     }
@@ -323,8 +364,10 @@ __global__ __launch_bounds__(NTF) void k_cg_final_post(double *s, Red rd, int ns
 constexpr int PROJ_L = 8;
 // partial[v * NB + blk] = sum over the block's share of X_v . y   (v < nvec <= PROJ_L)
 __global__ __launch_bounds__(NT) void k_proj_dots(int64_t n, const double *__restrict__ X, int64_t stride, int nvec,
-                                                  const double *__restrict__ y, double *__restrict__ partial) {
+                                                  const double *__restrict__ y, double *__restrict__ partial, int64_t ld) {
     __shared__ double sm[PROJ_L][NT / 64];
+    const int64_t lo = lane_lo(ld);
+    X += lo, y += lo, partial += lo;
     double a[PROJ_L];
 #pragma unroll
     for (int v = 0; v < PROJ_L; ++v) a[v] = 0.0;
@@ -350,8 +393,9 @@ __global__ __launch_bounds__(NT) void k_proj_dots(int64_t n, const double *__res
     }
 }
 // out[v] = sum_blk partial[v * NB + blk]
-__global__ __launch_bounds__(NT) void k_proj_reduce(const double *__restrict__ partial, int nblk, int nvec, double *__restrict__ out) {
+__global__ __launch_bounds__(NT) void k_proj_reduce(const double *__restrict__ partial, int nblk, int nvec, double *__restrict__ out, int64_t ld) {
     __shared__ double sm[NT / 64];
+    partial += lane_lo(ld), out += lane_lo(ld);
     for (int v = 0; v < nvec; ++v) {
         double t = 0.0;
         for (int i = threadIdx.x; i < nblk; i += NT) t += partial[v * NB + i];
@@ -369,8 +413,9 @@ __global__ __launch_bounds__(NT) void k_proj_reduce(const double *__restrict__ p
 }
 // y += sgn * sum_v c[v] M_v
 __global__ __launch_bounds__(NT) void k_proj_comb(int64_t n, double *__restrict__ y, const double *__restrict__ M, int64_t stride,
-                                                  int nvec, const double *__restrict__ c, double sgn) {
+                                                  int nvec, const double *__restrict__ c, double sgn, int64_t ld) {
     double cv[PROJ_L];
+    y += lane_lo(ld), M += lane_lo(ld), c += lane_lo(ld);
 #pragma unroll
     for (int v = 0; v < PROJ_L; ++v) cv[v] = v < nvec ? sgn * c[v] : 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -383,7 +428,9 @@ __global__ __launch_bounds__(NT) void k_proj_comb(int64_t n, double *__restrict_
 }
 // new basis pair: X_new = v / sqrt(nrm2), B_new = w / sqrt(nrm2); a non-positive nrm2 stores zeros (a harmless member)
 __global__ __launch_bounds__(NT) void k_proj_store(int64_t n, const double *__restrict__ v, const double *__restrict__ w,
-                                                   const double *__restrict__ nrm2, double *__restrict__ Xn, double *__restrict__ Bn) {
+                                                   const double *__restrict__ nrm2, double *__restrict__ Xn, double *__restrict__ Bn, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    v += lo, w += lo, nrm2 += lo, Xn += lo, Bn += lo;
     const double q = nrm2[0];
     const double sc = q > 0.0 ? 1.0 / sqrt(q) : 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -539,7 +586,10 @@ __global__ __launch_bounds__(NT) void k_buoyancy(int64_t n, F3 F, const double *
 
 // generic pointwise helpers
 template <int NF>
-__global__ __launch_bounds__(NT) void k_colmul_gated(const double *s, F3 w, CF3 wt, int64_t n) {
+__global__ __launch_bounds__(NT) void k_colmul_gated(const double *s, F3 w, CF3 wt, int64_t n, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    if (s) s += lo;
+    w = lane_f3(w, lo);
     if (s && s[S_DONE] != 0.0) return;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
 #pragma unroll
@@ -555,7 +605,16 @@ struct Hist {
     int k;
 };
 template <int NF>
-__global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1, double rdt, F3 rhs) {
+__global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1, double rdt, F3 rhs, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    rhs = lane_f3(rhs, lo);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (h.f[j][c]) h.f[j][c] += lo;
+            if (h.u[j][c]) h.u[j][c] += lo;
+        }
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double b = bm1[i] * rdt;
 #pragma unroll
@@ -572,7 +631,9 @@ __global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1
 
 // y_c = a_c + s1 * b_c + s2 * c_c   (any of b, c may be null)
 template <int NF>
-__global__ __launch_bounds__(NT) void k_lin3(int64_t n, F3 y, CF3 a, CF3 b, double s1, CF3 c, double s2) {
+__global__ __launch_bounds__(NT) void k_lin3(int64_t n, F3 y, CF3 a, CF3 b, double s1, CF3 c, double s2, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    y = lane_f3(y, lo), a = lane_f3(a, lo), b = lane_f3(b, lo), c = lane_f3(c, lo);
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
 #pragma unroll
         for (int q = 0; q < NF; ++q) {
@@ -587,7 +648,8 @@ __global__ __launch_bounds__(NT) void k_lin3(int64_t n, F3 y, CF3 a, CF3 b, doub
 __global__ __launch_bounds__(NT) void k_scale1(int64_t n, double *y, const double *x, double s) {
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = s * x[i];
 }
-__global__ __launch_bounds__(NT) void k_axpy1(int64_t n, double *y, const double *x, double s) {
+__global__ __launch_bounds__(NT) void k_axpy1(int64_t n, double *y, const double *x, double s, int64_t ld) {
+    y += lane_lo(ld), x += lane_lo(ld);
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] += s * x[i];
 }
 __global__ __launch_bounds__(NT) void k_recipmask(int64_t n, double *y, const double *d, const double *mask) {
@@ -650,7 +712,16 @@ struct nlg_linop {
     double *nwp = nullptr;     // bm2inv / volvm2
     double *d_s = nullptr;     // solver scalars (two blocks of S_N)
     double *d_part = nullptr;  // first-stage sums written by opdiv ([2][E]) and by the FDM kernel ([2][E/4])
+    double *d_cgpart = nullptr;   // [3][NB] first-stage sums of the PCG vector kernels
+    double *d_red = nullptr;      // several ranks: [lanes][3] sums of all lanes for ONE all-reduce (owner only, not in the slab)
     double *h_s = nullptr;     // pinned
+    // All per-lane work buffers (integrator state, PCG vectors, projection space, scalars, partial sums) are carved from ONE
+    // allocation of `slab_cap` lanes at a constant stride `slab_ld` doubles: lane v's copy of any of them is the owner's
+    // pointer + v * slab_ld, which is what lets one launch with gridDim.y = lanes serve the whole block (lane_lo()).
+    double *slab = nullptr;
+    int64_t slab_ld = 0;
+    int slab_cap = 0;
+    int64_t n_launch = 0, n_coll = 0;   // kernel launches / collectives issued by the time stepper (nlg_linop_get_counters)
     int istep = 0, adjoint = 0;
     // block stepper: lanes 1 .. 3 (created on first use by the operator that owns them); a lane shares the base-flow data
     // of its owner and must never free it
@@ -679,17 +750,6 @@ struct nlg_linop {
     int64_t st_steps = 0, st_viters = 0, st_piters = 0, st_matvecs = 0;
     int last_piters = 16, last_viters = 8;
     std::vector<int> pit_hist, vit_hist;   // iteration counts of the previous matvec, by time-step index (the pattern repeats)
-    // hipGraphs of PCG iterations, by solver / argument signature.  OPT-IN (NLG_GRAPH=1|2): measured on the reference's
-    // cylinder case (1996 elements, ~330 kernels of ~4 us per time step) graph replay changes nothing — 1437 us per time
-    // step with direct launches, 1510 / 1436 / 1456 us with graphs of 1 / 2 / 4 iterations: the host is already ahead
-    // of the device, the cost is the device-side start-up of each dependent tiny kernel, which a graph does not remove.
-    struct GraphSlot {
-        hipGraphExec_t exec = nullptr;
-        int uses = 0;
-        bool failed = false;
-    };
-    std::map<std::string, GraphSlot> graphs;
-    int graph_mode = -1;       // NLG_GRAPH: 0 off (default), 1 meshes below NLG_GRAPH_MAX points, 2 always; -1 = not read yet
 };
 
 namespace {
@@ -700,14 +760,91 @@ int lalloc(nlg_linop *op, double **p, int64_t n) {
     return 0;
 }
 
+// ---- the lane slab ----------------------------------------------------------------------------------------------------
+// every per-lane work buffer of the integrator, in slab order: f(pointer member, length in doubles).  The rotating history
+// buffers come first and are contiguous, so that one strided memset clears the integrator state of all lanes.
+template <typename F>
+void lane_buffers(nlg_linop *op, F f) {
+    nlg_mesh *m = op->mesh;
+    const int dim = m->dim;
+    for (int s = 0; s < 3; ++s)
+        for (int c = 0; c < dim; ++c) f(&op->ubuf[s][c], m->lvs);
+    for (int s = 0; s < 3; ++s)
+        for (int c = 0; c < dim; ++c) f(&op->fbuf[s][c], m->lvs);
+    if (op->cfg.ifheat) {
+        for (int q = 0; q < 3; ++q) f(&op->tbuf[q], m->lvs);
+        for (int q = 0; q < 3; ++q) f(&op->ftbuf[q], m->lvs);
+    }
+    for (int c = 0; c < dim; ++c) {
+        f(&op->rhs[c], m->lvs);
+        f(&op->x[c], m->lvs);
+        f(&op->z[c], m->lvs);
+        f(&op->pv[c], m->lvs);
+        f(&op->w[c], m->lvs);
+        f(&op->gp[c], m->lvs);
+    }
+    if (op->cfg.ifheat)
+        for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) f(v, m->lvs);
+    for (double **q : {&op->p, &op->pr_r, &op->pr_x, &op->pr_z, &op->pr_p, &op->pr_w}) f(q, m->lps);
+    if (op->cfg.pproj) {
+        f(&op->prX, (int64_t)PROJ_L * m->lps);
+        f(&op->prB, (int64_t)PROJ_L * m->lps);
+        f(&op->d_pc, 4 * PROJ_L + PROJ_L * NB);
+    }
+    f(&op->d_s, 4 * S_N);
+    f(&op->d_part, 3 * m->E + 16);
+    f(&op->d_cgpart, 3 * NB);
+}
+
+int64_t lane_stride(nlg_linop *op) {
+    int64_t off = 0;
+    lane_buffers(op, [&](double **, int64_t len) { off += round_up(len, kAlign); });
+    return off;
+}
+
+// point the members of `ln` (the owner itself for lane 0) at lane `v` of the owner's slab; the rotating buffers return to
+// their canonical places, which keeps "lane v = lane 0 + v * slab_ld" true for every member whatever was run before
+void lane_bind(nlg_linop *owner, nlg_linop *ln, int v) {
+    int64_t off = 0;
+    double *base = owner->slab + (int64_t)v * owner->slab_ld;
+    const bool heat = ln->cfg.ifheat;
+    ln->cfg.ifheat = owner->cfg.ifheat;   // (same buffer list as the owner's)
+    lane_buffers(ln, [&](double **p, int64_t len) {
+        *p = base + off;
+        off += round_up(len, kAlign);
+    });
+    ln->cfg.ifheat = heat;
+    ln->slab_ld = owner->slab_ld;
+}
+
+// make room for `cap` lanes (the work buffers hold no state between two matvecs, so growing = a new allocation)
+int slab_ensure(nlg_linop *op, int cap) {
+    if (op->slab && op->slab_cap >= cap) return 0;
+    nlg_ctx *ctx = op->mesh->ctx;
+    NLG_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t ld = lane_stride(op);
+    double *nslab = nullptr;
+    NLG_HIP(hipMalloc(&nslab, sizeof(double) * (size_t)(ld * cap)));
+    NLG_HIP(hipMemsetAsync(nslab, 0, sizeof(double) * (size_t)(ld * cap), ctx->stream));
+    if (op->slab) NLG_HIP(hipFree(op->slab));
+    op->slab = nslab;
+    op->slab_ld = ld;
+    op->slab_cap = cap;
+    lane_bind(op, op, 0);
+    for (int v = 1; v < kMaxLanes; ++v)
+        if (op->lanes[v - 1]) lane_bind(op, op->lanes[v - 1], v);
+    if (!op->d_red) NLG_TRY(lalloc(op, &op->d_red, 3 * kMaxLanes));
+    return 0;
+}
+
 template <typename K, typename... A>
 void launch_nf(int nf, K k1, K k2, K k3, dim3 g, hipStream_t s, A... a) {
     if (nf == 1)
-        hipLaunchKernelGGL(k1, g, dim3(NT), 0, s, a...);
+        NLG_LAUNCH(k1, g, dim3(NT), 0, s, a...);
     else if (nf == 2)
-        hipLaunchKernelGGL(k2, g, dim3(NT), 0, s, a...);
+        NLG_LAUNCH(k2, g, dim3(NT), 0, s, a...);
     else
-        hipLaunchKernelGGL(k3, g, dim3(NT), 0, s, a...);
+        NLG_LAUNCH(k3, g, dim3(NT), 0, s, a...);
 }
 
 F3 f3(double *const *a, int nf) {
@@ -718,7 +855,11 @@ CF3 cf3(double *const *a, int nf) {
     CF3 r = {{a[0], nf > 1 ? a[1] : nullptr, nf > 2 ? a[2] : nullptr}};
     return r;
 }
+inline dim3 lgrid(int g, int nl) { return dim3((unsigned)g, (unsigned)nl); }
 
+// One PCG problem for nl lanes in lockstep: every pointer is lane 0's, lane v's copy sits v * ld doubles behind it (the lanes
+// share a slab); tolerances, iteration limits and the operator are the same for all lanes, alpha / beta / residual norms / the
+// convergence flag are per lane (device scalars), so each lane performs exactly the iteration it would perform on its own.
 struct CGProblem {
     int nf;
     int64_t n;           // entries per field
@@ -728,9 +869,11 @@ struct CGProblem {
     double tol2;         // squared tolerance on sum r^2 nw
     int use_tol, maxit;
     double *s;           // device scalars
-    int chunk;           // iterations launched before the host first looks at the done flag (the prediction)
+    int chunk;           // iterations launched before the host first looks at the done flags (the prediction)
     int chunk_next = 2;  // ... and per look afterwards
     double inv_n;        // 1/n for the mean-free projected solve, 0 = no projection
+    int nl = 1;          // lanes
+    int64_t ld = 0;      // lane stride
     // non-pointwise M^-1 (nf = 1): writes the element-wise part to z and returns the coarse part per element in *xc
     std::function<int(const double *flag, const double *r, double *z, const double **xc)> precond;
     int npe = 1;         // points per element (for the per-element coarse part)
@@ -743,38 +886,37 @@ struct CGProblem {
     int rz_n = 0;
     const double *rr_part = nullptr;   // [rr_n]: sum r^2 nw, written by `precond`, which then also performs the update
     int rr_n = 0;                      // x += alpha p, r -= alpha (w - wmean) of the iteration (no k_cg_update launch)
-    std::string tag;                   // non-empty: the iteration may be replayed from a hipGraph; names the solver and
-                                       // every argument of `apply` / `precond` that is not a member of this struct
 };
 
-// Generic device-scalar PCG. `apply` computes w = A p (must itself be stream-ordered and may be gated
-// by s[S_DONE]).
+// Device-scalar PCG for P.nl lanes.  `apply` computes w = A p for ALL lanes (stream-ordered, gated by each lane's s[S_DONE]).
+// Every kernel of the iteration is ONE launch with gridDim.y = lanes; several ranks: ONE all-reduce per reduction carries the
+// sums of all lanes.  iters_out[v]: iterations of lane v.
 template <typename Apply>
 int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     nlg_ctx *ctx = op->mesh->ctx;
     hipStream_t st = ctx->stream;
-    const int nf = P.nf;
+    const int nf = P.nf, nl = P.nl;
+    const int64_t ld = P.ld;
     const int g = red_grid(P.n);
-    double *partial = ctx->d_partial;
+    double *partial = op->d_cgpart;
     double *s = P.s;
     F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
-    (void)x;
     CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf);
     CF3 cr = cf3(P.r, nf);
     const Red rd_std = {{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
     auto reduce_post = [&](const Red &rd, int nsums, int gate, int mode) -> int {
         if (!ctx->distributed()) {
-            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
-                               P.inv_n, 1);
+            NLG_LAUNCH(k_cg_final_post, lgrid(1, nl), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
+                       P.inv_n, 1, ld, (double *)nullptr);
         } else {
-            hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
-                               P.inv_n, 0);
-            NLG_TRY(allreduce_sum(ctx, s + S_T0, nsums));
-            hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n);
+            NLG_LAUNCH(k_cg_final_post, lgrid(1, nl), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
+                       P.inv_n, 0, ld, op->d_red);
+            NLG_TRY(allreduce_sum(ctx, op->d_red, 3 * nl));
+            NLG_LAUNCH(k_cg_post, lgrid(1, nl), dim3(1), 0, st, s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n, ld, (const double *)op->d_red, nsums);
         }
         return 0;
     };
-    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
+    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, lgrid(g, nl), st, P.n, x, r, z, pc, P.ipw, P.nw, partial, ld);
     const double *xc = nullptr;
     Red rd_rz = rd_std;
     if (P.precond) {
@@ -785,7 +927,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
             rd_rz.p[2] = P.rz_part + P.rz_n;
             rd_rz.n[2] = P.rz_n;
         } else {
-            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 0, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, lgrid(g, nl), st, (const double *)s, 0, P.n, cr, cz, P.ipw, xc, P.npe, partial, ld);
         }
     }
     Red rd_rz_loop = rd_rz;   // inside the loop the r^2 sums may come from the preconditioner's first kernel
@@ -802,110 +944,64 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     }
     NLG_TRY(reduce_post(rd_rz, 3, 0, 0));
     if (!P.fused_pupdate)
-        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);   // p = z - zmean
-    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
+        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, lgrid(g, nl), st, (const double *)s, P.n, p, cz, xc, P.npe, ld);   // p = z - zmean
+    NLG_LAUNCH(k_cg_post, lgrid(1, nl), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n, ld, (const double *)nullptr, 0);
     auto body = [&]() -> int {
         NLG_TRY(apply(s));
         const bool prof_cg = prof_want(ctx, P_CGVEC);
         if (prof_cg) prof_begin(ctx, P_CGVEC);
         if (!P.pw_part)
-            launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)s, P.n, cp, cw, P.ipw, partial);
+            launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, lgrid(g, nl), st, (const double *)s, P.n, cp, cw, P.ipw, partial, ld);
         NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
         if (!P.rr_part)
-            launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)s, P.n, x, r, z, cp, cw,
-                      pc, P.ipw, P.nw, partial);
+            launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, lgrid(g, nl), st, (const double *)s, P.n, x, r, z, cp, cw,
+                      pc, P.ipw, P.nw, partial, ld);
         if (prof_cg) prof_end(ctx, P_CGVEC);
         if (P.precond) {
             NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
             if (!P.rz_part)
-                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial);
+                launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, lgrid(g, nl), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial, ld);
         }
         NLG_TRY(reduce_post(rd_rz_loop, 3, 1, 2));
         if (!P.fused_pupdate)
-            launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)s, P.n, p, cz, xc, P.npe);
+            launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, lgrid(g, nl), st, (const double *)s, P.n, p, cz, xc, P.npe, ld);
         return 0;
     };
-    // One iteration as a hipGraph: every argument is fixed for the life of the signature (the scalars live on the
-    // device), so the graph captured at the second solve with a signature is replayed by all later ones.
-    hipGraphExec_t exec = nullptr;
-    int giters = 1;   // iterations per graph
-    if (const char *ev = getenv("NLG_GRAPH_ITERS")) giters = std::max(1, atoi(ev));
-    if (op->graph_mode < 0) {
-        const char *ev = getenv("NLG_GRAPH");
-        op->graph_mode = ev ? atoi(ev) : 0;
-    }
-    {
-        int64_t gmax = 1500000;
-        if (const char *ev = getenv("NLG_GRAPH_MAX")) gmax = atoll(ev);
-        const bool want = !P.tag.empty() && !ctx->prof_on && !ctx->distributed() &&
-                          (op->graph_mode == 2 || (op->graph_mode == 1 && op->mesh->lvn <= gmax));
-        if (want) {
-            char kb[512];
-            // (the reduction workspace is part of the signature: reduce_ws_reserve may reallocate it when a larger basis
-            //  arrives later, and the captured kernels hold the old pointer)
-            snprintf(kb, sizeof(kb), "%s|%p|%d|%d|%lld|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p%p%p|%p|%p|%a|%d|%d|%p|%a|%d|%p|%d|%d|%d|%p|%d", P.tag.c_str(), (void *)ctx->d_partial, giters, nf,
-                     (long long)P.n, (void *)P.x[0], (void *)(nf > 1 ? P.x[1] : nullptr), (void *)(nf > 2 ? P.x[2] : nullptr), (void *)P.r[0],
-                     (void *)(nf > 1 ? P.r[1] : nullptr), (void *)(nf > 2 ? P.r[2] : nullptr), (void *)P.z[0], (void *)(nf > 1 ? P.z[1] : nullptr),
-                     (void *)(nf > 2 ? P.z[2] : nullptr), (void *)P.p[0], (void *)(nf > 1 ? P.p[1] : nullptr), (void *)(nf > 2 ? P.p[2] : nullptr),
-                     (void *)P.w[0], (void *)(nf > 1 ? P.w[1] : nullptr), (void *)(nf > 2 ? P.w[2] : nullptr),
-                     (void *)(P.pc ? P.pc[0] : nullptr), (void *)(P.pc && nf > 1 ? P.pc[1] : nullptr), (void *)(P.pc && nf > 2 ? P.pc[2] : nullptr),
-                     (const void *)P.ipw, (const void *)P.nw, P.tol2, P.use_tol, P.maxit, (void *)P.s, P.inv_n, P.npe, (const void *)P.pw_part,
-                     P.pw_n, (int)P.pw_sum, (int)P.fused_pupdate, (const void *)P.rz_part, P.rz_n + 100000 * (P.rr_part ? 1 : 0));
-            nlg_linop::GraphSlot &slot = op->graphs[kb];
-            ++slot.uses;
-            if (!slot.exec && !slot.failed && slot.uses >= 2) {
-                // everything the iteration allocates lazily exists after the first solve
-                hipGraph_t gr = nullptr;
-                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    int rc = 0;
-                    for (int q = 0; q < giters && rc == 0; ++q) rc = body();
-                    const hipError_t e1 = hipStreamEndCapture(st, &gr);
-                    if (rc == 0 && e1 == hipSuccess && gr && hipGraphInstantiate(&slot.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
-                    } else {
-                        slot.exec = nullptr;
-                        slot.failed = true;   // direct launches from now on
-                        (void)hipGetLastError();
-                    }
-                    if (gr) hipGraphDestroy(gr);
-                } else {
-                    slot.failed = true;
-                    (void)hipGetLastError();
-                }
-            }
-            exec = slot.exec;
-        }
-    }
     int launched = 0;
-    int iters = 0;
     while (true) {
         int todo = launched == 0 ? P.chunk : P.chunk_next;
         if (launched + todo > P.maxit) todo = P.maxit - launched;
-        for (int it = 0; it < todo;) {
-            if (exec && it + giters <= todo) {
-                NLG_HIP(hipGraphLaunch(exec, st));
-                it += giters;
-            } else {
-                NLG_TRY(body());
-                ++it;
-            }
-        }
+        for (int it = 0; it < todo; ++it) NLG_TRY(body());
         launched += todo;
         NLG_HIP(hipGetLastError());
-        NLG_HIP(hipMemcpyAsync(op->h_s, s, sizeof(double) * S_N, hipMemcpyDeviceToHost, st));
+        for (int v = 0; v < nl; ++v)
+            NLG_HIP(hipMemcpyAsync(op->h_s + (size_t)v * S_N, s + (int64_t)v * ld, sizeof(double) * S_N, hipMemcpyDeviceToHost, st));
         NLG_HIP(hipStreamSynchronize(st));
-        iters = (int)op->h_s[S_ITERS];
-        if (op->h_s[S_DONE] != 0.0 || launched >= P.maxit) break;
+        bool all_done = true;
+        for (int v = 0; v < nl; ++v) all_done = all_done && op->h_s[(size_t)v * S_N + S_DONE] != 0.0;
+        if (all_done || launched >= P.maxit) break;
     }
-    if (!std::isfinite(op->h_s[S_RN2])) {
-        set_error("PCG diverged (residual is not finite) after %d iterations", iters);
-        return 1;
+    for (int v = 0; v < nl; ++v) {
+        const double *h = op->h_s + (size_t)v * S_N;
+        if (!std::isfinite(h[S_RN2])) {
+            set_error("PCG diverged (residual is not finite) after %d iterations (lane %d of %d)", (int)h[S_ITERS], v, nl);
+            return 1;
+        }
+        iters_out[v] = (int)h[S_ITERS];
     }
-    *iters_out = iters;
     return 0;
 }
 
-// The velocity solve in three pieces, so that the single-vector path and the block (multi-vector) stepper share them:
-// problem set-up, one operator application, bookkeeping afterwards.
+// The lanes of a time step: ops[0] is the operator itself, ops[1..] its lanes (all bound to one slab); nl = 1 is the
+// single-vector path.  Every phase launches once for all lanes and keeps the host-side bookkeeping per lane.
+struct Lanes {
+    nlg_linop *const *ops;
+    int nl;
+    nlg_linop *op() const { return ops[0]; }
+    int64_t ld() const { return nl > 1 ? ops[0]->slab_ld : 0; }
+};
+
+// The velocity solve in three pieces: problem set-up, one operator application, bookkeeping afterwards.
 struct HelmSolve {
     CGProblem P;
     bool xp = false;
@@ -913,7 +1009,8 @@ struct HelmSolve {
     double *pw_part = nullptr;
 };
 
-int helm_problem(nlg_linop *op, int order, double h2, HelmSolve &H) {
+int helm_problem(const Lanes &L, int order, double h2, HelmSolve &H) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     const int dim = m->dim;
     const auto &c = op->cfg;
@@ -923,7 +1020,7 @@ int helm_problem(nlg_linop *op, int order, double h2, HelmSolve &H) {
     const bool xp = op->use_xp > 0;
     H.xp = xp;
     H.h2 = h2;
-    if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim));
+    if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim, L.nl, L.ld()));
     P.nf = dim;
     P.n = m->lvn;
     P.x = op->x;
@@ -939,58 +1036,58 @@ int helm_problem(nlg_linop *op, int order, double h2, HelmSolve &H) {
     P.maxit = c.fixed_iters_v > 0 ? c.fixed_iters_v : c.maxit_v;
     P.s = op->d_s;
     P.inv_n = 0.0;
+    P.nl = L.nl;
+    P.ld = L.ld();
     // the iteration count barely changes from one time step to the next: launch exactly the previous count, then look at
-    // the flag every second iteration; launches issued after convergence are gated on the device but still cost a launch
-    {
-        const int pred = (op->istep < (int)op->vit_hist.size() && op->vit_hist[op->istep] > 0) ? op->vit_hist[op->istep] : op->last_viters;
-        P.chunk = std::max(2, std::min(pred, 64));
+    // the flags every second iteration; launches issued after convergence are gated on the device but still cost a launch
+    P.chunk = 2;
+    for (int v = 0; v < L.nl; ++v) {
+        const nlg_linop *ln = L.ops[v];
+        const int pred = (ln->istep < (int)ln->vit_hist.size() && ln->vit_hist[ln->istep] > 0) ? ln->vit_hist[ln->istep] : ln->last_viters;
+        P.chunk = std::max(P.chunk, std::min(pred, 64));
     }
     H.nu = 1.0 / c.re;
     // w = QQ^T (nu A + h2 B) p.  The Dirichlet mask is not applied to w: p is masked (z = pc r with pc = mask/diag), so
     // (p, w) does not see the masked entries, and k_cg_update zeroes the residual where pc == 0.
-    // 3-D: (p, w) = sum over the local dofs of p . w_local (p is continuous), summed inside the operator kernel.
-    H.pw_part = op->d_part;   // both the 2-D and the 3-D operator kernels sum (p, w) and update p themselves
-    if (H.pw_part) {
-        P.pw_part = H.pw_part;
-        P.pw_n = sem_axhelm_blocks(m, dim);
-        P.pw_sum = false;
-        P.fused_pupdate = true;   // 3-D: p <- z + beta p happens while the operator kernel loads p
-    }
-    {
-        char tb[96];
-        snprintf(tb, sizeof(tb), "helm|%a|%a|%d|%d", H.nu, h2, H.pw_part ? 1 : 0, xp ? 1 : 0);
-        P.tag = tb;
-    }
+    // (p, w) = sum over the local dofs of p . w_local (p is continuous), summed inside the operator kernel, which also
+    // performs p <- z + beta p while it loads p.
+    H.pw_part = op->d_part;
+    P.pw_part = H.pw_part;
+    P.pw_n = sem_axhelm_blocks(m, dim);
+    P.pw_sum = false;
+    P.fused_pupdate = true;
     return 0;
 }
 
-int helm_apply(nlg_linop *op, const HelmSolve &H) {
+int helm_apply(const Lanes &L, const HelmSolve &H) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     const int dim = m->dim;
-    if (H.pw_part)
-        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, H.xp));
-    else
-        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part));
-    NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE, H.xp ? LAYOUT_XP : LAYOUT_NAT));
+    NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, H.xp, L.nl, L.ld()));
+    NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE, H.xp ? LAYOUT_XP : LAYOUT_NAT, L.nl, L.ld(), L.ld()));
     return 0;
 }
 
-int helm_finish(nlg_linop *op, const HelmSolve &H, int iters) {
-    if (H.xp) NLG_TRY(sem_from_xp(op->mesh, op->x, op->rhs, op->mesh->dim));   // the increment, natural layout
-    op->st_viters += iters;
-    op->last_viters = iters;
-    if ((int)op->vit_hist.size() <= op->istep) op->vit_hist.resize(op->istep + 1, 0);
-    op->vit_hist[op->istep] = iters;
+int helm_finish(const Lanes &L, const HelmSolve &H, const int *iters) {
+    nlg_linop *op = L.op();
+    if (H.xp) NLG_TRY(sem_from_xp(op->mesh, op->x, op->rhs, op->mesh->dim, L.nl, L.ld()));   // the increment, natural layout
+    for (int v = 0; v < L.nl; ++v) {
+        nlg_linop *ln = L.ops[v];
+        ln->st_viters += iters[v];
+        ln->last_viters = iters[v];
+        if ((int)ln->vit_hist.size() <= ln->istep) ln->vit_hist.resize(ln->istep + 1, 0);
+        ln->vit_hist[ln->istep] = iters[v];
+    }
     return 0;
 }
 
-int helm_solve(nlg_linop *op, int order, double h2) {
+int helm_solve(const Lanes &L, int order, double h2) {
     HelmSolve H;
-    NLG_TRY(helm_problem(op, order, h2, H));
-    auto apply = [&](double *) -> int { return helm_apply(op, H); };
-    int iters = 0;
-    NLG_TRY(run_pcg(op, H.P, apply, &iters));
-    return helm_finish(op, H, iters);
+    NLG_TRY(helm_problem(L, order, h2, H));
+    auto apply = [&](double *) -> int { return helm_apply(L, H); };
+    int iters[kMaxLanes] = {};
+    NLG_TRY(run_pcg(L.op(), H.P, apply, iters));
+    return helm_finish(L, H, iters);
 }
 
 // One scalar (temperature) step of the Boussinesq coupling, see oracle/lns.py advance (ifheat branch):
@@ -1009,7 +1106,7 @@ int heat_step(nlg_linop *op, int k, double b0) {
         // (stored term N_t = -conv(U, theta+) - bm1 b . u+ ; oracle/lns.py advance, adjoint branch)
         for (int i = 0; i < m->dim; ++i)
             if (c.buoy[i] != 0.0)
-                hipLaunchKernelGGL(k_mul3_acc, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->ftbuf[2], (const double *)m->d_bm1,
+                NLG_LAUNCH(k_mul3_acc, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->ftbuf[2], (const double *)m->d_bm1,
                                    (const double *)op->ubuf[0][i], -c.buoy[i]);
     }
     {
@@ -1029,18 +1126,18 @@ int heat_step(nlg_linop *op, int k, double b0) {
         }
     }
     F3 rhs = {{op->trhs, nullptr, nullptr}};
-    hipLaunchKernelGGL(k_rhs<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, h, (const double *)m->d_bm1, rc / dt, rhs);
+    NLG_LAUNCH(k_rhs<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, h, (const double *)m->d_bm1, rc / dt, rhs, (int64_t)0);
     const double h1 = c.conductivity, h2 = rc * b0 / dt;
     double *tin[1] = {op->tbuf[0]}, *tw[1] = {op->tw}, *trhs[1] = {op->trhs};
     NLG_TRY(sem_axhelm(m, tin, tw, 1, h1, h2));
     {
         CF3 a = {{op->trhs, nullptr, nullptr}}, b = {{op->tw, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
-        hipLaunchKernelGGL(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, rhs, a, b, -1.0, none, 0.0);
+        NLG_LAUNCH(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, rhs, a, b, -1.0, none, 0.0, (int64_t)0);
     }
     NLG_TRY(sem_gs(m, trhs, 1));
     {
         CF3 mk = {{m->d_tmask, nullptr, nullptr}};
-        hipLaunchKernelGGL(k_colmul_gated<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, (const double *)nullptr, rhs, mk, m->lvn);
+        NLG_LAUNCH(k_colmul_gated<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, (const double *)nullptr, rhs, mk, m->lvn, (int64_t)0);
     }
     // Jacobi-PCG, one field; the operator kernel sums (p, w) and updates p itself
     double *x[1] = {op->tx}, *z[1] = {op->tz}, *p[1] = {op->tpv}, *pc[1] = {op->pct[k]};
@@ -1070,20 +1167,15 @@ int heat_step(nlg_linop *op, int k, double b0) {
         NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE));
         return 0;
     };
-    {
-        char tb[96];
-        snprintf(tb, sizeof(tb), "heat|%a|%a", h1, h2);
-        P.tag = tb;
-    }
-    int iters = 0;
-    NLG_TRY(run_pcg(op, P, apply, &iters));
-    op->st_titers += iters;
-    op->last_titers = iters;
+    int iters[kMaxLanes] = {};
+    NLG_TRY(run_pcg(op, P, apply, iters));
+    op->st_titers += iters[0];
+    op->last_titers = iters[0];
     // theta^{n+1} = theta^n + x into the oldest level, then rotate: new -> current
     {
         F3 y = {{op->tbuf[2], nullptr, nullptr}};
         CF3 a = {{op->tbuf[0], nullptr, nullptr}}, b = {{op->tx, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
-        hipLaunchKernelGGL(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0);
+        NLG_LAUNCH(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0, (int64_t)0);
         double *t = op->tbuf[2];
         op->tbuf[2] = op->tbuf[1];
         op->tbuf[1] = op->tbuf[0];
@@ -1103,9 +1195,12 @@ struct PresSolve {
     int nold = 0;
 };
 
-int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
+int pres_problem(const Lanes &L, double scale, PresSolve &Q) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     const auto &c = op->cfg;
+    const int nl = L.nl;
+    const int64_t ld = L.ld();
     Q.x[0] = op->pr_x, Q.r[0] = op->pr_r, Q.z[0] = op->pr_z, Q.p[0] = op->pr_p, Q.w[0] = op->pr_w, Q.pc[0] = op->pce, Q.nopc[0] = nullptr;
     CGProblem &P = Q.P;
     P.nf = 1;
@@ -1123,6 +1218,8 @@ int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
     P.maxit = c.fixed_iters_p > 0 ? c.fixed_iters_p : c.maxit_p;
     P.s = op->d_s + S_N;
     P.inv_n = m->has_outflow ? 0.0 : 1.0 / (double)m->lpn_global;
+    P.nl = nl;
+    P.ld = ld;
     if (c.pprecond == 0 || c.pprecond == 2) {   // two-level Schwarz (pprec.hip): 0 = with overlap where available, 2 = without; 1 = Jacobi on diag(E), as in the oracle
         const bool overlap = c.pprecond == 0 && m->pprec.overlap;
         P.pc = Q.nopc;
@@ -1140,20 +1237,22 @@ int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
         upd.rr_part = op->d_part + 2 * m->E + 2 * ((m->E + 3) / 4);
         P.rr_part = upd.rr_part;
         P.rr_n = (int)((m->E + 3) / 4);
-        P.precond = [m, rzp, overlap, upd](const double *flag, const double *rr, double *zz, const double **xc) -> int {
+        P.precond = [m, rzp, overlap, upd, nl, ld](const double *flag, const double *rr, double *zz, const double **xc) -> int {
             // one stream: a fork/join through events costs more than it hides (measured: 98 vs 84 us per apply)
             nlg_ctx *c = m->ctx;
             ProfScope ps(c, P_PPREC);
             const double *coarse = nullptr;
-            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse, overlap, flag ? &upd : nullptr));   // flag == null: the initial residual
-            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz, rzp, overlap));   // z = local solves + prolonged coarse part
+            NLG_TRY(pprec_coarse(m, c->stream, flag, rr, &coarse, overlap, flag ? &upd : nullptr, nl, ld));   // flag == null: the initial residual
+            NLG_TRY(pprec_fine(m, c->stream, flag, rr, coarse, zz, rzp, overlap, nl, ld));   // z = local solves + prolonged coarse part
             *xc = nullptr;
             return 0;
         };
     }
-    {
-        const int pred = (op->istep < (int)op->pit_hist.size() && op->pit_hist[op->istep] > 0) ? op->pit_hist[op->istep] : op->last_piters;
-        P.chunk = std::max(2, std::min(pred, 96));
+    P.chunk = 2;
+    for (int v = 0; v < nl; ++v) {
+        const nlg_linop *ln = L.ops[v];
+        const int pred = (ln->istep < (int)ln->pit_hist.size() && ln->pit_hist[ln->istep] > 0) ? ln->pit_hist[ln->istep] : ln->last_piters;
+        P.chunk = std::max(P.chunk, std::min(pred, 96));
     }
     // fused first-stage sums (rank-local; the all-reduce follows the second stage): p.w and sum w from the divergence kernel,
     // r.z and sum z from the preconditioner's last kernel
@@ -1178,110 +1277,145 @@ int pres_problem(nlg_linop *op, double scale, PresSolve &Q) {
         double *alpha = op->d_pc, *ppart = op->d_pc + 4 * PROJ_L;
         const int gp = red_grid(m->lpn);
         ProfScope ps(m->ctx, P_VECOPS);
-        hipLaunchKernelGGL(k_proj_dots, dim3(gp), dim3(NT), 0, st, m->lpn, (const double *)op->prX, m->lps, Q.nold, (const double *)op->pr_r, ppart);
-        hipLaunchKernelGGL(k_proj_reduce, dim3(1), dim3(NT), 0, st, (const double *)ppart, gp, Q.nold, alpha);
-        NLG_TRY(allreduce_sum(m->ctx, alpha, Q.nold));                       // alpha = X^T b
-        hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_r, (const double *)op->prB, m->lps,
-                           Q.nold, (const double *)alpha, -1.0);               // b <- b - B alpha
-    }
-    {
-        char tb[96];
-        snprintf(tb, sizeof(tb), "pres|%d|%d", c.pprecond, P.precond ? 1 : 0);
-        P.tag = tb;
+        NLG_LAUNCH(k_proj_dots, lgrid(gp, nl), dim3(NT), 0, st, m->lpn, (const double *)op->prX, m->lps, Q.nold, (const double *)op->pr_r, ppart, ld);
+        NLG_LAUNCH(k_proj_reduce, lgrid(1, nl), dim3(NT), 0, st, (const double *)ppart, gp, Q.nold, alpha, ld);
+        for (int v = 0; v < nl; ++v) NLG_TRY(allreduce_sum(m->ctx, alpha + v * ld, Q.nold));                       // alpha = X^T b
+        NLG_LAUNCH(k_proj_comb, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->pr_r, (const double *)op->prB, m->lps,
+                   Q.nold, (const double *)alpha, -1.0, ld);               // b <- b - B alpha
     }
     return 0;
 }
 
-// gated: launches past convergence (the host only looks at the flag once per chunk) return at once
-int pres_apply(nlg_linop *op, const PresSolve &Q) {
-    if (Q.P.fused_pupdate) {   // p <- (z - zmean) + beta p while the gradient kernel loads p
-        nlg_pupd u;
-        u.z = op->pr_z, u.beta = op->d_s + S_N + S_BETA, u.zmean = op->d_s + S_N + S_ZMEAN, u.p = op->pr_p;
-        return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE, &u);
+// gated: launches past convergence (the host only looks at the flags once per chunk) return at once
+int pres_apply(const Lanes &L, const PresSolve &Q) {
+    nlg_linop *op = L.op();
+    if (L.nl == 1) {
+        if (Q.P.fused_pupdate) {   // p <- (z - zmean) + beta p while the gradient kernel loads p
+            nlg_pupd u;
+            u.z = op->pr_z, u.beta = op->d_s + S_N + S_BETA, u.zmean = op->d_s + S_N + S_ZMEAN, u.p = op->pr_p;
+            return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE, &u);
+        }
+        return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE);
     }
-    return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE);
+    // E p for all lanes: the gradient and divergence kernels take the lanes in one launch each, so does the gather-scatter
+    const double *pp[kMaxLanes], *gg[kMaxLanes];
+    double *ww[kMaxLanes], *pw[kMaxLanes];
+    nlg_pupd pu[kMaxLanes];
+    const int64_t ld = L.ld();
+    for (int v = 0; v < L.nl; ++v) {
+        pp[v] = op->pr_p + v * ld, ww[v] = op->pr_w + v * ld, pw[v] = Q.pw_part + v * ld, gg[v] = op->d_s + S_N + S_DONE + v * ld;
+        if (Q.P.fused_pupdate)
+            pu[v].z = op->pr_z + v * ld, pu[v].beta = op->d_s + S_N + S_BETA + v * ld, pu[v].zmean = op->d_s + S_N + S_ZMEAN + v * ld, pu[v].p = op->pr_p + v * ld;
+    }
+    return sem_cdabdtp_lanes(op->mesh, L.nl, pp, ww, pw, gg, Q.P.fused_pupdate ? pu : nullptr);
 }
 
-int pres_finish(nlg_linop *op, const PresSolve &Q, int iters) {
+int pres_finish(const Lanes &L, const PresSolve &Q, const int *iters) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
-    op->st_piters += iters;
-    op->last_piters = iters;
-    if ((int)op->pit_hist.size() <= op->istep) op->pit_hist.resize(op->istep + 1, 0);
-    op->pit_hist[op->istep] = iters;
+    const int nl = L.nl;
+    const int64_t ld = L.ld();
+    for (int v = 0; v < nl; ++v) {
+        nlg_linop *ln = L.ops[v];
+        ln->st_piters += iters[v];
+        ln->last_piters = iters[v];
+        if ((int)ln->pit_hist.size() <= ln->istep) ln->pit_hist.resize(ln->istep + 1, 0);
+        ln->pit_hist[ln->istep] = iters[v];
+    }
     if (Q.proj) {
         double *alpha = op->d_pc, *beta = op->d_pc + PROJ_L, *nrm2 = op->d_pc + 2 * PROJ_L, *ppart = op->d_pc + 4 * PROJ_L;
         const int gp = red_grid(m->lpn);
         const int nold = Q.nold;
         auto dots = [&](const double *y, int nvec, const double *M, double *out) -> int {
-            hipLaunchKernelGGL(k_proj_dots, dim3(gp), dim3(NT), 0, st, m->lpn, M, m->lps, nvec, y, ppart);
-            hipLaunchKernelGGL(k_proj_reduce, dim3(1), dim3(NT), 0, st, (const double *)ppart, gp, nvec, out);
-            return allreduce_sum(m->ctx, out, nvec);
+            NLG_LAUNCH(k_proj_dots, lgrid(gp, nl), dim3(NT), 0, st, m->lpn, M, m->lps, nvec, y, ppart, ld);
+            NLG_LAUNCH(k_proj_reduce, lgrid(1, nl), dim3(NT), 0, st, (const double *)ppart, gp, nvec, out, ld);
+            for (int v = 0; v < nl; ++v) NLG_TRY(allreduce_sum(m->ctx, out + v * ld, nvec));
+            return 0;
         };
         // new member from the increment d = pr_x: w = A d, A-orthogonalised against the old members, normalised
-        NLG_TRY(sem_cdabdtp(m, op->pr_x, op->pr_w));
-        if (!m->has_outflow) NLG_TRY(sem_ortho(m, op->pr_w));                // A = P E P
+        if (nl == 1) {
+            NLG_TRY(sem_cdabdtp(m, op->pr_x, op->pr_w));
+        } else {
+            const double *pp[kMaxLanes];
+            double *ww[kMaxLanes], *none[kMaxLanes] = {};
+            for (int v = 0; v < nl; ++v) pp[v] = op->pr_x + v * ld, ww[v] = op->pr_w + v * ld;
+            NLG_TRY(sem_cdabdtp_lanes(m, nl, pp, ww, none, nullptr, nullptr));
+        }
+        if (!m->has_outflow) NLG_TRY(sem_ortho(m, op->pr_w, nl, ld));                // A = P E P
         ProfScope ps(m->ctx, P_VECOPS);
-        NLG_HIP(hipMemcpyAsync(op->pr_z, op->pr_x, sizeof(double) * (size_t)m->lpn, hipMemcpyDeviceToDevice, st));   // v = d
+        NLG_HIP(hipMemcpy2DAsync(op->pr_z, sizeof(double) * (size_t)std::max<int64_t>(ld, m->lpn), op->pr_x, sizeof(double) * (size_t)std::max<int64_t>(ld, m->lpn),
+                                 sizeof(double) * (size_t)m->lpn, (size_t)nl, hipMemcpyDeviceToDevice, st));   // v = d (all lanes)
         if (nold > 0) {
             NLG_TRY(dots(op->pr_w, nold, op->prX, beta));                    // beta = X^T A d
-            hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_z, (const double *)op->prX, m->lps,
-                               nold, (const double *)beta, -1.0);
-            hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_w, (const double *)op->prB, m->lps,
-                               nold, (const double *)beta, -1.0);
+            NLG_LAUNCH(k_proj_comb, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->pr_z, (const double *)op->prX, m->lps,
+                       nold, (const double *)beta, -1.0, ld);
+            NLG_LAUNCH(k_proj_comb, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->pr_w, (const double *)op->prB, m->lps,
+                       nold, (const double *)beta, -1.0, ld);
             // total solution: x = d + X alpha
-            hipLaunchKernelGGL(k_proj_comb, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pr_x, (const double *)op->prX, m->lps,
-                               nold, (const double *)alpha, 1.0);
+            NLG_LAUNCH(k_proj_comb, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->pr_x, (const double *)op->prX, m->lps,
+                       nold, (const double *)alpha, 1.0, ld);
         }
         NLG_TRY(dots(op->pr_w, 1, op->pr_z, nrm2));                          // v^T A v
         const int slot = nold < PROJ_L ? nold : 0;                           // full: start over with the newest member
-        hipLaunchKernelGGL(k_proj_store, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, (const double *)op->pr_z, (const double *)op->pr_w,
-                           (const double *)nrm2, op->prX + (size_t)slot * m->lps, op->prB + (size_t)slot * m->lps);
-        op->nproj = nold < PROJ_L ? nold + 1 : 1;
+        NLG_LAUNCH(k_proj_store, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, (const double *)op->pr_z, (const double *)op->pr_w,
+                   (const double *)nrm2, op->prX + (size_t)slot * m->lps, op->prB + (size_t)slot * m->lps, ld);
+        for (int v = 0; v < nl; ++v) L.ops[v]->nproj = nold < PROJ_L ? nold + 1 : 1;
         NLG_HIP(hipGetLastError());
     }
     return 0;
 }
 
-int pres_solve(nlg_linop *op, double scale) {
+int pres_solve(const Lanes &L, double scale) {
     PresSolve Q;
-    NLG_TRY(pres_problem(op, scale, Q));
-    auto apply = [&](double *) -> int { return pres_apply(op, Q); };
-    int iters = 0;
-    NLG_TRY(run_pcg(op, Q.P, apply, &iters));
-    return pres_finish(op, Q, iters);
+    NLG_TRY(pres_problem(L, scale, Q));
+    auto apply = [&](double *) -> int { return pres_apply(L, Q); };
+    int iters[kMaxLanes] = {};
+    NLG_TRY(run_pcg(L.op(), Q.P, apply, iters));
+    return pres_finish(L, Q, iters);
 }
 
-// one restated nek_advance step (perturbation mode), see oracle/lns.py ExptA.advance
-// one restated nek_advance step in three phases around the two solves (shared by the single-vector and the block stepper)
-// phase 0: the whole of it; 1: up to the convective term (exclusive); 2: from after the convective term on -- the block stepper
-// evaluates the convective terms of all its lanes in one launch between 1 and 2
-int adv_a(nlg_linop *op, int phase = 0) {
+// rotate a set of three level pointers in every lane: the oldest becomes the newest
+void rotate3(const Lanes &L, double *(nlg_linop::*buf)[3][3]) {
+    for (int v = 0; v < L.nl; ++v) {
+        double *(&b)[3][3] = L.ops[v]->*buf;
+        double *t[3] = {b[2][0], b[2][1], b[2][2]};
+        for (int c = 0; c < 3; ++c) {
+            b[2][c] = b[1][c];
+            b[1][c] = b[0][c];
+            b[0][c] = t[c];
+        }
+    }
+}
+
+// one restated nek_advance step (perturbation mode), see oracle/lns.py ExptA.advance; three phases around the two solves
+int adv_a(const Lanes &L) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
-    const int dim = m->dim;
+    const int dim = m->dim, nl = L.nl;
+    const int64_t ld = L.ld();
     const double dt = op->dt, nu = 1.0 / op->cfg.re;
-    if (phase != 2) {
-        op->istep += 1;
-        // gauge: keep the pressure mean-free (see oracle/lns.py advance)
-        NLG_TRY(sem_ortho(m, op->p));
-    }
+    for (int v = 0; v < nl; ++v) L.ops[v]->istep += 1;
+    // gauge: keep the pressure mean-free (see oracle/lns.py advance)
+    NLG_TRY(sem_ortho(m, op->p, nl, ld));
     const int k = std::min(op->istep, op->cfg.torder);
     const double b0 = BDF_B0[k];
-    op->adv_k = k;
-    op->adv_b0 = b0;
-    op->adv_h2 = b0 / dt;
-    if (phase != 2) {
-        if (op->nonlinear) {   // the "base flow" is the current state (velocity, and temperature when coupled)
-            NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));
-            if (op->cfg.ifheat) NLG_TRY(sem_conv_scalar_setup(m, op->tbuf[0], op->GT));
-        }
-        if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
+    for (int v = 0; v < nl; ++v) L.ops[v]->adv_k = k, L.ops[v]->adv_b0 = b0, L.ops[v]->adv_h2 = b0 / dt;
+    if (op->nonlinear) {   // the "base flow" is the current state (velocity, and temperature when coupled); one lane only
+        NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));
+        if (op->cfg.ifheat) NLG_TRY(sem_conv_scalar_setup(m, op->tbuf[0], op->GT));
     }
-    if (phase == 1) return 0;
+    if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
-    if (phase == 0) NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
+    if (nl == 1) {
+        NLG_TRY(sem_conv_apply(m, op->Ur, op->GU, op->ubuf[0], Fnew, op->nonlinear ? 0 : op->adjoint));
+    } else {   // convective terms of all lanes against the shared base-flow fields: one launch
+        double *const *ul[kMaxLanes], *const *ol[kMaxLanes];
+        for (int v = 0; v < nl; ++v) ul[v] = L.ops[v]->ubuf[0], ol[v] = L.ops[v]->fbuf[2];
+        NLG_TRY(sem_conv_apply_lanes(m, op->Ur, op->GU, nl, ul, ol, op->adjoint));
+    }
     if (op->cfg.ifheat && op->adjoint && !op->nonlinear) {
         // adjoint momentum equation: - theta+ grad Theta with the new theta+ (stored F is +N: add the weak term)
         NLG_TRY(sem_scalar_grad_apply(m, op->GT, op->tbuf[0], Fnew, 1.0));
@@ -1300,16 +1434,7 @@ int adv_a(nlg_linop *op, int phase = 0) {
         launch_nf(dim, k_add_force<1>, k_add_force<2>, k_add_force<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(Fnew, dim),
                   (const double *)m->d_bm1, fr, fi, std::cos(ph), -std::sin(ph));
     }
-    {
-        double *t0 = op->fbuf[2][0], *t1 = op->fbuf[2][1], *t2 = op->fbuf[2][2];
-        for (int c = 0; c < 3; ++c) {
-            op->fbuf[2][c] = op->fbuf[1][c];
-            op->fbuf[1][c] = op->fbuf[0][c];
-        }
-        op->fbuf[0][0] = t0;
-        op->fbuf[0][1] = t1;
-        op->fbuf[0][2] = t2;
-    }
+    rotate3(L, &nlg_linop::fbuf);
     Hist h;
     h.k = k;
     for (int j = 0; j < 3; ++j) {
@@ -1320,79 +1445,108 @@ int adv_a(nlg_linop *op, int phase = 0) {
             h.u[j][c] = op->ubuf[j][c];
         }
     }
-    launch_nf(dim, k_rhs<1>, k_rhs<2>, k_rhs<3>, dim3(grid_for(m->lvn)), st, m->lvn, h, (const double *)m->d_bm1, 1.0 / dt,
-              f3(op->rhs, dim));
+    launch_nf(dim, k_rhs<1>, k_rhs<2>, k_rhs<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, h, (const double *)m->d_bm1, 1.0 / dt,
+              f3(op->rhs, dim), ld);
     // residual form: res = mask QQ^T (rhs + D^T p - H u)
     const double h2 = b0 / dt;
-    NLG_TRY(sem_opgradt(m, op->p, op->gp));
-    NLG_TRY(sem_axhelm(m, op->ubuf[0], op->w, dim, nu, h2));
-    launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(op->rhs, dim), cf3(op->rhs, dim),
-              cf3(op->gp, dim), 1.0, cf3(op->w, dim), -1.0);
-    NLG_TRY(sem_gs(m, op->rhs, dim));
+    if (nl == 1) {
+        NLG_TRY(sem_opgradt(m, op->p, op->gp));
+    } else {
+        const double *pp[kMaxLanes];
+        double *const *gl[kMaxLanes];
+        for (int v = 0; v < nl; ++v) pp[v] = L.ops[v]->p, gl[v] = L.ops[v]->gp;
+        NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, false, nullptr));
+    }
+    NLG_TRY(sem_axhelm(m, op->ubuf[0], op->w, dim, nu, h2, nullptr, nullptr, nullptr, nullptr, false, nl, ld));
+    launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(op->rhs, dim), cf3(op->rhs, dim),
+              cf3(op->gp, dim), 1.0, cf3(op->w, dim), -1.0, ld);
+    NLG_TRY(sem_gs(m, op->rhs, dim, nullptr, LAYOUT_NAT, nl, ld, 0));
     {
         CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
-        launch_nf(dim, k_colmul_gated<1>, k_colmul_gated<2>, k_colmul_gated<3>, dim3(grid_for(m->lvn)), st,
-                  (const double *)nullptr, f3(op->rhs, dim), mk, m->lvn);
+        launch_nf(dim, k_colmul_gated<1>, k_colmul_gated<2>, k_colmul_gated<3>, lgrid(grid_for(m->lvn), nl), st,
+                  (const double *)nullptr, f3(op->rhs, dim), mk, m->lvn, ld);
     }
-    op->adv_k = k;
-    op->adv_b0 = b0;
-    op->adv_h2 = h2;
     return 0;
 }
 
-int adv_b(nlg_linop *op) {
+int adv_b(const Lanes &L) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
-    const int dim = m->dim;
+    const int dim = m->dim, nl = L.nl;
+    const int64_t ld = L.ld();
     const double dt = op->dt, b0 = op->adv_b0;
-    (void)st;
     // uh = u + du -> into the oldest velocity buffer (slot 2), which becomes the new current after rotation
     double **unew = op->ubuf[2];
     {
         CF3 none = {{nullptr, nullptr, nullptr}};
-        launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(unew, dim), cf3(op->ubuf[0], dim),
-                  cf3(op->use_xp > 0 ? op->rhs : op->x, dim), 1.0, none, 0.0);
+        launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(op->ubuf[0], dim),
+                  cf3(op->use_xp > 0 ? op->rhs : op->x, dim), 1.0, none, 0.0, ld);
     }
     // pressure correction
-    NLG_TRY(sem_opdiv(m, unew, op->pr_r, -(b0 / dt)));
-    NLG_TRY(sem_ortho(m, op->pr_r));
+    if (nl == 1) {
+        NLG_TRY(sem_opdiv(m, unew, op->pr_r, -(b0 / dt)));
+    } else {
+        double *const *ul[kMaxLanes];
+        double *ol[kMaxLanes], *none[kMaxLanes] = {};
+        for (int v = 0; v < nl; ++v) ul[v] = L.ops[v]->ubuf[2], ol[v] = L.ops[v]->pr_r;
+        NLG_TRY(sem_opdiv_lanes(m, nl, ul, ol, -(b0 / dt), nullptr, false, nullptr, none, nullptr));
+    }
+    NLG_TRY(sem_ortho(m, op->pr_r, nl, ld));
     return 0;
 }
 
-int adv_c(nlg_linop *op) {
+int adv_c(const Lanes &L) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
-    const int dim = m->dim;
+    const int dim = m->dim, nl = L.nl;
+    const int64_t ld = L.ld();
     const double dt = op->dt, b0 = op->adv_b0;
     double **unew = op->ubuf[2];
-    hipLaunchKernelGGL(k_axpy1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->p, (const double *)op->pr_x, 1.0);
-    NLG_TRY(sem_opgradt(m, op->pr_x, op->gp));
-    NLG_TRY(sem_opbinv(m, op->gp));
+    NLG_LAUNCH(k_axpy1, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->p, (const double *)op->pr_x, 1.0, ld);
+    if (nl == 1) {
+        NLG_TRY(sem_opgradt(m, op->pr_x, op->gp));
+    } else {
+        const double *pp[kMaxLanes];
+        double *const *gl[kMaxLanes];
+        for (int v = 0; v < nl; ++v) pp[v] = L.ops[v]->pr_x, gl[v] = L.ops[v]->gp;
+        NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, false, nullptr));
+    }
+    NLG_TRY(sem_opbinv(m, op->gp, nl, ld));
     {
         CF3 none = {{nullptr, nullptr, nullptr}};
-        launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(unew, dim), cf3(unew, dim),
-                  cf3(op->gp, dim), dt / b0, none, 0.0);
+        launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(unew, dim),
+                  cf3(op->gp, dim), dt / b0, none, 0.0, ld);
     }
     NLG_HIP(hipGetLastError());
     // rotate velocity history: new -> current, current -> lag1, lag1 -> lag2
-    {
-        double *t[3] = {op->ubuf[2][0], op->ubuf[2][1], op->ubuf[2][2]};
-        for (int c = 0; c < 3; ++c) {
-            op->ubuf[2][c] = op->ubuf[1][c];
-            op->ubuf[1][c] = op->ubuf[0][c];
-            op->ubuf[0][c] = t[c];
-        }
-    }
-    op->st_steps += 1;
+    rotate3(L, &nlg_linop::ubuf);
+    for (int v = 0; v < nl; ++v) L.ops[v]->st_steps += 1;
     return 0;
 }
 
+int advance(const Lanes &L) {
+    NLG_TRY(adv_a(L));
+    NLG_TRY(helm_solve(L, L.op()->adv_k, L.op()->adv_h2));
+    NLG_TRY(adv_b(L));
+    NLG_TRY(pres_solve(L, L.op()->dt / L.op()->adv_b0));
+    return adv_c(L);
+}
 int advance(nlg_linop *op) {
-    NLG_TRY(adv_a(op));
-    NLG_TRY(helm_solve(op, op->adv_k, op->adv_h2));
-    NLG_TRY(adv_b(op));
-    NLG_TRY(pres_solve(op, op->dt / op->adv_b0));
-    return adv_c(op);
+    nlg_linop *one[1] = {op};
+    return advance(Lanes{one, 1});
+}
+
+// integrator state of nl lanes <- 0: the rotating velocity / forcing (/ temperature) levels are the first buffers of a lane, in
+// canonical order after the re-binding, so ONE strided memset clears them in every lane
+int reset_state(nlg_linop *op, int nl) {
+    nlg_mesh *m = op->mesh;
+    lane_bind(op, op, 0);
+    for (int v = 1; v < nl; ++v) lane_bind(op, op->lanes[v - 1], v);
+    const int64_t nlev = (int64_t)(6 * m->dim + (op->cfg.ifheat ? 6 : 0)) * m->lvs;
+    NLG_HIP(hipMemset2DAsync(op->slab, sizeof(double) * (size_t)op->slab_ld, 0, sizeof(double) * (size_t)nlev, (size_t)nl, m->ctx->stream));
+    return 0;
 }
 
 int load_state(nlg_linop *op, const nlg_vec *v, int irst) {
@@ -1435,20 +1589,20 @@ int project_alpha(nlg_linop *op, int slot = 0) {
             CF3 cf = {{f.p[0], f.p[1], f.p[2]}};
             if (nl > 0) {
                 if (nf == 3)
-                    hipLaunchKernelGGL(k_proj_sums<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                    NLG_LAUNCH(k_proj_sums<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
                 else if (nf == 2)
-                    hipLaunchKernelGGL(k_proj_sums<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                    NLG_LAUNCH(k_proj_sums<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
                 else
-                    hipLaunchKernelGGL(k_proj_sums<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                    NLG_LAUNCH(k_proj_sums<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
             }
             NLG_TRY(allreduce_sum(m->ctx, op->proj_glob, (int)cnt));
             if (nl > 0) {
                 if (nf == 3)
-                    hipLaunchKernelGGL(k_proj_apply<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                    NLG_LAUNCH(k_proj_apply<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
                 else if (nf == 2)
-                    hipLaunchKernelGGL(k_proj_apply<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                    NLG_LAUNCH(k_proj_apply<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
                 else
-                    hipLaunchKernelGGL(k_proj_apply<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                    NLG_LAUNCH(k_proj_apply<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
             }
             return 0;
         };
@@ -1463,11 +1617,11 @@ int project_alpha(nlg_linop *op, int slot = 0) {
         return 0;
     }
     if (m->dim == 3)
-        hipLaunchKernelGGL(k_proj_alpha<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
+        NLG_LAUNCH(k_proj_alpha<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
                            (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
                            (const double *)op->proj_iden, u);
     else
-        hipLaunchKernelGGL(k_proj_alpha<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
+        NLG_LAUNCH(k_proj_alpha<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
                            (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
                            (const double *)op->proj_iden, u);
     if (op->proj_nlines2 > 0 && slot == 0) {
@@ -1476,7 +1630,7 @@ int project_alpha(nlg_linop *op, int slot = 0) {
         // |mu| = 1.41 for plane Poiseuille flow at alpha = 2 instead of 0.945)
         const unsigned grid2 = (unsigned)((op->proj_nlines2 + NT / 64 - 1) / (NT / 64));
         F3 pp = {{op->p, nullptr, nullptr}};
-        hipLaunchKernelGGL(k_proj_alpha<1>, dim3(grid2), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines2, (const int *)op->proj_off2,
+        NLG_LAUNCH(k_proj_alpha<1>, dim3(grid2), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines2, (const int *)op->proj_off2,
                            (const int *)op->proj_idx2, (const double *)m->d_bm2, (const double *)op->proj_cv2, (const double *)op->proj_sv2,
                            (const double *)op->proj_iden2, pp);
     }
@@ -1495,19 +1649,8 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     NLG_CHECK(vin->lorder >= op->cfg.torder && vout->lorder >= op->cfg.torder,
               "exptA matvec: vector lorder %d < time order %d", vin->lorder, op->cfg.torder);
     NLG_CHECK(vin != vout, "exptA matvec: vec_in and vec_out must be distinct (intent(in) / intent(out))");
-    hipStream_t st = m->ctx->stream;
     const int nrst = op->cfg.torder - 1;
-    // reset integrator state
-    for (int s = 0; s < 3; ++s)
-        for (int c = 0; c < m->dim; ++c) {
-            NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
-            NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
-        }
-    if (op->cfg.ifheat)
-        for (int q = 0; q < 3; ++q) {
-            NLG_HIP(hipMemsetAsync(op->tbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
-            NLG_HIP(hipMemsetAsync(op->ftbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
-        }
+    NLG_TRY(reset_state(op, 1));
     op->istep = 0;
     op->adjoint = adjoint;
     op->nproj = 0;   // the projection space belongs to one matvec: the result must not depend on earlier calls
@@ -1543,209 +1686,16 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
 // =====================================================================================================================
 // Multi-vector (block) propagator: s <= 4 perturbations advanced together, time step by time step (the reference advances
 // several perturbations together through Nek5000's lpert / npert, src/neklab_nek_setup.f90:39-247, src/neklab_otd.f90:37-49).
-// Every vector has a LANE: an operator object with its own integrator state, PCG work vectors and device scalars; the base-
-// flow data (fine-mesh fields of the convective term, preconditioners, weights) belongs to lane 0 and is shared.  The s
-// velocity solves (and the s pressure solves) run as independent PCGs in lockstep -- own alpha, beta, convergence flag per
-// lane, so each lane performs exactly the iteration of the single-vector path -- with the operator applications of an
-// iteration issued together, which is where data that does not depend on the vector is read once for all lanes.
+// Every vector has a LANE: its own integrator state, PCG work vectors and device scalars, all lanes carved from one slab at a
+// constant stride (struct nlg_linop); the base-flow data (fine-mesh fields of the convective term, preconditioners, weights)
+// is shared.  The time step is the single-vector one (advance(Lanes)) with every kernel launched ONCE for all lanes
+// (gridDim.y = lanes, or a lane loop inside the fused element kernels), own alpha / beta / convergence flag per lane -- each
+// lane performs exactly the iteration of the single-vector path -- and, across ranks, ONE halo exchange / all-reduce per
+// gather-scatter / reduction carrying all lanes.
 // =====================================================================================================================
-struct PcgState {
-    Red rd_std, rd_rz, rd_rz_loop, rd_pw;
-    const double *xc = nullptr;
-    int g = 0;
-};
-
-int pcg_reduce_post(nlg_linop *op, const CGProblem &P, const Red &rd, int nsums, int gate, int mode) {
-    nlg_ctx *ctx = op->mesh->ctx;
-    hipStream_t st = ctx->stream;
-    if (!ctx->distributed()) {
-        hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, P.s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit, P.inv_n, 1);
-    } else {
-        hipLaunchKernelGGL(k_cg_final_post, dim3(1), dim3(NTF), 0, st, P.s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit, P.inv_n, 0);
-        NLG_TRY(allreduce_sum(ctx, P.s + S_T0, nsums));
-        hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, P.s, mode, P.tol2, P.use_tol, P.maxit, P.inv_n);
-    }
-    return 0;
-}
-
-// everything run_pcg does before its first operator application
-int pcg_begin(nlg_linop *op, const CGProblem &P, PcgState &S) {
-    nlg_ctx *ctx = op->mesh->ctx;
-    hipStream_t st = ctx->stream;
-    const int nf = P.nf;
-    const int g = S.g = red_grid(P.n);
-    double *partial = ctx->d_partial;
-    F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
-    CF3 pc = cf3(P.pc, nf), cz = cf3(P.z, nf), cr = cf3(P.r, nf);
-    S.rd_std = Red{{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
-    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, dim3(g), st, P.n, x, r, z, pc, P.ipw, P.nw, partial);
-    S.xc = nullptr;
-    S.rd_rz = S.rd_std;
-    if (P.precond) {
-        NLG_TRY(P.precond(nullptr, P.r[0], P.z[0], &S.xc));
-        if (P.rz_part) {
-            S.rd_rz.p[0] = P.rz_part;
-            S.rd_rz.n[0] = P.rz_n;
-            S.rd_rz.p[2] = P.rz_part + P.rz_n;
-            S.rd_rz.n[2] = P.rz_n;
-        } else {
-            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)P.s, 0, P.n, cr, cz, P.ipw, S.xc, P.npe, partial);
-        }
-    }
-    S.rd_rz_loop = S.rd_rz;
-    if (P.rr_part) {
-        S.rd_rz_loop.p[1] = P.rr_part;
-        S.rd_rz_loop.n[1] = P.rr_n;
-    }
-    S.rd_pw = S.rd_std;
-    if (P.pw_part) {
-        S.rd_pw.p[0] = P.pw_part;
-        S.rd_pw.n[0] = P.pw_n;
-        S.rd_pw.p[1] = P.pw_part + P.pw_n;
-        S.rd_pw.n[1] = P.pw_sum ? P.pw_n : 0;
-    }
-    NLG_TRY(pcg_reduce_post(op, P, S.rd_rz, 3, 0, 0));
-    if (!P.fused_pupdate)
-        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)P.s, P.n, p, cz, S.xc, P.npe);   // p = z - zmean
-    hipLaunchKernelGGL(k_cg_post, dim3(1), dim3(1), 0, st, P.s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n);
-    return 0;
-}
-
-// the part of a PCG iteration that follows w = A p
-int pcg_after_apply(nlg_linop *op, const CGProblem &P, PcgState &S) {
-    nlg_ctx *ctx = op->mesh->ctx;
-    hipStream_t st = ctx->stream;
-    const int nf = P.nf, g = S.g;
-    double *partial = ctx->d_partial;
-    F3 x = f3(P.x, nf), r = f3(P.r, nf), z = f3(P.z, nf), p = f3(P.p, nf);
-    CF3 pc = cf3(P.pc, nf), cp = cf3(P.p, nf), cw = cf3(P.w, nf), cz = cf3(P.z, nf), cr = cf3(P.r, nf);
-    const bool prof_cg = prof_want(ctx, P_CGVEC);
-        if (prof_cg) prof_begin(ctx, P_CGVEC);
-    if (!P.pw_part) launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, dim3(g), st, (const double *)P.s, P.n, cp, cw, P.ipw, partial);
-    NLG_TRY(pcg_reduce_post(op, P, S.rd_pw, 2, 1, 1));
-    if (!P.rr_part)
-        launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, dim3(g), st, (const double *)P.s, P.n, x, r, z, cp, cw, pc, P.ipw, P.nw, partial);
-    if (prof_cg) prof_end(ctx, P_CGVEC);
-    if (P.precond) {
-        NLG_TRY(P.precond(P.s + S_DONE, P.r[0], P.z[0], &S.xc));
-        if (!P.rz_part)
-            launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, dim3(g), st, (const double *)P.s, 1, P.n, cr, cz, P.ipw, S.xc, P.npe, partial);
-    }
-    NLG_TRY(pcg_reduce_post(op, P, S.rd_rz_loop, 3, 1, 2));
-    if (!P.fused_pupdate)
-        launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, dim3(g), st, (const double *)P.s, P.n, p, cz, S.xc, P.npe);
-    return 0;
-}
-
-// s PCGs in lockstep.  apply_all() issues w = A p for every lane (each gated by its own done flag on the device).
-template <typename ApplyAll>
-int run_pcg_block(nlg_linop *const *ops, int s, const CGProblem *const *P, ApplyAll apply_all, int *iters) {
-    hipStream_t st = ops[0]->mesh->ctx->stream;
-    PcgState S[4];
-    int chunk = 2, maxit = 0;
-    for (int v = 0; v < s; ++v) {
-        NLG_TRY(pcg_begin(ops[v], *P[v], S[v]));
-        chunk = std::max(chunk, P[v]->chunk);
-        maxit = std::max(maxit, P[v]->maxit);
-    }
-    int launched = 0;
-    while (true) {
-        int todo = launched == 0 ? chunk : 2;
-        if (launched + todo > maxit) todo = maxit - launched;
-        for (int it = 0; it < todo; ++it) {
-            NLG_TRY(apply_all());
-            for (int v = 0; v < s; ++v) NLG_TRY(pcg_after_apply(ops[v], *P[v], S[v]));
-        }
-        launched += todo;
-        NLG_HIP(hipGetLastError());
-        for (int v = 0; v < s; ++v)
-            NLG_HIP(hipMemcpyAsync(ops[0]->h_s + (size_t)v * S_N, P[v]->s, sizeof(double) * S_N, hipMemcpyDeviceToHost, st));
-        NLG_HIP(hipStreamSynchronize(st));
-        bool all_done = true;
-        for (int v = 0; v < s; ++v) all_done = all_done && ops[0]->h_s[(size_t)v * S_N + S_DONE] != 0.0;
-        if (all_done || launched >= maxit) break;
-    }
-    for (int v = 0; v < s; ++v) {
-        const double *h = ops[0]->h_s + (size_t)v * S_N;
-        if (!std::isfinite(h[S_RN2])) {
-            set_error("PCG diverged (residual is not finite) after %d iterations (lane %d of the block)", (int)h[S_ITERS], v);
-            return 1;
-        }
-        iters[v] = (int)h[S_ITERS];
-    }
-    return 0;
-}
-
 // lane v of the block stepper: lane 0 is the operator itself, lanes 1 .. 3 are created on first use
 nlg_linop *lane_get(nlg_linop *op0, int v);
 int lane_refresh(nlg_linop *op0, nlg_linop *ln);
-
-int advance_block(nlg_linop *const *ops, int s) {
-    for (int v = 0; v < s; ++v) NLG_TRY(adv_a(ops[v], 1));
-    {   // convective terms of all lanes against the shared base-flow fields: one launch
-        double *const *ul[4], *const *ol[4];
-        for (int v = 0; v < s; ++v) ul[v] = ops[v]->ubuf[0], ol[v] = ops[v]->fbuf[2];
-        NLG_TRY(sem_conv_apply_lanes(ops[0]->mesh, ops[0]->Ur, ops[0]->GU, s, ul, ol, ops[0]->adjoint));
-    }
-    for (int v = 0; v < s; ++v) NLG_TRY(adv_a(ops[v], 2));
-    {
-        HelmSolve H[4];
-        const CGProblem *P[4];
-        for (int v = 0; v < s; ++v) {
-            NLG_TRY(helm_problem(ops[v], ops[v]->adv_k, ops[v]->adv_h2, H[v]));
-            P[v] = &H[v].P;
-        }
-        int iters[4];
-        // 3-D, lx1 <= 8: the Helmholtz operator of all lanes in one launch, one (p, w) sum per (lane, element)
-        nlg_mesh *m = ops[0]->mesh;
-        // (measured at E = 10^4, lx1 = 8, s = 4: 715 us per launch = 179 us per lane against 167 - 175 us for the per-lane kernel
-        //  -- the kernel is bound by its LDS hand-overs, not by the metric-factor bytes it saves; opt-in: NLG_AXHELM_LANES=1)
-        static const bool lanes_kernel = getenv("NLG_AXHELM_LANES") && atoi(getenv("NLG_AXHELM_LANES")) != 0;
-        const bool batched = lanes_kernel && m->dim == 3 && m->n <= 8 && s >= 2 && H[0].pw_part != nullptr;
-        double *const *uu[4], *const *ww[4], *const *zz[4];
-        double *pw[4];
-        const double *bb[4], *dd[4];
-        for (int v = 0; v < s; ++v) {
-            uu[v] = ops[v]->pv, ww[v] = ops[v]->w, zz[v] = ops[v]->z, pw[v] = H[v].pw_part;
-            bb[v] = ops[v]->d_s + S_BETA, dd[v] = ops[v]->d_s + S_DONE;
-            if (batched) H[v].P.pw_n = (int)m->E;
-        }
-        auto apply_all = [&]() -> int {
-            if (!batched) {
-                for (int v = 0; v < s; ++v) NLG_TRY(helm_apply(ops[v], H[v]));
-                return 0;
-            }
-            NLG_TRY(sem_axhelm_lanes(m, s, uu, ww, H[0].nu, H[0].h2, pw, zz, bb, dd, H[0].xp));
-            for (int v = 0; v < s; ++v) NLG_TRY(sem_gs(m, ops[v]->w, m->dim, dd[v], H[v].xp ? LAYOUT_XP : LAYOUT_NAT));
-            return 0;
-        };
-        NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
-        for (int v = 0; v < s; ++v) NLG_TRY(helm_finish(ops[v], H[v], iters[v]));
-    }
-    for (int v = 0; v < s; ++v) NLG_TRY(adv_b(ops[v]));
-    {
-        PresSolve Q[4];
-        const CGProblem *P[4];
-        for (int v = 0; v < s; ++v) {
-            NLG_TRY(pres_problem(ops[v], ops[v]->dt / ops[v]->adv_b0, Q[v]));
-            P[v] = &Q[v].P;
-        }
-        int iters[4];
-        // E p for all lanes: the gradient and divergence kernels take the lanes in one launch each
-        const double *pp[4], *gg[4];
-        double *ww[4], *pw[4];
-        for (int v = 0; v < s; ++v) pp[v] = ops[v]->pr_p, ww[v] = ops[v]->pr_w, pw[v] = Q[v].pw_part, gg[v] = ops[v]->d_s + S_N + S_DONE;
-        nlg_pupd pu[4];
-        const bool fused = Q[0].P.fused_pupdate;
-        for (int v = 0; v < s; ++v)
-            if (fused) pu[v].z = ops[v]->pr_z, pu[v].beta = ops[v]->d_s + S_N + S_BETA, pu[v].zmean = ops[v]->d_s + S_N + S_ZMEAN, pu[v].p = ops[v]->pr_p;
-        auto apply_all = [&]() -> int { return sem_cdabdtp_lanes(ops[0]->mesh, s, pp, ww, pw, gg, fused ? pu : nullptr); };
-        NLG_TRY(run_pcg_block(ops, s, P, apply_all, iters));
-        for (int v = 0; v < s; ++v) NLG_TRY(pres_finish(ops[v], Q[v], iters[v]));
-    }
-    for (int v = 0; v < s; ++v) NLG_TRY(adv_c(ops[v]));
-    return 0;
-}
 
 // vec_out = state after the nsteps of one application started from `ic` (null: rest) under the time-harmonic body force
 // Re[(f_re + i f_im) exp(i s omega t)], s = -1 for the adjoint equations: evaluate_rhs / evaluate_imaginary_part of the
@@ -1758,11 +1708,7 @@ int do_integrate_forced(nlg_linop *op, const nlg_vec *ic, const nlg_vec *f_re, c
     NLG_CHECK(vout != f_re && vout != f_im && vout != ic, "integrate_forced: the output must be distinct from the inputs");
     NLG_CHECK(f_re->nscal == 0 && vout->nscal == 0, "integrate_forced: scalar (temperature) coupling is not built yet");
     hipStream_t st = m->ctx->stream;
-    for (int s = 0; s < 3; ++s)
-        for (int c = 0; c < m->dim; ++c) {
-            NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
-            NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
-        }
+    NLG_TRY(reset_state(op, 1));
     NLG_HIP(hipMemsetAsync(op->p, 0, sizeof(double) * (size_t)m->lps, st));
     op->istep = 0;
     op->adjoint = adjoint;
@@ -1794,16 +1740,7 @@ int do_nonlinear_map(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout) {
     // "setup_nonlinear_solver(recompute_dt = .true.)": the time step follows the state that is integrated
     NLG_TRY(nlg_vec_copy(op->baseflow, vin));
     NLG_TRY(nlg_linop_init(op));
-    for (int s = 0; s < 3; ++s)
-        for (int c = 0; c < m->dim; ++c) {
-            NLG_HIP(hipMemsetAsync(op->ubuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
-            NLG_HIP(hipMemsetAsync(op->fbuf[s][c], 0, sizeof(double) * (size_t)m->lvs, st));
-        }
-    if (op->cfg.ifheat)
-        for (int q = 0; q < 3; ++q) {
-            NLG_HIP(hipMemsetAsync(op->tbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
-            NLG_HIP(hipMemsetAsync(op->ftbuf[q], 0, sizeof(double) * (size_t)m->lvs, st));
-        }
+    NLG_TRY(reset_state(op, 1));
     op->istep = 0;
     op->adjoint = 0;
     op->nproj = 0;
@@ -1864,54 +1801,24 @@ int nlg_linop_destroy(nlg_linop *op) {
         if (ln) nlg_linop_destroy(ln);
         ln = nullptr;
     }
-    if (op->is_lane) {   // shared with the owner: forget the pointers, free only what the lane allocated itself
-        for (int c = 0; c < 3; ++c) {
-            op->Ur[c] = nullptr;
-            for (int k = 0; k < 4; ++k) op->pcv[k][c] = op->pcv_xp[k][c] = nullptr;
-        }
-        for (int q = 0; q < 9; ++q) op->GU[q] = nullptr;
-        op->pce = op->nwv = op->nwv_xp = op->nwp = nullptr;
-        op->baseflow = nullptr;
+    if (op->is_lane) {   // a lane owns nothing: its work buffers are the owner's slab, the base-flow data is shared
+        delete op;
+        return 0;
     }
-    for (auto &kv : op->graphs)
-        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
-    op->graphs.clear();
     auto fr = [](double *p) {
         if (p) hipFree(p);
     };
+    fr(op->slab);        // every per-lane work buffer (lane_buffers)
+    fr(op->d_red);
     for (int c = 0; c < 3; ++c) {
         fr(op->Ur[c]);
-        for (int s = 0; s < 3; ++s) {
-            fr(op->ubuf[s][c]);
-            fr(op->fbuf[s][c]);
-        }
-        fr(op->rhs[c]);
-        fr(op->x[c]);
-        fr(op->z[c]);
-        fr(op->pv[c]);
-        fr(op->w[c]);
-        fr(op->gp[c]);
         for (int k = 0; k < 4; ++k) fr(op->pcv[k][c]);
         for (int k = 0; k < 4; ++k) fr(op->pcv_xp[k][c]);
     }
     for (int q = 0; q < 9; ++q) fr(op->GU[q]);
-    fr(op->p);
-    fr(op->pr_r);
-    fr(op->pr_x);
-    fr(op->pr_z);
-    fr(op->pr_p);
-    fr(op->pr_w);
     fr(op->pce);
-    for (int q = 0; q < 3; ++q) {
-        fr(op->tbuf[q]);
-        fr(op->ftbuf[q]);
-        fr(op->GT[q]);
-    }
+    for (int q = 0; q < 3; ++q) fr(op->GT[q]);
     for (int k = 0; k < 4; ++k) fr(op->pct[k]);
-    for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) fr(*v);
-    fr(op->prX);
-    fr(op->prB);
-    fr(op->d_pc);
     fr(op->proj_cv);
     fr(op->proj_sv);
     fr(op->proj_iden);
@@ -1928,8 +1835,6 @@ int nlg_linop_destroy(nlg_linop *op) {
     fr(op->nwv);
     fr(op->nwv_xp);
     fr(op->nwp);
-    fr(op->d_s);
-    fr(op->d_part);
     if (op->h_s) hipHostFree(op->h_s);
     if (op->baseflow) nlg_vec_destroy(op->baseflow);
     delete op;
@@ -1943,40 +1848,18 @@ int nlg_linop_init(nlg_linop *op) {
     hipStream_t st = ctx->stream;
     const int dim = m->dim;
     NLG_HIP(hipSetDevice(ctx->device));
-    if (!op->d_s) {
+    if (!op->slab) {
         for (int c = 0; c < dim; ++c) {
             NLG_HIP(hipMalloc(&op->Ur[c], sizeof(double) * (size_t)m->lfn));
-            for (int s = 0; s < 3; ++s) {
-                NLG_TRY(lalloc(op, &op->ubuf[s][c], m->lvs));
-                NLG_TRY(lalloc(op, &op->fbuf[s][c], m->lvs));
-            }
-            NLG_TRY(lalloc(op, &op->rhs[c], m->lvs));
-            NLG_TRY(lalloc(op, &op->x[c], m->lvs));
-            NLG_TRY(lalloc(op, &op->z[c], m->lvs));
-            NLG_TRY(lalloc(op, &op->pv[c], m->lvs));
-            NLG_TRY(lalloc(op, &op->w[c], m->lvs));
-            NLG_TRY(lalloc(op, &op->gp[c], m->lvs));
             for (int k = 1; k <= op->cfg.torder; ++k) NLG_TRY(lalloc(op, &op->pcv[k][c], m->lvs));
         }
         for (int q = 0; q < dim * dim; ++q) NLG_HIP(hipMalloc(&op->GU[q], sizeof(double) * (size_t)m->lfn));
-        NLG_TRY(lalloc(op, &op->p, m->lps));
-        NLG_TRY(lalloc(op, &op->pr_r, m->lps));
-        NLG_TRY(lalloc(op, &op->pr_x, m->lps));
-        NLG_TRY(lalloc(op, &op->pr_z, m->lps));
-        NLG_TRY(lalloc(op, &op->pr_p, m->lps));
-        NLG_TRY(lalloc(op, &op->pr_w, m->lps));
         NLG_TRY(lalloc(op, &op->pce, m->lps));
-        if (op->cfg.pproj) {
-            NLG_TRY(lalloc(op, &op->prX, (int64_t)PROJ_L * m->lps));
-            NLG_TRY(lalloc(op, &op->prB, (int64_t)PROJ_L * m->lps));
-            NLG_TRY(lalloc(op, &op->d_pc, 4 * PROJ_L + PROJ_L * NB));
-        }
         NLG_TRY(lalloc(op, &op->nwv, m->lvs));
         NLG_TRY(lalloc(op, &op->nwp, m->lps));
-        NLG_TRY(lalloc(op, &op->d_s, 4 * S_N));
-        NLG_TRY(lalloc(op, &op->d_part, 3 * m->E + 16));
-        NLG_HIP(hipHostMalloc(&op->h_s, sizeof(double) * 4 * S_N, hipHostMallocDefault));
+        NLG_HIP(hipHostMalloc(&op->h_s, sizeof(double) * kMaxLanes * S_N, hipHostMallocDefault));
         NLG_TRY(reduce_ws_reserve(ctx, 4));
+        NLG_TRY(slab_ensure(op, 1));   // the work buffers of one lane; a block matvec grows the slab on first use
     }
     double *U[3] = {op->baseflow->vel(0), op->baseflow->vel(1), dim == 3 ? op->baseflow->vel(2) : nullptr};
     // dt / nsteps (reference: neklab_nek_setup.f90:195-198)
@@ -2004,7 +1887,7 @@ int nlg_linop_init(nlg_linop *op) {
         double *f[1] = {dg};
         NLG_TRY(sem_gs(m, f, 1));
         for (int c = 0; c < dim; ++c)
-            hipLaunchKernelGGL(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pcv[k][c], (const double *)dg,
+            NLG_LAUNCH(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pcv[k][c], (const double *)dg,
                                (const double *)m->d_mask[c]);
     }
     if (op->use_xp < 0) {
@@ -2019,12 +1902,7 @@ int nlg_linop_init(nlg_linop *op) {
         }
     }
     if (op->cfg.ifheat) {
-        if (!op->trhs) {
-            for (int q = 0; q < 3; ++q) {
-                NLG_TRY(lalloc(op, &op->tbuf[q], m->lvs));
-                NLG_TRY(lalloc(op, &op->ftbuf[q], m->lvs));
-            }
-            for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) NLG_TRY(lalloc(op, v, m->lvs));
+        if (!op->pct[1]) {
             for (int k = 1; k <= op->cfg.torder; ++k) NLG_TRY(lalloc(op, &op->pct[k], m->lvs));
             for (int q = 0; q < dim; ++q) NLG_HIP(hipMalloc(&op->GT[q], sizeof(double) * (size_t)m->lfn));
         }
@@ -2035,7 +1913,7 @@ int nlg_linop_init(nlg_linop *op) {
             NLG_TRY(sem_helm_diag(m, dg, op->cfg.conductivity, op->cfg.rhocp * BDF_B0[k] / op->dt));
             double *f[1] = {dg};
             NLG_TRY(sem_gs(m, f, 1));
-            hipLaunchKernelGGL(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pct[k], (const double *)dg,
+            NLG_LAUNCH(k_recipmask, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->pct[k], (const double *)dg,
                                (const double *)m->d_tmask);
         }
     }
@@ -2043,11 +1921,11 @@ int nlg_linop_init(nlg_linop *op) {
         double *ed = sem_scratch2(m, 5);
         NLG_CHECK(ed, "nlg_linop_init: scratch allocation failed");
         NLG_TRY(sem_ediag(m, ed));
-        hipLaunchKernelGGL(k_recip1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pce, (const double *)ed);
+        NLG_LAUNCH(k_recip1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->pce, (const double *)ed);
     }
-    hipLaunchKernelGGL(k_mul3, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->nwv, (const double *)m->d_binvm1,
+    NLG_LAUNCH(k_mul3, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->nwv, (const double *)m->d_binvm1,
                        (const double *)m->d_vmult, 1.0 / m->volvm1);
-    hipLaunchKernelGGL(k_scale1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->nwp, (const double *)m->d_bm2inv,
+    NLG_LAUNCH(k_scale1, dim3(grid_for(m->lpn)), dim3(NT), 0, st, m->lpn, op->nwp, (const double *)m->d_bm2inv,
                        1.0 / m->volvm2);
     if (op->use_xp > 0) {
         if (!op->nwv_xp) NLG_TRY(lalloc(op, &op->nwv_xp, m->lvs));
@@ -2128,7 +2006,7 @@ int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_
             NLG_HIP(hipMemcpy(tmp, h_x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
             xs = tmp;
         }
-        hipLaunchKernelGGL(k_cossin, dim3(grid_for(n)), dim3(NT), 0, st, n, xs, alpha, *d_cv, *d_sv);
+        NLG_LAUNCH(k_cossin, dim3(grid_for(n)), dim3(NT), 0, st, n, xs, alpha, *d_cv, *d_sv);
         NLG_HIP(hipGetLastError());
         NLG_HIP(hipStreamSynchronize(st));
         if (tmp) hipFree(tmp);
@@ -2180,11 +2058,11 @@ int nlg_linop_set_projection(nlg_linop *op, double alpha, int idir, const int64_
             NLG_HIP(hipMemsetAsync(op->proj_glob, 0, sizeof(double) * (size_t)*nglob, st));
             const unsigned g1 = (unsigned)((nlines + NT / 64 - 1) / (NT / 64));
             if (nlines > 0)
-                hipLaunchKernelGGL(k_proj_wsum, dim3(g1), dim3(NT), 0, st, (int64_t)nlines, (const int *)*d_off, (const int *)*d_idx,
+                NLG_LAUNCH(k_proj_wsum, dim3(g1), dim3(NT), 0, st, (int64_t)nlines, (const int *)*d_off, (const int *)*d_idx,
                                    (const int *)*d_gslot, d_w, op->proj_glob);
             NLG_TRY(allreduce_sum(ctx, op->proj_glob, (int)*nglob));
             if (nlines > 0)
-                hipLaunchKernelGGL(k_proj_iden, dim3(grid_for(nlines)), dim3(NT), 0, st, (int64_t)nlines, (const int *)*d_gslot,
+                NLG_LAUNCH(k_proj_iden, dim3(grid_for(nlines)), dim3(NT), 0, st, (int64_t)nlines, (const int *)*d_gslot,
                                    (const double *)op->proj_glob, *d_iden);
             NLG_HIP(hipGetLastError());
             NLG_HIP(hipStreamSynchronize(st));
@@ -2247,42 +2125,14 @@ int nlg_linop_get_stats(const nlg_linop *op, int64_t *steps, int64_t *v_iters, i
 
 namespace {
 
-// lane v >= 1: own integrator state and PCG work vectors (the allocations of nlg_linop_init), shared base-flow data
+// lane v >= 1: an operator object whose work buffers are lane v of the owner's slab; base-flow data shared with the owner
 nlg_linop *lane_get(nlg_linop *op0, int v) {
     if (v == 0) return op0;
     if (op0->lanes[v - 1]) return op0->lanes[v - 1];
-    nlg_mesh *m = op0->mesh;
-    const int dim = m->dim;
     nlg_linop *ln = new nlg_linop();
-    ln->mesh = m;
+    ln->mesh = op0->mesh;
     ln->is_lane = true;
     ln->cfg = op0->cfg;
-    bool ok = true;
-    auto al = [&](double **p, int64_t n) { ok = ok && lalloc(ln, p, n) == 0; };
-    for (int c = 0; c < dim; ++c) {
-        for (int q = 0; q < 3; ++q) {
-            al(&ln->ubuf[q][c], m->lvs);
-            al(&ln->fbuf[q][c], m->lvs);
-        }
-        al(&ln->rhs[c], m->lvs);
-        al(&ln->x[c], m->lvs);
-        al(&ln->z[c], m->lvs);
-        al(&ln->pv[c], m->lvs);
-        al(&ln->w[c], m->lvs);
-        al(&ln->gp[c], m->lvs);
-    }
-    for (double **q : {&ln->p, &ln->pr_r, &ln->pr_x, &ln->pr_z, &ln->pr_p, &ln->pr_w}) al(q, m->lps);
-    if (op0->cfg.pproj) {
-        al(&ln->prX, (int64_t)PROJ_L * m->lps);
-        al(&ln->prB, (int64_t)PROJ_L * m->lps);
-        al(&ln->d_pc, 4 * PROJ_L + PROJ_L * NB);
-    }
-    al(&ln->d_s, 4 * S_N);
-    al(&ln->d_part, 3 * m->E + 16);
-    if (!ok) {
-        nlg_linop_destroy(ln);
-        return nullptr;
-    }
     op0->lanes[v - 1] = ln;
     return ln;
 }
@@ -2301,13 +2151,13 @@ int lane_refresh(nlg_linop *op0, nlg_linop *ln) {
     for (int q = 0; q < 9; ++q) ln->GU[q] = op0->GU[q];
     ln->pce = op0->pce, ln->nwv = op0->nwv, ln->nwv_xp = op0->nwv_xp, ln->nwp = op0->nwp;
     ln->use_xp = op0->use_xp;
-    ln->h_s = nullptr;   // the block PCG reads every lane's scalars through the owner's pinned buffer
+    ln->h_s = nullptr;   // the PCG reads every lane's scalars through the owner's pinned buffer
     return 0;
 }
 
 int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *const *vout, int adjoint) {
     NLG_CHECK(op && vin && vout, "exptA block matvec: NULL argument");
-    NLG_CHECK(s >= 1 && s <= 4, "exptA block matvec: %d vectors unsupported (1..4)", s);
+    NLG_CHECK(s >= 1 && s <= kMaxLanes, "exptA block matvec: %d vectors unsupported (1..%d)", s, kMaxLanes);
     NLG_CHECK(op->inited, "exptA block matvec: nlg_linop_init has not been called");
     NLG_CHECK(!op->is_lane, "exptA block matvec: called on a lane");
     nlg_mesh *m = op->mesh;
@@ -2320,28 +2170,25 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
         for (int u = 0; u < s; ++u) NLG_CHECK(vin[v] != vout[u], "exptA block matvec: an input vector is also an output vector");
         for (int u = 0; u < v; ++u) NLG_CHECK(vout[v] != vout[u], "exptA block matvec: the same output vector twice");
     }
-    hipStream_t st = m->ctx->stream;
-    nlg_linop *ops[4];
+    nlg_linop *ops[kMaxLanes];
     for (int v = 0; v < s; ++v) {
         ops[v] = lane_get(op, v);
         NLG_CHECK(ops[v], "exptA block matvec: lane allocation failed");
         NLG_TRY(lane_refresh(op, ops[v]));
     }
+    NLG_TRY(slab_ensure(op, s));
+    NLG_TRY(reset_state(op, s));
     const int nrst = op->cfg.torder - 1;
     for (int v = 0; v < s; ++v) {
         nlg_linop *ln = ops[v];
-        for (int q = 0; q < 3; ++q)
-            for (int c = 0; c < m->dim; ++c) {
-                NLG_HIP(hipMemsetAsync(ln->ubuf[q][c], 0, sizeof(double) * (size_t)m->lvs, st));
-                NLG_HIP(hipMemsetAsync(ln->fbuf[q][c], 0, sizeof(double) * (size_t)m->lvs, st));
-            }
         ln->istep = 0;
         ln->adjoint = adjoint;
         ln->nproj = 0;
         NLG_TRY(load_state(ln, vin[v], 0));
     }
+    const Lanes L{ops, s};
     for (int istep = 1; istep <= op->nsteps; ++istep) {
-        NLG_TRY(advance_block(ops, s));
+        NLG_TRY(advance(L));
         if (istep <= nrst)
             for (int v = 0; v < s; ++v)
                 if (vin[v]->nrst > 0) NLG_TRY(load_state(ops[v], vin[v], istep));   // get_rst, exponential_propagator.f90:129-142
@@ -2351,7 +2198,7 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
         NLG_TRY(store_state(ops[v], vout[v], 0));
     }
     for (int irst = 1; irst <= nrst; ++irst) {   // compute_rst, :109-127
-        NLG_TRY(advance_block(ops, s));
+        NLG_TRY(advance(L));
         for (int v = 0; v < s; ++v) {
             NLG_TRY(store_state(ops[v], vout[v], irst));
             vout[v]->nrst = std::max(vout[v]->nrst, irst);

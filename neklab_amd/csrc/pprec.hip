@@ -239,10 +239,15 @@ template <int N, int WPB, int WPE = 1>
 __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                 const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                 const double *__restrict__ wq, double *__restrict__ W,
-                                                double *__restrict__ z, const int *__restrict__ tab) {
+                                                double *__restrict__ z, const int *__restrict__ tab, int64_t ld, int64_t lW) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
     __shared__ double sL[WPB][3][N];
     __shared__ double sA[WPB][NP];   // the six transforms run in place (fdm_stage_inplace3)
+    {   // blockIdx.y = lane of a block step
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+        if (flag) flag += lo;
+        r += lo, z += lo, W += (int64_t)blockIdx.y * lW;
+    }
     if (flag && flag[0] != 0.0) return;
     static_assert(WPB == 1 || WPE == 1, "either several elements per block or several waves per element");
     constexpr int ST = 64 * WPE;                                   // threads that share one element
@@ -363,9 +368,17 @@ __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ fl
                                                    const double *__restrict__ r, const double *__restrict__ wq,
                                                    const double *__restrict__ xc, const double *__restrict__ xa,
                                                    const int *__restrict__ agg, const int *__restrict__ vg, Hat hat,
-                                                   double *__restrict__ z, double *__restrict__ part, const int *__restrict__ wslot) {
+                                                   double *__restrict__ z, double *__restrict__ part, const int *__restrict__ wslot,
+                                                   int64_t ld, int64_t lW, int64_t lv, int64_t la) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
     __shared__ double sred[8];
+    {   // blockIdx.y = lane of a block step
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+        if (flag) flag += lo;
+        r += lo, z += lo, W += (int64_t)blockIdx.y * lW;
+        if (part) part += lo;
+        if (xc) xc += (int64_t)blockIdx.y * lv, xa += (int64_t)blockIdx.y * la;
+    }
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 4 + wv;
@@ -586,8 +599,16 @@ template <int DIM>
 __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restrict__ flag, int64_t E, int n2, Hat hat,
                                                           double *__restrict__ r, double *__restrict__ t,
                                                           double *__restrict__ W, const double *__restrict__ wq,
-                                                          nlg_pcg_upd u) {
+                                                          nlg_pcg_upd u, int64_t ld = 0, int64_t lt = 0, int64_t lW = 0) {
     __shared__ double srr[4];
+    {   // blockIdx.y = lane of a block step: solver fields ld doubles apart (the integrator's slab), the preconditioner's own scratch at its strides
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+        if (flag) flag += lo;
+        r += lo;
+        t += (int64_t)blockIdx.y * lt;
+        if (W) W += (int64_t)blockIdx.y * lW;
+        if (u.alpha) u.alpha += lo, u.wmean += lo, u.x += lo, u.p += lo, u.w += lo, u.rr_part += lo;
+    }
     if (flag && flag[0] != 0.0) return;
     constexpr int NC = 1 << DIM;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -664,8 +685,16 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restri
 template <int N2>
 __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__restrict__ flag, int64_t E, Hat hat, double *__restrict__ r,
                                                             double *__restrict__ t, double *__restrict__ W, const double *__restrict__ wq,
-                                                            const int *__restrict__ wslot, nlg_pcg_upd u) {
+                                                            const int *__restrict__ wslot, nlg_pcg_upd u, int64_t ld, int64_t lt, int64_t lW) {
     __shared__ double srr[4];
+    {   // blockIdx.y = lane of a block step: solver fields ld doubles apart (the integrator's slab), the preconditioner's own scratch at its strides
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+        if (flag) flag += lo;
+        r += lo;
+        t += (int64_t)blockIdx.y * lt;
+        if (W) W += (int64_t)blockIdx.y * lW;
+        if (u.alpha) u.alpha += lo, u.wmean += lo, u.x += lo, u.p += lo, u.w += lo, u.rr_part += lo;
+    }
     if (flag && flag[0] != 0.0) return;
     constexpr int NP2 = N2 * N2 * N2, N = N2 + 2, NIT = 4;   // four points per lane in flight (lx1 = 8: the whole element)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -750,7 +779,9 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
 __global__ __launch_bounds__(NT) void k_q1_gather(const double *__restrict__ flag, int nvert, const int *__restrict__ vp,
                                                   const int *__restrict__ vi, const double *__restrict__ t,
                                                   double *__restrict__ rc, const double *__restrict__ dinv, double om,
-                                                  double *__restrict__ x) {
+                                                  double *__restrict__ x, int64_t ld = 0, int64_t lt = 0, int64_t lv = 0) {
+    if (flag) flag += (int64_t)blockIdx.y * ld;
+    t += (int64_t)blockIdx.y * lt, rc += (int64_t)blockIdx.y * lv, x += (int64_t)blockIdx.y * lv;
     if (flag && flag[0] != 0.0) return;
     const int v = blockIdx.x * NT + threadIdx.x;
     if (v >= nvert) return;
@@ -834,7 +865,9 @@ __global__ void k_mirror_upper(int n, double *__restrict__ A) {
 // ra[a] = sum of rr over the members of aggregate a, one wave per aggregate
 __global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na, const int *__restrict__ ap,
                                                      const int *__restrict__ am, const double *__restrict__ rr,
-                                                     double *__restrict__ ra) {
+                                                     double *__restrict__ ra, int64_t ld = 0, int64_t lv = 0, int64_t la = 0) {
+    if (flag) flag += (int64_t)blockIdx.y * ld;
+    rr += (int64_t)blockIdx.y * lv, ra += (int64_t)blockIdx.y * la;
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int a = blockIdx.x * 4 + wid;
@@ -852,11 +885,27 @@ __global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na,
 // across the ranks that hold its rows; sums in double.
 template <typename T>
 __global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, int ncols, const T *__restrict__ Ainv,
-                                                   const double *__restrict__ ra, double *__restrict__ xa) {
+                                                   const double *__restrict__ ra, double *__restrict__ xa, int64_t ld = 0, int64_t la = 0,
+                                                   int na_max = 0, int nlanes = 1) {
+    // lanes of a block step (blockIdx.y): one rank -- ra, xa la doubles apart; several ranks -- ra is the all-gathered array
+    // [rank][lane][na_max] (na_max > 0), column c of the global aggregate level = entry c % na_max of rank c / na_max
+    if (flag) flag += (int64_t)blockIdx.y * ld;
+    xa += (int64_t)blockIdx.y * la;
+    if (na_max == 0) ra += (int64_t)blockIdx.y * la;
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     if (row >= na) return;
+    if (na_max > 0 && nlanes > 1) {   // (strided gather of the lane's entries; set-up sizes: a few thousand columns)
+        double s = 0.0;
+        const T *__restrict__ Ar = Ainv + (size_t)row * ncols;
+        for (int j = lane; j < ncols; j += 64)
+            s += (double)Ar[j] * ra[((int64_t)(j / na_max) * nlanes + blockIdx.y) * na_max + j % na_max];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) xa[row] = s;
+        return;
+    }
     // eight loads of the row in flight per lane (same summation order as the plain loop: the products are added one after the
     // other); a wave per row gives only ~1.3 waves per SIMD at 1300 rows, so the loads of one wave must overlap themselves
     double s = 0.0;
@@ -1347,16 +1396,16 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
                     for (int e1 : adj[e]) owner[e1] = (int)e;
             for (int c = 0; c < NC && rc == 0; ++c) {
                 if (dim == 3) {
-                    hipLaunchKernelGGL(k_q1_probe<3>, dim3(gp), dim3(NT), 0, st, E, n2, hat, d_colour, col, c, pp);
+                    NLG_LAUNCH(k_q1_probe<3>, dim3(gp), dim3(NT), 0, st, E, n2, hat, d_colour, col, c, pp);
                 } else {
-                    hipLaunchKernelGGL(k_q1_probe<2>, dim3(gp), dim3(NT), 0, st, E, n2, hat, d_colour, col, c, pp);
+                    NLG_LAUNCH(k_q1_probe<2>, dim3(gp), dim3(NT), 0, st, E, n2, hat, d_colour, col, c, pp);
                 }
                 rc = sem_cdabdtp(m, pp, ep);
                 if (rc) break;
                 if (dim == 3) {
-                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
+                    NLG_LAUNCH(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 } else {
-                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
+                    NLG_LAUNCH(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, d_t8, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 }
                 if (hipMemcpyAsync(t8.data(), d_t8, sizeof(double) * t8.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipStreamSynchronize(st) != hipSuccess) {
@@ -1541,8 +1590,8 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         NLG_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
         const unsigned gx = (unsigned)((nn + NT - 1) / NT);
         for (int k = 0; k < nn; ++k) {
-            hipLaunchKernelGGL(k_gj_prep, dim3(gx), dim3(NT), 0, st, nn, k, (const double *)dA, rk, ck, bad);
-            hipLaunchKernelGGL(k_gj_update, dim3(gx, (unsigned)nn), dim3(NT), 0, st, nn, k, dA, (const double *)rk, (const double *)ck);
+            NLG_LAUNCH(k_gj_prep, dim3(gx), dim3(NT), 0, st, nn, k, (const double *)dA, rk, ck, bad);
+            NLG_LAUNCH(k_gj_update, dim3(gx, (unsigned)nn), dim3(NT), 0, st, nn, k, dA, (const double *)rk, (const double *)ck);
         }
         NLG_HIP(hipGetLastError());
         NLG_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1574,7 +1623,7 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         NLG_CHECK(s1 == rocblas_status_success && s2 == rocblas_status_success, "pprec_setup: rocSOLVER potrf/potri failed (%d, %d)", (int)s1, (int)s2);
         NLG_CHECK(hinfo[0] == 0 && hinfo[1] == 0, "pprec_setup: aggregate operator is not positive definite (potrf info %d)", hinfo[0]);
         // column-major lower triangle = row-major upper triangle: mirror it
-        hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)((nn + 255) / 256), (unsigned)nn), dim3(256), 0, st, nn, dA);
+        NLG_LAUNCH(k_mirror_upper, dim3((unsigned)((nn + 255) / 256), (unsigned)nn), dim3(256), 0, st, nn, dA);
         NLG_HIP(hipGetLastError());
         return 0;
     };
@@ -1662,20 +1711,20 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
                 const int a_src = (int)ifa_all[(size_t)r * stride_i + i];
                 const int a = me == r ? a_src : -1;
                 if (dim == 3) {
-                    hipLaunchKernelGGL(k_agg_probe<3>, dim3(gp), dim3(NT), 0, st, E, n2, hat, (const int *)P.d_vg, (const int *)P.d_agg, a, pp);
+                    NLG_LAUNCH(k_agg_probe<3>, dim3(gp), dim3(NT), 0, st, E, n2, hat, (const int *)P.d_vg, (const int *)P.d_agg, a, pp);
                 } else {
-                    hipLaunchKernelGGL(k_agg_probe<2>, dim3(gp), dim3(NT), 0, st, E, n2, hat, (const int *)P.d_vg, (const int *)P.d_agg, a, pp);
+                    NLG_LAUNCH(k_agg_probe<2>, dim3(gp), dim3(NT), 0, st, E, n2, hat, (const int *)P.d_vg, (const int *)P.d_agg, a, pp);
                 }
                 NLG_TRY(sem_cdabdtp(m, pp, ep));
                 if (me == r) continue;   // own block: already there
                 if (dim == 3) {
-                    hipLaunchKernelGGL(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
+                    NLG_LAUNCH(k_q1_restrict_local<3>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 } else {
-                    hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
+                    NLG_LAUNCH(k_q1_restrict_local<2>, dim3(ge), dim3(NT), 0, st, (const double *)nullptr, E, n2, hat, ep, P.d_tq, (double *)nullptr, (const double *)nullptr, nlg_pcg_upd{});
                 }
-                hipLaunchKernelGGL(k_q1_gather, dim3((nvert + NT - 1) / NT), dim3(NT), 0, st, (const double *)nullptr, nvert, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, 0.0, P.d_x);
-                hipLaunchKernelGGL(k_agg_restrict, dim3((na + 3) / 4), dim3(NT), 0, st, (const double *)nullptr, na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
-                hipLaunchKernelGGL(k_store_col, dim3((na + 255) / 256), dim3(256), 0, st, na, (const double *)P.d_ra, d_rows, ntot, (int64_t)r * na_max + a_src);
+                NLG_LAUNCH(k_q1_gather, dim3((nvert + NT - 1) / NT), dim3(NT), 0, st, (const double *)nullptr, nvert, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, 0.0, P.d_x);
+                NLG_LAUNCH(k_agg_restrict, dim3((na + 3) / 4), dim3(NT), 0, st, (const double *)nullptr, na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
+                NLG_LAUNCH(k_store_col, dim3((na + 255) / 256), dim3(256), 0, st, na, (const double *)P.d_ra, d_rows, ntot, (int64_t)r * na_max + a_src);
             }
         NLG_HIP(hipGetLastError());
         NLG_HIP(hipMalloc(&d_full, sizeof(double) * (size_t)ntot * ntot));
@@ -1701,11 +1750,11 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
         int *d_na_of = nullptr;
         NLG_TRY(up(na_all, &d_na_of));
         const double alpha = m->has_outflow ? 0.0 : tr_all / nreal / nreal;
-        hipLaunchKernelGGL(k_glob_fix, dim3((unsigned)((ntot + 255) / 256), (unsigned)ntot), dim3(256), 0, st, ntot, na_max, (const int *)d_na_of, alpha, d_full);
+        NLG_LAUNCH(k_glob_fix, dim3((unsigned)((ntot + 255) / 256), (unsigned)ntot), dim3(256), 0, st, ntot, na_max, (const int *)d_na_of, alpha, d_full);
         NLG_TRY(spd_inverse_dev(d_full, (int)ntot));
         const int64_t nrow_el = (int64_t)std::max(na, 1) * ntot;
         NLG_HIP(hipMalloc(&P.d_Ainv32, sizeof(float) * (size_t)nrow_el));
-        hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nrow_el + 255) / 256)), dim3(256), 0, st, (int64_t)na * ntot,
+        NLG_LAUNCH(k_to_float, dim3((unsigned)((nrow_el + 255) / 256)), dim3(256), 0, st, (int64_t)na * ntot,
                            (const double *)(d_full + (size_t)me * na_max * ntot), P.d_Ainv32);
         NLG_HIP(hipGetLastError());
         NLG_HIP(hipStreamSynchronize(st));
@@ -1719,48 +1768,97 @@ int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
     return 0;
 }
 
+// Scratch of the preconditioner for `nl` lanes of a block step: nl copies of the exchange array W, the element-corner
+// residuals, the vertex-level and the aggregate-level vectors at constant strides (the kernels reach lane v through blockIdx.y).
+// One copy exists after pprec_setup; more are made on first use.
+int pprec_reserve_lanes(nlg_mesh *m, int nl) {
+    nlg_pprec &P = m->pprec;
+    NLG_CHECK(P.ready, "pprec: preconditioner not set up");
+    NLG_CHECK(nl >= 1 && nl <= kMaxLanes, "pprec: %d lanes", nl);
+    if (nl <= P.lanes_cap) return 0;
+    hipStream_t st = m->ctx->stream;
+    NLG_HIP(hipStreamSynchronize(st));
+    const int NC = 1 << m->dim;
+    auto regrow = [&](double **p, int64_t len1, int64_t *stride, bool exact = false) -> int {
+        if (!*p) {
+            *stride = 0;
+            return 0;
+        }
+        const int64_t sd = exact ? std::max<int64_t>(len1, 1) : round_up(std::max<int64_t>(len1, 1), kAlign);
+        double *q = nullptr;
+        NLG_HIP(hipMalloc(&q, sizeof(double) * (size_t)(sd * nl)));
+        NLG_HIP(hipMemsetAsync(q, 0, sizeof(double) * (size_t)(sd * nl), st));
+        NLG_HIP(hipMemcpyAsync(q, *p, sizeof(double) * (size_t)len1, hipMemcpyDeviceToDevice, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        NLG_HIP(hipFree(*p));
+        *p = q;
+        *stride = sd;
+        return 0;
+    };
+    NLG_TRY(regrow(&P.d_W, m->lvs, &P.lW));
+    NLG_TRY(regrow(&P.d_tq, m->E * NC, &P.lt));
+    int64_t lv2 = 0, la2 = 0;
+    NLG_TRY(regrow(&P.d_rc, P.nvert, &P.lv));
+    NLG_TRY(regrow(&P.d_x, P.nvert, &lv2));
+    const bool glob = P.ncols != P.na;                         // several ranks: d_ra holds na_max entries (zero-padded)
+    NLG_TRY(regrow(&P.d_ra, glob ? P.na_max : P.na, &P.la, glob));   // several ranks: the lanes contiguous, [lane][na_max]
+    NLG_TRY(regrow(&P.d_xa, P.na, &la2));
+    if (glob) {
+        // all-gathered aggregate residuals [rank][lane][na_max]: the lanes of a rank stay together in one all-gather
+        NLG_HIP(hipFree(P.d_rag));
+        NLG_HIP(hipMalloc(&P.d_rag, sizeof(double) * (size_t)P.ncols * nl));
+    }
+    NLG_CHECK(lv2 == P.lv && (la2 == P.la || glob), "pprec: inconsistent lane strides");
+    P.la_x = la2;
+    P.lanes_cap = nl;
+    return 0;
+}
+
 // Coarse part of M^-1 r on `st`: xc[v] = omega dinv[v] (R_1^T r)[v] and P.d_xa = aggregate-level solve; pprec_fine
-// adds the two while prolonging.
+// adds the two while prolonging.  nl > 1: the lanes of a block step in the same launches (r, flag and the fused PCG update of
+// lane v sit v * ld doubles behind the given pointers).
 int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double **xc, bool overlap,
-                 const nlg_pcg_upd *upd) {
+                 const nlg_pcg_upd *upd, int nl, int64_t ld) {
     const nlg_pcg_upd uu = upd ? *upd : nlg_pcg_upd{};
     double *rw = const_cast<double *>(r);   // written only when the PCG update rides along
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
+    NLG_TRY(pprec_reserve_lanes(m, nl));
     const int64_t E = m->E;
     const int nv = P.nvert;
     const double om = P.na == nv ? 0.0 : 0.7;   // exact coarse solve when every vertex is its own aggregate
     Hat hat;
     for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
+    NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
+    double *Wp = overlap ? P.d_W : (double *)nullptr;
+    const dim3 gq((unsigned)((E + 3) / 4), (unsigned)nl);
     if (m->dim == 3) {
-        NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
-        double *Wp = overlap ? P.d_W : (double *)nullptr;
-        const dim3 gq((unsigned)((E + 3) / 4));
         if (P.d_wslot && m->n2 == 6)
-            hipLaunchKernelGGL(k_q1_restrict_local3s<6>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu);
+            NLG_LAUNCH(k_q1_restrict_local3s<6>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu, ld, P.lt, P.lW);
         else if (P.d_wslot && m->n2 == 8)
-            hipLaunchKernelGGL(k_q1_restrict_local3s<8>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu);
+            NLG_LAUNCH(k_q1_restrict_local3s<8>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu, ld, P.lt, P.lW);
         else if (P.d_wslot && m->n2 == 10)
-            hipLaunchKernelGGL(k_q1_restrict_local3s<10>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu);
+            NLG_LAUNCH(k_q1_restrict_local3s<10>, gq, dim3(NT), 0, st, flag, E, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, (const int *)P.d_wslot, uu, ld, P.lt, P.lW);
         else
-            hipLaunchKernelGGL(k_q1_restrict_local<3>, gq, dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, uu);
+            NLG_LAUNCH(k_q1_restrict_local<3>, gq, dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, uu, ld, P.lt, P.lW);
     } else {
-        NLG_CHECK(!overlap || P.overlap, "pprec: the overlapping variant is not set up for this mesh");
-        hipLaunchKernelGGL(k_q1_restrict_local<2>, dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq,
-                           overlap ? P.d_W : (double *)nullptr, (const double *)P.d_wq, uu);
+        NLG_LAUNCH(k_q1_restrict_local<2>, gq, dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, uu, ld, P.lt, P.lW);
     }
-    hipLaunchKernelGGL(k_q1_gather, dim3((nv + NT - 1) / NT), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x);
-    hipLaunchKernelGGL(k_agg_restrict, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra);
+    NLG_LAUNCH(k_q1_gather, dim3((nv + NT - 1) / NT, nl), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x, ld, P.lt, P.lv);
+    NLG_LAUNCH(k_agg_restrict, dim3((P.na + 3) / 4, nl), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra, ld, P.lv, P.la);
     const double *ra = P.d_ra;
-    if (P.ncols != P.na) {   // several ranks: the aggregate level is global
+    int na_max = 0;
+    if (P.ncols != P.na) {   // several ranks: the aggregate level is global; ONE all-gather carries the lanes of every rank
         NLG_CHECK(st == m->ctx->stream, "pprec: the global aggregate level runs on the context's stream");
-        NLG_TRY(allgather_f64(m->ctx, P.d_ra, P.d_rag, P.na_max));
+        NLG_TRY(allgather_f64(m->ctx, P.d_ra, P.d_rag, (int64_t)P.na_max * nl));
         ra = P.d_rag;
+        na_max = nl > 1 ? P.na_max : 0;   // (one lane: the gathered array is the plain column vector)
     }
+    const dim3 gg((unsigned)((P.na + 3) / 4), (unsigned)nl);
     if (P.d_Ainv32)
-        hipLaunchKernelGGL(k_dense_gemv<float>, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.ncols, (const float *)P.d_Ainv32, ra, P.d_xa);
+        NLG_LAUNCH(k_dense_gemv<float>, gg, dim3(NT), 0, st, flag, P.na, P.ncols, (const float *)P.d_Ainv32, ra, P.d_xa, ld, P.ncols != P.na ? P.la_x : P.la, na_max, nl);
     else
-        hipLaunchKernelGGL(k_dense_gemv<double>, dim3((P.na + 3) / 4), dim3(NT), 0, st, flag, P.na, P.ncols, (const double *)P.d_Ainv, ra, P.d_xa);
+        NLG_LAUNCH(k_dense_gemv<double>, gg, dim3(NT), 0, st, flag, P.na, P.ncols, (const double *)P.d_Ainv, ra, P.d_xa, ld, P.ncols != P.na ? P.la_x : P.la, na_max, nl);
     NLG_HIP(hipGetLastError());
     *xc = P.d_x;   // the Jacobi term; pprec_fine adds xa[agg[v]] while prolonging
     return 0;
@@ -1769,30 +1867,47 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
 // ghost layers of face neighbours on other ranks: the copies of a face on a rank boundary are summed by the halo
 // exchange exactly as the pairs kernel sums the two local copies of an interior face (edge and corner slots of W
 // are never written and travel as zeros)
-static int overlap_halo(nlg_mesh *m, hipStream_t st, bool face_grouped) {
+static int overlap_halo(nlg_mesh *m, hipStream_t st, bool face_grouped, int nl) {
+    ++g_collectives;
     if (!m->halo.active) return 0;
     NLG_CHECK(st == m->ctx->stream, "pprec: the overlap exchange across ranks runs on the context's stream");
     double *f1[1] = {m->pprec.d_W};
-    return halo_exchange(m, f1, 1, face_grouped);
+    return halo_exchange(m, f1, 1, face_grouped, nl, m->pprec.lW);
 }
 
 // Fine part: z = sum_e R_e^T Etilde_e^-1 R_e r (+ R_1 xc when xc is given), launched on `st`.
 int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r, const double *xc, double *z,
-               double *rz_part, bool overlap) {
+               double *rz_part, bool overlap, int nl, int64_t ld) {
     nlg_pprec &P = m->pprec;
     NLG_CHECK(P.ready, "pprec: preconditioner not set up");
+    NLG_TRY(pprec_reserve_lanes(m, nl));
     const int64_t E = m->E;
     Hat hat;
     for (int k = 0; k < 12; ++k) hat.h1[k] = P.hat1[k];
     const int *vg = P.d_vg;
+    if (nl > 1 && !(overlap && m->dim == 3)) {
+        // kernels without the lane dimension (2-D, the variant without overlap): lane by lane, on the lane's copies of the scratch
+        NLG_CHECK(xc == nullptr || xc == P.d_x, "pprec_fine: foreign coarse vector with several lanes");
+        nlg_pprec keep = P;
+        int rc = 0;
+        for (int v = 0; v < nl && rc == 0; ++v) {
+            P.d_W = keep.d_W ? keep.d_W + v * keep.lW : nullptr;
+            P.d_xa = keep.d_xa + v * (keep.ncols != keep.na ? keep.la_x : keep.la);
+            rc = pprec_fine(m, st, flag ? flag + v * ld : nullptr, r + v * ld, xc ? keep.d_x + v * keep.lv : nullptr, z + v * ld,
+                            rz_part ? rz_part + v * ld : nullptr, overlap, 1, 0);
+        }
+        P.d_W = keep.d_W, P.d_xa = keep.d_xa;
+        return rc;
+    }
+    const int64_t la_x = P.ncols != P.na ? P.la_x : P.la;
     if (overlap && m->dim == 2) {
         NLG_CHECK(P.overlap, "pprec: the overlapping variant is not set up for this mesh");
         const unsigned gb = (unsigned)((E + 3) / 4);
         NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
-        NLG_TRY(overlap_halo(m, st, false));
+        NLG_TRY(overlap_halo(m, st, false, 1));
 #define FX2_CASE(N_)                                                                                                  \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_fdm_ext2<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
+        NLG_LAUNCH((k_fdm_ext2<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
         break;
         switch (m->n) {
             FX2_CASE(4) FX2_CASE(5) FX2_CASE(6) FX2_CASE(7) FX2_CASE(8)
@@ -1800,11 +1915,11 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         }
 #undef FX2_CASE
         NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
-        NLG_TRY(overlap_halo(m, st, false));
+        NLG_TRY(overlap_halo(m, st, false, 1));
         const unsigned gf = (unsigned)((E * m->np2 + NT - 1) / NT);
 #define FF2_CASE(N_)                                                                                                  \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_sch_finish2<N_>), dim3(gf), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
+        NLG_LAUNCH((k_sch_finish2<N_>), dim3(gf), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
         break;
         switch (m->n) {
             FF2_CASE(4) FF2_CASE(5) FF2_CASE(6) FF2_CASE(7) FF2_CASE(8)
@@ -1817,24 +1932,24 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
     if (overlap) {
         // pprec_coarse has packed the adjacent layers into P.d_W (same stream)
         NLG_CHECK(P.overlap && m->dim == 3, "pprec: the overlapping variant is not set up for this mesh");
-        const unsigned gb = (unsigned)((E + 3) / 4);
-        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
-        NLG_TRY(overlap_halo(m, st, true));
+        const dim3 gb((unsigned)((E + 3) / 4), (unsigned)nl);
+        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag, nl, P.lW, ld));
+        NLG_TRY(overlap_halo(m, st, true, nl));
 #define FX_CASE(N_)                                                                                                   \
     case N_: {                                                                                                        \
         constexpr int WPE_ = (N_ * N_ + 63) / 64;   /* one column per lane: 1 wave up to lx1 = 8, 2 at 9 / 10, 3 at 12 */ \
-        hipLaunchKernelGGL((k_fdm_ext<N_, 1, WPE_>), dim3((unsigned)E), dim3(64 * WPE_), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab); \
+        NLG_LAUNCH((k_fdm_ext<N_, 1, WPE_>), dim3((unsigned)E, (unsigned)nl), dim3(64 * WPE_), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab, ld, P.lW); \
     } break;
         switch (m->n) {
             FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(12)
             default: set_error("pprec: overlapping variant built for lx1 = 4..10 and 12, got %d", m->n); return 1;
         }
 #undef FX_CASE
-        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag));
-        NLG_TRY(overlap_halo(m, st, true));
+        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag, nl, P.lW, ld));
+        NLG_TRY(overlap_halo(m, st, true, nl));
 #define FF_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \
-        hipLaunchKernelGGL((k_sch_finish<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part, (const int *)P.d_wslot); \
+        NLG_LAUNCH((k_sch_finish<N_>), gb, dim3(NT), 0, st, flag, E, P.d_W, r, P.d_wq, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part, (const int *)P.d_wslot, ld, P.lW, P.lv, la_x); \
         break;
         switch (m->n) {
             FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10) FF_CASE(12)
@@ -1846,9 +1961,9 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
     }
 #define FDM_CASE(N_)                                                                                                  \
     if (m->dim == 3)                                                                                                  \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
+        NLG_LAUNCH((k_fdm<N_ - 2, 3>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part); \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part);
+        NLG_LAUNCH((k_fdm<N_ - 2, 2>), dim3((unsigned)((E + 3) / 4)), dim3(NT), 0, st, flag, E, P.d_S, P.d_invden, r, xc, P.d_xa, P.d_agg, vg, hat, z, rz_part);
     switch (m->n) {
         case 4: FDM_CASE(4); break;
         case 5: FDM_CASE(5); break;

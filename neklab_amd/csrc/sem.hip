@@ -374,8 +374,14 @@ __global__ void k_mul(double *y, const double *a, const double *b, int64_t n) {
 // DESIGN.md -- because there neighbouring pairs are 64 bytes apart; the check below falls back to the scalar path then.)
 template <int NF>
 __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const int *__restrict__ idx, int64_t ngroups,
-                                           int64_t npairs, int64_t nquads, F3 f, const double *__restrict__ gate) {
-    if (gate && gate[0] != 0.0) return;
+                                           int64_t npairs, int64_t nquads, F3 f, const double *__restrict__ gate, int64_t ld, int64_t ldg) {
+    // blockIdx.y = lane of a block step: its fields sit ld doubles, its gate ldg doubles behind lane 0's (internal.h kMaxLanes)
+    if (gate && gate[(int64_t)blockIdx.y * ldg] != 0.0) return;
+    {
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+#pragma unroll
+        for (int c = 0; c < NF; ++c) f.p[c] += lo;
+    }
     const int64_t t = blockIdx.x * (int64_t)NT + threadIdx.x;
     const int64_t np2 = npairs >> 1;
     if (t < np2) {
@@ -462,7 +468,9 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
 
 // w_c <- wt_c * w_c  (opbinv after dssum; also mask application)
 template <int NF>
-__global__ __launch_bounds__(NT) void k_colmul(F3 w, CF3 wt, int64_t n) {
+__global__ __launch_bounds__(NT) void k_colmul(F3 w, CF3 wt, int64_t n, int64_t ld = 0) {
+#pragma unroll
+    for (int c = 0; c < NF; ++c) w.p[c] += (int64_t)blockIdx.y * ld;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
 #pragma unroll
         for (int c = 0; c < NF; ++c) w.p[c][i] *= wt.p[c][i];
@@ -601,12 +609,24 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
                                                        const double *__restrict__ G4, const double *__restrict__ G5,
                                                        const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                        double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                       const double *__restrict__ done_p, const int *__restrict__ xptab) {
+                                                       const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld) {
     static_assert(N * N <= 64, "one lane per (i, j)");
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1;
     __shared__ double sD[N * N];
     __shared__ double sU[WPB][N * NQ], sR[WPB][N * NQ], sS[WPB][N * NQ];
     __shared__ double sred[WPB];
+    {   // blockIdx.y = lane of a block step (all per-lane arguments ld doubles apart, internal.h)
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (u.p[q]) u.p[q] += lo;
+            if (w.p[q]) w.p[q] += lo;
+            if (zf.p[q]) zf.p[q] += lo;
+        }
+        if (pw_part) pw_part += lo;
+        if (beta_p) beta_p += lo;
+        if (done_p) done_p += lo;
+    }
     if (done_p && done_p[0] != 0.0) return;   // the surrounding PCG has converged: nothing consumes w any more
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: element, field and every base pointer stay scalar
@@ -869,11 +889,23 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
                                                                         const double *__restrict__ G4, const double *__restrict__ G5,
                                                                         const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                                         double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab) {
+                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld) {
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((NS + 63) / 64) * 64, NWB = NTB / 64;
     __shared__ double sD[NS];
     __shared__ double mU[N * NQ], mR[N * NQ], mS[N * NQ];
     __shared__ double sred[NWB];
+    {
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (u.p[q]) u.p[q] += lo;
+            if (w.p[q]) w.p[q] += lo;
+            if (zf.p[q]) zf.p[q] += lo;
+        }
+        if (pw_part) pw_part += lo;
+        if (beta_p) beta_p += lo;
+        if (done_p) done_p += lo;
+    }
     if (done_p && done_p[0] != 0.0) return;
     const int tid = threadIdx.x;
     for (int p = tid; p < NS; p += NTB) sD[p] = Dg[p];
@@ -2253,9 +2285,11 @@ __global__ void k_max_final(const double *partial, int n, double *out) {
     out[0] = m;
 }
 
-// sum of a pressure-mesh vector (ortho)
-__global__ __launch_bounds__(NT) void k_sum_partial(const double *x, int64_t n, double *partial) {
+// sum of a pressure-mesh vector (ortho).  blockIdx.y = lane of a block step: x is ld doubles, the partial sums NPART doubles apart.
+constexpr int NPART = 256;
+__global__ __launch_bounds__(NT) void k_sum_partial(const double *x, int64_t n, double *partial, int64_t ld) {
     __shared__ double sm[NT];
+    x += (int64_t)blockIdx.y * ld, partial += (int64_t)blockIdx.y * NPART;
     double a = 0.0;
     for (int64_t q = blockIdx.x * (int64_t)NT + threadIdx.x; q < n; q += (int64_t)gridDim.x * NT) a += x[q];
     sm[threadIdx.x] = a;
@@ -2266,14 +2300,38 @@ __global__ __launch_bounds__(NT) void k_sum_partial(const double *x, int64_t n, 
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
-__global__ void k_sum_final(const double *partial, int n, double *out) {
-    double m = 0.0;
-    for (int i = 0; i < n; ++i) m += partial[i];
-    out[0] = m;
+// second stage, one block per lane: out[lane] = sum of the lane's NPART partials (fixed tree: every rank, every run the same)
+__global__ __launch_bounds__(NT) void k_sum_final(const double *partial, int n, double *out) {
+    __shared__ double sm[NT];
+    partial += (int64_t)blockIdx.x * NPART;
+    sm[threadIdx.x] = (int)threadIdx.x < n ? partial[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
-__global__ void k_sub_mean(double *x, int64_t n, const double *sum, double inv_count) {
-    const double mean = sum[0] * inv_count;
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) x[q] -= mean;
+// x -= mean.  sum != null: the (all-reduced) sums, one per lane; otherwise every block re-sums the lane's partials itself with the
+// tree of k_sum_final (one launch less on a single rank; all blocks obtain the same bits)
+__global__ __launch_bounds__(NT) void k_sub_mean(double *x, int64_t n, const double *sum, const double *partial, int npart, double inv_count, int64_t ld) {
+    __shared__ double sm[NT];
+    x += (int64_t)blockIdx.y * ld;
+    double tot;
+    if (sum) {
+        tot = sum[blockIdx.y];
+    } else {
+        partial += (int64_t)blockIdx.y * NPART;
+        sm[threadIdx.x] = (int)threadIdx.x < npart ? partial[threadIdx.x] : 0.0;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            __syncthreads();
+        }
+        tot = sm[0];
+    }
+    const double mean = tot * inv_count;
+    for (int64_t q = blockIdx.x * (int64_t)NT + threadIdx.x; q < n; q += (int64_t)gridDim.x * NT) x[q] -= mean;
 }
 
 // nek_drand noise (reference: real_vectors.f90:52-98 + neklab_vectors.f90:305-314), counter-based RNG
@@ -2367,22 +2425,23 @@ double *sem_scratch2(nlg_mesh *m, int i) {
 }
 
 static int gs_launch(nlg_mesh *m, const int *goff, const int *gidx, int64_t ngroups, int64_t npairs, int64_t nquads, double *const *fields,
-                     int nf, const double *gate) {
+                     int nf, const double *gate, int nl = 1, int64_t ld = 0, int64_t ldg = 0) {
     if (ngroups == 0) return 0;
     F3 f = {{fields[0], nf > 1 ? fields[1] : nullptr, nf > 2 ? fields[2] : nullptr}};
-    const int grid = (int)((ngroups + NT - 1) / NT);
+    const dim3 grid((unsigned)((ngroups + NT - 1) / NT), (unsigned)nl);
     if (nf == 1)
-        hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate);
+        NLG_LAUNCH(k_gs<1>, grid, dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate, ld, ldg);
     else if (nf == 2)
-        hipLaunchKernelGGL(k_gs<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate);
+        NLG_LAUNCH(k_gs<2>, grid, dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate, ld, ldg);
     else
-        hipLaunchKernelGGL(k_gs<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate);
+        NLG_LAUNCH(k_gs<3>, grid, dim3(NT), 0, m->ctx->stream, goff, gidx, ngroups, npairs, nquads, f, gate, ld, ldg);
     NLG_HIP(hipGetLastError());
     return 0;
 }
 
-int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int layout) {
+int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int layout, int nl, int64_t ld, int64_t ldg) {
     if (m->gs.ngroups == 0 && !m->halo.active) return 0;
+    ++g_collectives;   // one halo exchange (carrying all lanes) when the mesh is partitioned
     // (the timed class "gs" is the dim-field kernel of the two PCGs; scalar-field calls go to "vec_ops" so that the
     //  class average is the duration of ONE kernel with ONE algorithmic byte count)
     ProfScope ps(m->ctx, nf == m->dim ? P_GS : P_VECOPS);
@@ -2397,18 +2456,20 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int l
         // several ranks: first the groups that hold a dof another rank shares, so that their sums can be packed and sent,
         // then all other groups (disjoint dofs) while the exchange is under way, then the received sums (halo.hip)
         const nlg_gs_tab &th = m->gs.tab_halo[layout], &tr = m->gs.tab_rest[layout];
-        NLG_TRY(gs_launch(m, th.d_off, th.d_idx, th.ngroups, th.npairs, th.nquads, fields, nf, gate));
-        NLG_TRY(halo_begin(m, fields, nf, layout));
-        NLG_TRY(gs_launch(m, tr.d_off, tr.d_idx, tr.ngroups, tr.npairs, tr.nquads, fields, nf, gate));
-        return halo_finish(m, fields, nf, layout);
+        NLG_TRY(gs_launch(m, th.d_off, th.d_idx, th.ngroups, th.npairs, th.nquads, fields, nf, gate, nl, ld, ldg));
+        NLG_TRY(halo_begin(m, fields, nf, layout, nl, ld));
+        NLG_TRY(gs_launch(m, tr.d_off, tr.d_idx, tr.ngroups, tr.npairs, tr.nquads, fields, nf, gate, nl, ld, ldg));
+        return halo_finish(m, fields, nf, layout, nl, ld);
     }
-    NLG_TRY(gs_launch(m, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, fields, nf, gate));
-    return halo_exchange(m, fields, nf, layout);   // no-op on a single rank
+    NLG_TRY(gs_launch(m, goff, gidx, m->gs.ngroups, m->gs.npairs, m->gs.nquads, fields, nf, gate, nl, ld, ldg));
+    return halo_exchange(m, fields, nf, layout, nl, ld);   // no-op on a single rank
 }
 
 // natural <-> x-planes-first, out of place, one thread per point
 template <int NF, bool TO>
-__global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__restrict__ slot, CF3 src, F3 dst) {
+__global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__restrict__ slot, CF3 src, F3 dst, int64_t ld) {
+#pragma unroll
+    for (int c = 0; c < NF; ++c) src.p[c] += (int64_t)blockIdx.y * ld, dst.p[c] += (int64_t)blockIdx.y * ld;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const int64_t e = i / np;
         const int64_t q = e * np + slot[(int)(i - e * np)];
@@ -2422,17 +2483,17 @@ __global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__
     }
 }
 
-static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, bool to) {
+static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, bool to, int nl, int64_t ld) {
     NLG_CHECK(m->d_slot_xp && nf >= 1 && nf <= 3, "sem_to_xp: no x-planes-first table (3-D only) or bad field count");
     CF3 a = {{src[0], nf > 1 ? src[1] : nullptr, nf > 2 ? src[2] : nullptr}};
     F3 b = {{dst[0], nf > 1 ? dst[1] : nullptr, nf > 2 ? dst[2] : nullptr}};
-    const dim3 g(grid_for(m->lvn)), t(NT);
+    const dim3 g(grid_for(m->lvn), nl), t(NT);
     hipStream_t st = m->ctx->stream;
 #define XPL(NF_)                                                                                               \
     if (to)                                                                                                    \
-        hipLaunchKernelGGL((k_xp_perm<NF_, true>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b);  \
+        NLG_LAUNCH((k_xp_perm<NF_, true>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b, ld);  \
     else                                                                                                       \
-        hipLaunchKernelGGL((k_xp_perm<NF_, false>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b);
+        NLG_LAUNCH((k_xp_perm<NF_, false>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b, ld);
     if (nf == 1) {
         XPL(1)
     } else if (nf == 2) {
@@ -2444,8 +2505,8 @@ static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, 
     NLG_HIP(hipGetLastError());
     return 0;
 }
-int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf) { return xp_perm(m, src, dst, nf, true); }
-int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf) { return xp_perm(m, src, dst, nf, false); }
+int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl, int64_t ld) { return xp_perm(m, src, dst, nf, true, nl, ld); }
+int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl, int64_t ld) { return xp_perm(m, src, dst, nf, false, nl, ld); }
 
 // (element, field) slots per block of k_axhelm3: bounded by 512 threads and by 64 KB of dynamic LDS
 static int axhelm3_nslot(int N) {
@@ -2458,23 +2519,23 @@ static int axhelm3_nslot(int N) {
     return nslot;
 }
 
-int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate) {
+int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate, int nl, int64_t ld, int64_t ldg) {
     if (m->gs.npairs == 0) return 0;
     F3 f = {{w, nullptr, nullptr}};
-    const int grid = (int)((m->gs.npairs + NT - 1) / NT);
-    hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.npairs,
-                       m->gs.npairs, (int64_t)0, f, gate);
+    const dim3 grid((unsigned)((m->gs.npairs + NT - 1) / NT), (unsigned)nl);
+    NLG_LAUNCH(k_gs<1>, grid, dim3(NT), 0, m->ctx->stream, m->gs.d_offsets, m->gs.d_indices, m->gs.npairs,
+                       m->gs.npairs, (int64_t)0, f, gate, ld, ldg);
     NLG_HIP(hipGetLastError());
     return 0;
 }
 
-int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate) {
+int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate, int nl, int64_t ld, int64_t ldg) {
     NLG_CHECK(m->gs.d_indices_fg, "sem_gs_pairs_fg: no face-grouped tables (3-D only)");
     if (m->gs.npairs == 0) return 0;
     F3 f = {{w, nullptr, nullptr}};
-    const int grid = (int)((m->gs.npairs + NT - 1) / NT);
-    hipLaunchKernelGGL(k_gs<1>, dim3(grid), dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.npairs,
-                       m->gs.npairs, (int64_t)0, f, gate);
+    const dim3 grid((unsigned)((m->gs.npairs + NT - 1) / NT), (unsigned)nl);
+    NLG_LAUNCH(k_gs<1>, grid, dim3(NT), 0, m->ctx->stream, m->gs.d_offsets_fg, m->gs.d_indices_fg, m->gs.npairs,
+                       m->gs.npairs, (int64_t)0, f, gate, ld, ldg);
     NLG_HIP(hipGetLastError());
     return 0;
 }
@@ -2491,8 +2552,19 @@ int sem_axhelm_blocks(nlg_mesh *m, int nf) {
 }
 
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part,
-               double *const *zf, const double *beta_p, const double *done_p, bool xp) {
+               double *const *zf, const double *beta_p, const double *done_p, bool xp, int nl, int64_t ld) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
+    static const bool use_cube0 = getenv("NLG_AXHELM_CUBE") && atoi(getenv("NLG_AXHELM_CUBE")) != 0;
+    if (nl > 1 && (m->dim == 2 || (m->n > 8 && use_cube0))) {
+        // kernels without the lane dimension (2-D, the LDS-cube variant): one launch per lane at the lane's offsets
+        for (int v = 0; v < nl; ++v) {
+            double *uu[3], *ww[3], *zz[3];
+            for (int c = 0; c < nf; ++c) uu[c] = u[c] + v * ld, ww[c] = w[c] + v * ld, zz[c] = zf ? zf[c] + v * ld : nullptr;
+            NLG_TRY(sem_axhelm(m, uu, ww, nf, h1, h2, pw_part ? pw_part + v * ld : nullptr, zf ? zz : nullptr, beta_p ? beta_p + v * ld : nullptr,
+                               done_p ? done_p + v * ld : nullptr, xp, 1, 0));
+        }
+        return 0;
+    }
     NLG_CHECK(!xp || (m->dim == 3 && m->d_slot_xp), "sem_axhelm: the slab-permuted layout exists in 3-D only");
     ProfScope ps(m->ctx, P_AXHELM);
     CF3 cu = {{u[0], nf > 1 ? u[1] : nullptr, nf > 2 ? u[2] : nullptr}};
@@ -2510,21 +2582,21 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         const size_t lds = sizeof(double) * (size_t)(N_ * N_ + nslot * 4 * N_ * N_ * N_);                             \
         if constexpr (N_ <= 8) {                                                                                      \
             if (xp)                                                                                                   \
-            hipLaunchKernelGGL((k_axhelm3r<N_, 4, true>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
-                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp); \
+            NLG_LAUNCH((k_axhelm3r<N_, 4, true>), dim3(grid, nl), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
             else                                                                                                      \
-            hipLaunchKernelGGL((k_axhelm3r<N_, 4, false>), dim3(grid), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
-                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr); \
+            NLG_LAUNCH((k_axhelm3r<N_, 4, false>), dim3(grid, nl), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); \
         } else if (use_cube)                                                                                          \
-        hipLaunchKernelGGL((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
+        NLG_LAUNCH((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
                            m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
         else                                                                                                          \
         { if (xp)                                                                                                     \
-        hipLaunchKernelGGL((k_axhelm3c<N_, true>), dim3((unsigned)tot), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp); \
+        NLG_LAUNCH((k_axhelm3c<N_, true>), dim3((unsigned)tot, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
         else                                                                                                          \
-        hipLaunchKernelGGL((k_axhelm3c<N_, false>), dim3((unsigned)tot), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr); } \
+        NLG_LAUNCH((k_axhelm3c<N_, false>), dim3((unsigned)tot, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); } \
     }
         NLG_FOR_N(AX3)
 #undef AX3
@@ -2534,13 +2606,13 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         constexpr int EPB = (NT / (N_ * N_)) > 0 ? (NT / (N_ * N_)) : 1;                                              \
         const int grid = (int)((m->E + EPB - 1) / EPB);                                                               \
         if (nf == 1)                                                                                                  \
-            hipLaunchKernelGGL((k_axhelm2<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+            NLG_LAUNCH((k_axhelm2<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
                                m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
         else if (nf == 2)                                                                                             \
-            hipLaunchKernelGGL((k_axhelm2<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+            NLG_LAUNCH((k_axhelm2<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
                                m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_axhelm2<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
+            NLG_LAUNCH((k_axhelm2<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
                                m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
     }
         NLG_FOR_N(AX2)
@@ -2574,10 +2646,10 @@ int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const
     const int *tab = xp ? (const int *)m->d_slot_xp : nullptr;
 #define AXB(N_, NL_)                                                                                                         \
     if (xp)                                                                                                                  \
-        hipLaunchKernelGGL((k_axhelm3rb<N_, NL_, true>), dim3((unsigned)m->E), dim3(64 * 3 * NL_), 0, s, m->E, m->d_D, m->d_G[0], m->d_G[1], \
+        NLG_LAUNCH((k_axhelm3rb<N_, NL_, true>), dim3((unsigned)m->E), dim3(64 * 3 * NL_), 0, s, m->E, m->d_D, m->d_G[0], m->d_G[1], \
                            m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, L, h1, h2, tab);                          \
     else                                                                                                                     \
-        hipLaunchKernelGGL((k_axhelm3rb<N_, NL_, false>), dim3((unsigned)m->E), dim3(64 * 3 * NL_), 0, s, m->E, m->d_D, m->d_G[0], m->d_G[1], \
+        NLG_LAUNCH((k_axhelm3rb<N_, NL_, false>), dim3((unsigned)m->E), dim3(64 * 3 * NL_), 0, s, m->E, m->d_D, m->d_G[0], m->d_G[1], \
                            m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, L, h1, h2, tab);
 #define AXBN(N_)                        \
     case N_:                            \
@@ -2600,7 +2672,7 @@ int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const
 }
 
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2) {
-    hipLaunchKernelGGL(k_helm_diag, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, m->dim, m->n, m->E, m->d_D,
+    NLG_LAUNCH(k_helm_diag, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, m->dim, m->n, m->E, m->d_D,
                        m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, out, h1, h2);
     NLG_HIP(hipGetLastError());
     return 0;
@@ -2673,27 +2745,27 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped && !(N_ == 8 && n8new))                                                            \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
+            NLG_LAUNCH((k_opgradt3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else if (N_ <= 8 && !(N_ == 8 && n8new))                                                                       \
-            hipLaunchKernelGGL((k_opgradt3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
+            NLG_LAUNCH((k_opgradt3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, pl, wl, gl, nl);   \
         else if (!old_big && face_grouped)                                                                             \
             {                                                                                                          \
                 if (upd)                                                                                               \
-                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 && N_ <= 10 ? N_ : 9), true, ML_, true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);    \
+                    NLG_LAUNCH((k_opgradt3n<(N_ >= 8 && N_ <= 10 ? N_ : 9), true, ML_, true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);    \
                 else                                                                                                   \
-                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_, false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, NoPUpd{});    \
+                    NLG_LAUNCH((k_opgradt3n<(N_ >= 8 ? N_ : 9), true, ML_, false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, NoPUpd{});    \
             }                                                                                                          \
         else if (!old_big)                                                                                             \
             {                                                                                                          \
                 if (upd)                                                                                               \
-                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 && N_ <= 10 ? N_ : 9), false, ML_, true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);   \
+                    NLG_LAUNCH((k_opgradt3n<(N_ >= 8 && N_ <= 10 ? N_ : 9), false, ML_, true>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, pu);   \
                 else                                                                                                   \
-                    hipLaunchKernelGGL((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_, false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, NoPUpd{});   \
+                    NLG_LAUNCH((k_opgradt3n<(N_ >= 8 ? N_ : 9), false, ML_, false>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, pl, wl, gl, nl, NoPUpd{});   \
             }                                                                                                          \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
+            NLG_LAUNCH((k_opgradt3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);    \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opgradt3<N_, 1, false, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);   \
+            NLG_LAUNCH((k_opgradt3<N_, 1, false, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, pl, wl, gl, nl);   \
     }
 #define GT3(N_)           \
     if (nl == 1)          \
@@ -2710,7 +2782,7 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
 #define GT2(N_)                                                                                              \
     {                                                                                                        \
         constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                         \
-        hipLaunchKernelGGL((k_opgradt2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
+        NLG_LAUNCH((k_opgradt2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
                            m->d_I12t, m->d_D12t, g, pv, cw);                                                 \
     }
             NLG_FOR_N(GT2)
@@ -2761,17 +2833,17 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
         PMats<N_> M;                                                                                                   \
         fill_pmats<N_>(m, M);                                                                                          \
         if (N_ <= 8 && face_grouped && !(N_ == 8 && n8new))                                                            \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            NLG_LAUNCH((k_opdiv3<N_, 3, true, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (N_ <= 8 && !(N_ == 8 && n8new))                                                                       \
-            hipLaunchKernelGGL((k_opdiv3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            NLG_LAUNCH((k_opdiv3<N_, 3, false, ML_>), dim3((unsigned)m->E), dim3(NT), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (!old_big && face_grouped)                                                                             \
-            hipLaunchKernelGGL((k_opdiv3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            NLG_LAUNCH((k_opdiv3n<(N_ >= 8 ? N_ : 9), true, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else if (!old_big)                                                                                             \
-            hipLaunchKernelGGL((k_opdiv3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            NLG_LAUNCH((k_opdiv3n<(N_ >= 8 ? N_ : 9), false, ML_>), dim3((unsigned)m->E), dim3(PBlockN<N_>::NTB), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, ul, wt, ol, scale, dl, pl, gl, nl); \
         else if (face_grouped)                                                                                         \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
+            NLG_LAUNCH((k_opdiv3<N_, 1, true, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_opdiv3<N_, 1, false, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
+            NLG_LAUNCH((k_opdiv3<N_, 1, false, ML_>), dim3((unsigned)m->E), dim3(PBlock<N_, 1>::NTB), 0, s, m->E, M, g, ul, wt, ol, scale, dl, pl, gl, nl); \
     }
 #define DV3(N_)           \
     if (nl == 1)          \
@@ -2789,7 +2861,7 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
 #define DV2(N_)                                                                                            \
     {                                                                                                      \
         constexpr int EPB = NT / (N_ * N_) > 0 ? NT / (N_ * N_) : 1;                                       \
-        hipLaunchKernelGGL((k_opdiv2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
+        NLG_LAUNCH((k_opdiv2<N_>), dim3((unsigned)((m->E + EPB - 1) / EPB)), dim3(NT), 0, s, m->E, \
                            m->d_I12, m->d_D12, g, cu, wt, ov, scale, dv, pv, gv);                          \
     }
             NLG_FOR_N(DV2)
@@ -2800,15 +2872,15 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
     return 0;
 }
 
-int sem_opbinv(nlg_mesh *m, double *const *w) {
-    NLG_TRY(sem_gs(m, w, m->dim));
+int sem_opbinv(nlg_mesh *m, double *const *w, int nl, int64_t ld) {
+    NLG_TRY(sem_gs(m, w, m->dim, nullptr, LAYOUT_NAT, nl, ld, 0));
     ProfScope ps(m->ctx, P_COLMUL);
     F3 cw = {{w[0], w[1], m->dim == 3 ? w[2] : nullptr}};
     CF3 wt = {{m->d_mbinv[0], m->d_mbinv[1], m->d_mbinv[2]}};
     if (m->dim == 3)
-        hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn);
+        NLG_LAUNCH(k_colmul<3>, dim3(grid_for(m->lvn), nl), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn, ld);
     else
-        hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn);
+        NLG_LAUNCH(k_colmul<2>, dim3(grid_for(m->lvn), nl), dim3(NT), 0, m->ctx->stream, cw, wt, m->lvn, ld);
     NLG_HIP(hipGetLastError());
     return 0;
 }
@@ -2818,17 +2890,31 @@ int sem_opbinv(nlg_mesh *m, double *const *w) {
 int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate,
                       const nlg_pupd *upd) {
     const bool fg = m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg);
+    // the intermediate velocity-mesh fields of all lanes in ONE allocation at a constant stride, so that their gather-scatter
+    // (and its halo exchange) is one launch with gridDim.y = lanes
+    const int64_t ldw = 3 * m->lvs;
+    if (!m->d_wlanes) {
+        NLG_HIP(hipMalloc(&m->d_wlanes, sizeof(double) * (size_t)(kMaxLanes * ldw)));
+        NLG_HIP(hipMemsetAsync(m->d_wlanes, 0, sizeof(double) * (size_t)(kMaxLanes * ldw), m->ctx->stream));
+    }
     double *w[4][3];
     double *const *wl[4];
     for (int v = 0; v < nl; ++v) {
-        for (int c = 0; c < 3; ++c) w[v][c] = c < m->dim ? sem_scratch1(m, 8 + 3 * v + c) : nullptr;
-        NLG_CHECK(w[v][0] && w[v][1], "sem_cdabdtp: scratch allocation failed");
+        for (int c = 0; c < 3; ++c) w[v][c] = c < m->dim ? m->d_wlanes + v * ldw + c * m->lvs : nullptr;
         wl[v] = w[v];
     }
     NLG_TRY(sem_opgradt_lanes(m, nl, p, wl, fg, gate, upd));
-    for (int v = 0; v < nl; ++v) {
-        const double *gv = gate ? gate[v] : nullptr;
-        NLG_TRY(sem_gs(m, w[v], m->dim, gv, fg ? LAYOUT_FG : LAYOUT_NAT));
+    // the gates of the lanes are the done flags of their solver scalars: at a constant stride when the lanes share a slab
+    bool strided = true;
+    int64_t ldg = 0;
+    if (gate && nl > 1) {
+        ldg = gate[1] - gate[0];
+        for (int v = 1; v < nl; ++v) strided = strided && gate[v] && (gate[v] - gate[0]) == v * ldg;
+    }
+    if (strided) {
+        NLG_TRY(sem_gs(m, w[0], m->dim, gate ? gate[0] : nullptr, fg ? LAYOUT_FG : LAYOUT_NAT, nl, ldw, ldg));
+    } else {
+        for (int v = 0; v < nl; ++v) NLG_TRY(sem_gs(m, w[v], m->dim, gate ? gate[v] : nullptr, fg ? LAYOUT_FG : LAYOUT_NAT));
     }
     return sem_opdiv_lanes(m, nl, wl, out, 1.0, fg ? m->d_mbinv_fg : m->d_mbinv, fg, p, pw_part, gate);
 }
@@ -2850,16 +2936,21 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, cons
     return 0;
 }
 
-int sem_ortho(nlg_mesh *m, double *p) {
+int sem_ortho(nlg_mesh *m, double *p, int nl, int64_t ld) {
     if (m->has_outflow) return 0;
     nlg_ctx *ctx = m->ctx;
-    const int nb = 256;
-    hipLaunchKernelGGL(k_sum_partial, dim3(nb), dim3(NT), 0, ctx->stream, p, m->lpn, ctx->d_partial);
-    double *d_sum = ctx->d_scalars + 4000;
-    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(1), 0, ctx->stream, ctx->d_partial, nb, d_sum);
-    NLG_TRY(allreduce_sum(ctx, d_sum, 1));
-    hipLaunchKernelGGL(k_sub_mean, dim3(grid_for(m->lpn)), dim3(NT), 0, ctx->stream, p, m->lpn, d_sum,
-                       1.0 / (double)m->lpn_global);
+    NLG_CHECK(nl >= 1 && nl <= kMaxLanes, "sem_ortho: %d lanes", nl);
+    NLG_LAUNCH(k_sum_partial, dim3(NPART, nl), dim3(NT), 0, ctx->stream, p, m->lpn, ctx->d_partial, ld);
+    if (ctx->distributed()) {
+        double *d_sum = ctx->d_scalars + 4000;
+        NLG_LAUNCH(k_sum_final, dim3(nl), dim3(NT), 0, ctx->stream, ctx->d_partial, NPART, d_sum);
+        NLG_TRY(allreduce_sum(ctx, d_sum, nl));
+        NLG_LAUNCH(k_sub_mean, dim3(grid_for(m->lpn), nl), dim3(NT), 0, ctx->stream, p, m->lpn, (const double *)d_sum, (const double *)nullptr, 0,
+                   1.0 / (double)m->lpn_global, ld);
+    } else {
+        NLG_LAUNCH(k_sub_mean, dim3(grid_for(m->lpn), nl), dim3(NT), 0, ctx->stream, p, m->lpn, (const double *)nullptr, (const double *)ctx->d_partial,
+                   NPART, 1.0 / (double)m->lpn_global, ld);
+    }
     NLG_HIP(hipGetLastError());
     return 0;
 }
@@ -2870,10 +2961,10 @@ int sem_cfl(nlg_mesh *m, double *const *U, double dt, double *cfl_host) {
     for (int q = 0; q < 9; ++q) r.p[q] = m->d_rst[q];
     CF3 cu = {{U[0], U[1], m->dim == 3 ? U[2] : nullptr}};
     const int nb = 256;
-    hipLaunchKernelGGL(k_cfl, dim3(nb), dim3(NT), 0, ctx->stream, m->dim, m->n, m->E, r, m->d_jac, m->d_rdr, cu, dt,
+    NLG_LAUNCH(k_cfl, dim3(nb), dim3(NT), 0, ctx->stream, m->dim, m->n, m->E, r, m->d_jac, m->d_rdr, cu, dt,
                        ctx->d_partial);
     double *d_out = ctx->d_scalars + 4001;
-    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(1), 0, ctx->stream, ctx->d_partial, nb, d_out);
+    NLG_LAUNCH(k_max_final, dim3(1), dim3(1), 0, ctx->stream, ctx->d_partial, nb, d_out);
     NLG_HIP(hipGetLastError());
     NLG_TRY(allreduce_max(ctx, d_out, 1));
     return scalars_to_host(ctx, 4001, 1, cfl_host);
@@ -2884,7 +2975,7 @@ int sem_tensor(nlg_mesh *m, const double *in, double *out, int nin, int nout, co
                const double *Mz, const double *wt) {
     const int nmax = std::max(nin, nout);
     const size_t cap = (size_t)nmax * nmax * (m->dim == 3 ? nmax : 1);
-    hipLaunchKernelGGL(k_tensor_generic, dim3((unsigned)m->E), dim3(NT), 2 * cap * sizeof(double), m->ctx->stream, in, out,
+    NLG_LAUNCH(k_tensor_generic, dim3((unsigned)m->E), dim3(NT), 2 * cap * sizeof(double), m->ctx->stream, in, out,
                        m->dim, nin, nout, Mx, My, Mz, wt, m->E);
     NLG_HIP(hipGetLastError());
     return 0;
@@ -2904,15 +2995,15 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
         double *du[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), sem_scratchd(m, 5)};
         NLG_CHECK(ufb[0] && ufb[1] && ufb[2] && du[0] && du[1] && du[2], "sem_conv_setup: scratch allocation failed");
         for (int i = 0; i < 3; ++i) {
-            hipLaunchKernelGGL((k_interp4_mfma<8, 12>), dim3((unsigned)m->E), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd,
+            NLG_LAUNCH((k_interp4_mfma<8, 12>), dim3((unsigned)m->E), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd,
                                (const double *)m->d_DJd, (const double *)U[i], ufb[i], du[0], du[1], du[2]);
             CF3 dd = {{du[0], du[1], du[2]}};
             F3 gu = {{GU[i * 3 + 0], GU[i * 3 + 1], GU[i * 3 + 2]}};
-            hipLaunchKernelGGL(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, dd, gu);
+            NLG_LAUNCH(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, dd, gu);
         }
         CF3 uf = {{ufb[0], ufb[1], ufb[2]}};
         F3 ur = {{Ur[0], Ur[1], Ur[2]}};
-        hipLaunchKernelGGL(k_conv_ur, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, uf, ur);
+        NLG_LAUNCH(k_conv_ur, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, uf, ur);
         NLG_HIP(hipGetLastError());
         return 0;
     }
@@ -2922,7 +3013,7 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
     {
         CF3 uf = {{t[0], t[1], t[2]}};
         F3 ur = {{Ur[0], Ur[1], dim == 3 ? Ur[2] : nullptr}};
-        hipLaunchKernelGGL(k_conv_ur, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, uf, ur);
+        NLG_LAUNCH(k_conv_ur, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, uf, ur);
     }
     for (int i = 0; i < dim; ++i) {
         for (int j = 0; j < dim; ++j)
@@ -2930,7 +3021,7 @@ int sem_conv_setup(nlg_mesh *m, double *const *U, double **Ur, double **GU) {
                                j == 2 ? m->d_DJd : m->d_Jd, nullptr));
         CF3 du = {{t[0], t[1], t[2]}};
         F3 gu = {{GU[i * dim + 0], GU[i * dim + 1], dim == 3 ? GU[i * dim + 2] : nullptr}};
-        hipLaunchKernelGGL(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, du, gu);
+        NLG_LAUNCH(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, du, gu);
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -2949,7 +3040,7 @@ int sem_conv_scalar_setup(nlg_mesh *m, const double *Theta, double **GT) {
                            j == 2 ? m->d_DJd : m->d_Jd, nullptr));
     CF3 du = {{t[0], t[1], t[2]}};
     F3 gt = {{GT[0], GT[1], dim == 3 ? GT[2] : nullptr}};
-    hipLaunchKernelGGL(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, du, gt);
+    NLG_LAUNCH(k_conv_gu, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, rd, du, gt);
     NLG_HIP(hipGetLastError());
     return 0;
 }
@@ -2970,9 +3061,9 @@ int sem_scalar_grad_apply(nlg_mesh *m, double *const *GT, const double *theta, d
     NLG_CHECK(tf && prod && back, "sem_scalar_grad_apply: scratch allocation failed");
     NLG_TRY(sem_tensor(m, theta, tf, m->n, m->nd, m->d_Jd, m->d_Jd, m->d_Jd, nullptr));
     for (int i = 0; i < dim; ++i) {
-        hipLaunchKernelGGL(k_mul_fine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, m->lfn, (const double *)tf, (const double *)GT[i], prod);
+        NLG_LAUNCH(k_mul_fine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, m->lfn, (const double *)tf, (const double *)GT[i], prod);
         NLG_TRY(sem_tensor(m, prod, back, m->nd, m->n, m->d_Jdt, m->d_Jdt, m->d_Jdt, nullptr));
-        hipLaunchKernelGGL(k_axpy_field, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, m->lvn, out[i], (const double *)back, sgn);
+        NLG_LAUNCH(k_axpy_field, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, m->lvn, out[i], (const double *)back, sgn);
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -2994,9 +3085,9 @@ int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, dou
     CF3 cdt = {{dt[0], dt[1], dt[2]}}, cuf = {{uf[0], uf[1], uf[2]}};
     CF3 cgt = {{GT[0], GT[1], dim == 3 ? GT[2] : nullptr}};
     if (adjoint) {
-        hipLaunchKernelGGL(k_conv_combine_adj, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdt, acc);
+        NLG_LAUNCH(k_conv_combine_adj, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdt, acc);
     } else {
-        hipLaunchKernelGGL(k_conv_combine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdt, cuf, cgt, 1.0, acc);
+        NLG_LAUNCH(k_conv_combine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdt, cuf, cgt, 1.0, acc);
     }
     NLG_TRY(sem_tensor(m, acc, out, m->nd, m->n, m->d_Jdt, m->d_Jdt, m->d_Jdt, nullptr));
     NLG_HIP(hipGetLastError());
@@ -3031,10 +3122,10 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
         for (int q = 0; q < 9; ++q) cg.p[q] = GU[q];
 #define CV3(N_)                                                                                                       \
     if (nl == 1)                                                                                                      \
-        hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false, false>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
+        NLG_LAUNCH((k_conv3<N_, (3 * N_) / 2, NT, true, false, false>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
                            (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);          \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_conv3<N_, (3 * N_) / 2, NT, true, false, true>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
+        NLG_LAUNCH((k_conv3<N_, (3 * N_) / 2, NT, true, false, true>), dim3((unsigned)m->E), dim3(NT), 0, m->ctx->stream, m->E, \
                            (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);
 #define CV3D(N_, NTC_, ULDS_)                                                                                          \
     {                                                                                                                  \
@@ -3046,7 +3137,7 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_conv3<N_, ND_, NTC_, ULDS_, true>), dim3((unsigned)m->E), dim3(NTC_), lds, m->ctx->stream, m->E, \
+        NLG_LAUNCH((k_conv3<N_, ND_, NTC_, ULDS_, true>), dim3((unsigned)m->E), dim3(NTC_), lds, m->ctx->stream, m->E, \
                            (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);          \
     }
         switch (m->n) {
@@ -3086,7 +3177,7 @@ int sem_conv_apply_generic(nlg_mesh *m, double *const *Ur, double *const *GU, do
         for (int mm = 0; mm < 3; ++mm) gsel.p[mm] = nullptr;
         // direct: GU[i][m] ; adjoint: GU[m][i]
         for (int mm = 0; mm < dim; ++mm) gsel.p[mm] = adjoint ? GU[mm * dim + i] : GU[i * dim + mm];
-        hipLaunchKernelGGL(k_conv_combine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdu, cuf,
+        NLG_LAUNCH(k_conv_combine, dim3(grid_for(m->lfn)), dim3(NT), 0, m->ctx->stream, dim, m->lfn, cur, cdu, cuf,
                            gsel, adjoint ? -1.0 : 1.0, acc);
         NLG_TRY(sem_tensor(m, acc, out[i], m->nd, m->n, m->d_Jdt, m->d_Jdt, m->d_Jdt, nullptr));
     }
@@ -3122,11 +3213,11 @@ int sem_ediag(nlg_mesh *m, double *out) {
                     M[ax] = (a && b) ? dDD : ((a || b) ? dID : dII);
                 }
                 NLG_TRY(sem_tensor(m, m->d_mbinv[i], tmp, n, n2, M[0], M[1], M[2], nullptr));
-                hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, prod, m->d_rst2w[j * dim + i],
+                NLG_LAUNCH(k_mul, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, prod, m->d_rst2w[j * dim + i],
                                    m->d_rst2w[jj * dim + i], m->lpn);
                 // acc += prod * tmp  (reuse k_mul then add via colmul-less path)
-                hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, tmp, prod, tmp, m->lpn);
-                hipLaunchKernelGGL(k_addto, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, acc, tmp, m->lpn);
+                NLG_LAUNCH(k_mul, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, tmp, prod, tmp, m->lpn);
+                NLG_LAUNCH(k_addto, dim3(grid_for(m->lpn)), dim3(NT), 0, m->ctx->stream, acc, tmp, m->lpn);
             }
     NLG_HIP(hipStreamSynchronize(m->ctx->stream));
     hipFree(dII);
@@ -3226,7 +3317,7 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
     if (d->tmask)
         NLG_HIP(hipMemcpyAsync(m->d_tmask, d->tmask, sizeof(double) * (size_t)m->lvn, hipMemcpyHostToDevice, s));
     else
-        hipLaunchKernelGGL(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_tmask, 1.0, m->lvn);
+        NLG_LAUNCH(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_tmask, 1.0, m->lvn);
     m->h_lglel.resize(m->E);
     for (int64_t e = 0; e < m->E; ++e) m->h_lglel[e] = d->lglel ? d->lglel[e] : e;
     NLG_HIP(hipMalloc(&m->d_lglel, sizeof(int64_t) * (size_t)m->E));
@@ -3247,7 +3338,7 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
         CF3 X = {{m->d_x[0], m->d_x[1], m->d_x[2]}};
         F9 r;
         for (int q = 0; q < 9; ++q) r.p[q] = m->d_rst[q];
-        hipLaunchKernelGGL(k_geom, dim3((unsigned)m->E), dim3(NT), sizeof(double) * 3 * m->np1, s, dim, n, m->d_D, m->d_w1, X, r,
+        NLG_LAUNCH(k_geom, dim3((unsigned)m->E), dim3(NT), sizeof(double) * 3 * m->np1, s, dim, n, m->d_D, m->d_w1, X, r,
                            m->d_jac, m->d_bm1, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], d_bad);
         NLG_HIP(hipGetLastError());
     }
@@ -3369,16 +3460,16 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
     m->gs.h_groups.shrink_to_fit();
     // ---- multiplicity, assembled inverse mass, fused opbinv weights
     {
-        hipLaunchKernelGGL(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, 1.0, m->lvn);
+        NLG_LAUNCH(k_set, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, 1.0, m->lvn);
         double *f[1] = {m->d_vmult};
         NLG_TRY(sem_gs(m, f, 1));
-        hipLaunchKernelGGL(k_recip, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, m->d_vmult, m->lvn);
+        NLG_LAUNCH(k_recip, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_vmult, m->d_vmult, m->lvn);
         NLG_HIP(hipMemcpyAsync(m->d_binvm1, m->d_bm1, sizeof(double) * (size_t)m->lvn, hipMemcpyDeviceToDevice, s));
         double *f2[1] = {m->d_binvm1};
         NLG_TRY(sem_gs(m, f2, 1));
-        hipLaunchKernelGGL(k_recip, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_binvm1, m->d_binvm1, m->lvn);
+        NLG_LAUNCH(k_recip, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_binvm1, m->d_binvm1, m->lvn);
         for (int c = 0; c < dim; ++c)
-            hipLaunchKernelGGL(k_mul, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_mbinv[c], m->d_mask[c], m->d_binvm1, m->lvn);
+            NLG_LAUNCH(k_mul, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->d_mbinv[c], m->d_mask[c], m->d_binvm1, m->lvn);
         NLG_HIP(hipGetLastError());
         if (dim == 3 && m->d_slot_xp) {
             NLG_TRY(dalloc(&m->d_vmult_xp, m->lvs, s));
@@ -3408,7 +3499,7 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
     NLG_TRY(dalloc(&m->d_bm2, m->lps, s));
     NLG_TRY(dalloc(&m->d_bm2inv, m->lps, s));
     NLG_TRY(sem_tensor(m, m->d_jac, m->d_bm2, n, n2, m->d_I12, m->d_I12, m->d_I12, m->d_w2));
-    hipLaunchKernelGGL(k_recip, dim3(grid_for(m->lpn)), dim3(NT), 0, s, m->d_bm2inv, m->d_bm2, m->lpn);
+    NLG_LAUNCH(k_recip, dim3(grid_for(m->lpn)), dim3(NT), 0, s, m->d_bm2inv, m->d_bm2, m->lpn);
 
     // ---- volumes (host sums; set-up only)
     {
@@ -3470,6 +3561,7 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
 int nlg_mesh_destroy(nlg_mesh *m) {
     if (!m) return 0;
     hipDeviceSynchronize();
+    nlg_vec_pool_trim(nullptr);   // released vectors (nlg_vec_release) may still point at this mesh
     double *ptrs[] = {m->d_D, m->d_Dt, m->d_I12, m->d_I12t, m->d_D12, m->d_D12t, m->d_Jd, m->d_Jdt, m->d_DJd, m->d_DJdt,
                       m->d_rdr, m->d_w1, m->d_w2, m->d_wd, m->d_jac, m->d_bm1, m->d_binvm1, m->d_vmult, m->d_tmask,
                       m->d_bm2, m->d_bm2inv};
@@ -3497,6 +3589,7 @@ int nlg_mesh_destroy(nlg_mesh *m) {
     if (m->gs.d_indices_xp) hipFree(m->gs.d_indices_xp);
     if (m->d_slot_xp) hipFree(m->d_slot_xp);
     if (m->d_vmult_xp) hipFree(m->d_vmult_xp);
+    if (m->d_wlanes) hipFree(m->d_wlanes);
     for (int c = 0; c < 3; ++c)
         if (m->d_mbinv_fg[c]) hipFree(m->d_mbinv_fg[c]);
     if (m->gs.d_offsets) hipFree(m->gs.d_offsets);
@@ -3565,7 +3658,7 @@ int nlg_vec_rand_noise(nlg_vec *self, uint64_t seed) {
     CF3 X = {{m->d_x[0], m->d_x[1], m->d_x[2]}};
     for (int f = 0; f < self->ncomp; ++f) {
         double *fld = f < m->dim ? self->vel(f) : self->theta(f - m->dim);
-        hipLaunchKernelGGL(k_rand_add, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->dim, m->n, m->E, m->d_lglel, X, fld, f, seed);
+        NLG_LAUNCH(k_rand_add, dim3(grid_for(m->lvn)), dim3(NT), 0, s, m->dim, m->n, m->E, m->d_lglel, X, fld, f, seed);
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -3584,22 +3677,22 @@ int nlg_vec_rand_finish(nlg_vec *self, int ifnorm) {
     for (int pass = 0; pass < 2; ++pass) {
         NLG_TRY(sem_gs(m, v, m->dim));
         if (m->dim == 3)
-            hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, vm, m->lvn);
+            NLG_LAUNCH(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, vm, m->lvn);
         else
-            hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, vm, m->lvn);
+            NLG_LAUNCH(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, vm, m->lvn);
     }
     if (m->dim == 3)
-        hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, mk, m->lvn);
+        NLG_LAUNCH(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, mk, m->lvn);
     else
-        hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, mk, m->lvn);
+        NLG_LAUNCH(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, fv, mk, m->lvn);
     for (int sc = 0; sc < self->nscal; ++sc) {
         double *t[1] = {self->theta(sc)};
         F3 ft = {{t[0], nullptr, nullptr}};
         CF3 vm1 = {{m->d_vmult, nullptr, nullptr}};
         CF3 tm = {{m->d_tmask, nullptr, nullptr}};
         NLG_TRY(sem_gs(m, t, 1));
-        hipLaunchKernelGGL(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, ft, vm1, m->lvn);
-        hipLaunchKernelGGL(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, ft, tm, m->lvn);
+        NLG_LAUNCH(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, ft, vm1, m->lvn);
+        NLG_LAUNCH(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, s, ft, tm, m->lvn);
     }
     NLG_HIP(hipGetLastError());
     if (ifnorm) {
@@ -3645,7 +3738,7 @@ int nlg_vec_outpost(const nlg_vec *v, const char *path, int with_coords, double 
     {
         F3 fw = {{p1, nullptr, nullptr}};
         CF3 vm = {{m->d_vmult, nullptr, nullptr}};
-        hipLaunchKernelGGL(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, fw, vm, m->lvn);
+        NLG_LAUNCH(k_colmul<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, fw, vm, m->lvn);
     }
     std::vector<std::vector<double>> grp;   // each [E][nc][np1]
     std::vector<int> ncs;
@@ -3733,6 +3826,7 @@ int nlg_vec_outpost(const nlg_vec *v, const char *path, int with_coords, double 
 }
 
 int64_t nlg_vec_size_value(const nlg_vec *self) { return self ? (int64_t)self->ncomp * self->mesh->lvn + self->mesh->lpn : -1; }
+int nlg_vec_has_rst_value(const nlg_vec *self) { return (self && self->nrst > 0) ? 1 : 0; }
 
 // ---- operator-level entry points ------------------------------------------------------------------
 static int vel_ptrs(const nlg_vec *v, double **p) {
@@ -3752,9 +3846,9 @@ int nlg_op_helmholtz(nlg_mesh *m, const nlg_vec *in, nlg_vec *out, double h1, do
         F3 fw = {{w[0], w[1], w[2]}};
         CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
         if (m->dim == 3)
-            hipLaunchKernelGGL(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, fw, mk, m->lvn);
+            NLG_LAUNCH(k_colmul<3>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, fw, mk, m->lvn);
         else
-            hipLaunchKernelGGL(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, fw, mk, m->lvn);
+            NLG_LAUNCH(k_colmul<2>, dim3(grid_for(m->lvn)), dim3(NT), 0, m->ctx->stream, fw, mk, m->lvn);
         NLG_HIP(hipGetLastError());
     }
     return 0;

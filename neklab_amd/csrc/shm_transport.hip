@@ -111,7 +111,7 @@ int shm_allgather_i64(nlg_ctx *ctx, const int64_t *d_in, int64_t *d_out, int64_t
 }
 
 // Slot layout of an exchange: [nneigh, ntot, nf, (neigh, noff, ncnt) * nneigh] as int64, then nf * ntot doubles.
-int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf) {
+int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf, hipStream_t st) {
     nlg_shm *s = ctx->shm;
     const size_t nn = h.neigh.size();
     const size_t head = sizeof(int64_t) * (3 + 3 * nn);
@@ -126,8 +126,8 @@ int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf) {
         mine[4 + 3 * q] = h.noff[q];
         mine[5 + 3 * q] = h.ncnt[q];
     }
-    NLG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(mine) + head, h.d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    NLG_HIP(hipStreamSynchronize(ctx->stream));
+    NLG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(mine) + head, h.d_send, bytes, hipMemcpyDeviceToHost, st));
+    NLG_HIP(hipStreamSynchronize(st));
     NLG_TRY(shm_barrier(s));
     s->stage.resize(bytes);
     double *recv = reinterpret_cast<double *>(s->stage.data());
@@ -147,8 +147,8 @@ int shm_exchange(nlg_ctx *ctx, const nlg_halo &h, int nf) {
             memcpy(recv + (size_t)c * h.ntot + h.noff[q], pdata + (size_t)c * ptot + poff, sizeof(double) * (size_t)h.ncnt[q]);
     }
     NLG_TRY(shm_barrier(s));
-    NLG_HIP(hipMemcpyAsync(h.d_recv, recv, bytes, hipMemcpyHostToDevice, ctx->stream));
-    NLG_HIP(hipStreamSynchronize(ctx->stream));
+    NLG_HIP(hipMemcpyAsync(h.d_recv, recv, bytes, hipMemcpyHostToDevice, st));
+    NLG_HIP(hipStreamSynchronize(st));
     return 0;
 }
 

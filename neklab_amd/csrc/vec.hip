@@ -454,9 +454,9 @@ namespace nlg {
 int dev_dot(const nlg_vec *a, const nlg_vec *b, int slot) {
     nlg_ctx *ctx = a->mesh->ctx;
     const int nblk = dot_nblk(a);
-    hipLaunchKernelGGL(k_dot_partial, dim3(nblk, a->ncomp), dim3(NT), 0, ctx->stream, a->d, b->d, a->mesh->d_bm1,
+    NLG_LAUNCH(k_dot_partial, dim3(nblk, a->ncomp), dim3(NT), 0, ctx->stream, a->d, b->d, a->mesh->d_bm1,
                        a->mesh->lvs, nblk, ctx->d_partial);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(NT), 0, ctx->stream, ctx->d_partial, nblk * a->ncomp,
+    NLG_LAUNCH(k_reduce_rows, dim3(1), dim3(NT), 0, ctx->stream, ctx->d_partial, nblk * a->ncomp,
                        ctx->d_scalars + slot, 0, (double *)nullptr);
     NLG_HIP(hipGetLastError());
     NLG_TRY(allreduce_sum(ctx, ctx->d_scalars + slot, 1));
@@ -474,6 +474,40 @@ int nlg_set_axpby_rst_consistent(int flag) {
     return 0;
 }
 
+// ---- handle lifetimes for by-value host languages (the Fortran shim) ---------------------------------------------------
+// The reference's vectors are plain arrays: intrinsic assignment, sourced allocation, array constructors and reallocation on
+// assignment copy them bit by bit (neklab_analysis.f90:250 `allocate(Lu(r), source=..)`).  A shim object holding a handle is
+// then duplicated behind its type's back, and its finaliser may run on the ORIGINAL while a copy is still going to be used
+// (`X = [X, v]`: the temporary holds the copies, the old X is finalised, the new X receives the bits).  So the owner's
+// finaliser does not free: it RELEASES the handle (state "released", buffer kept); a copy that turns up later ADOPTS it --
+// released: the copy becomes the owner, nothing is copied or leaked; still owned elsewhere: the caller clones.  Every handle
+// carries a generation number, so that a copy whose handle has meanwhile been freed and whose address has been reused is
+// recognised instead of reading someone else's data.  Released buffers are freed oldest first once they hold more than
+// g_pool_limit bytes (nlg_vec_pool_limit) or when an allocation fails, and all of them by nlg_vec_pool_trim.
+namespace {
+struct VecInfo {
+    uint64_t gen = 0;
+    bool released = false;
+    uint64_t released_at = 0;
+};
+std::map<const nlg_vec *, VecInfo> g_vecs;      // every live or released handle
+uint64_t g_next_gen = 1, g_release_tick = 0;
+int64_t g_pool_bytes = 0, g_pool_limit = (int64_t)32 << 30;
+
+void pool_free_oldest() {
+    const nlg_vec *old = nullptr;
+    uint64_t at = ~0ull;
+    for (auto &kv : g_vecs)
+        if (kv.second.released && kv.second.released_at < at) at = kv.second.released_at, old = kv.first;
+    if (!old) return;
+    nlg_vec *v = const_cast<nlg_vec *>(old);
+    g_pool_bytes -= (int64_t)sizeof(double) * v->total_len;
+    g_vecs.erase(old);
+    if (v->owns && v->d) hipFree(v->d);
+    delete v;
+}
+}  // namespace
+
 int nlg_vec_create(nlg_mesh *mesh, int nscal, int lorder, nlg_vec **out) {
     NLG_CHECK(mesh && out, "nlg_vec_create: NULL argument");
     NLG_CHECK(nscal >= 0 && nscal <= 8, "nlg_vec_create: nscal %d out of range", nscal);
@@ -487,6 +521,11 @@ int nlg_vec_create(nlg_mesh *mesh, int nscal, int lorder, nlg_vec **out) {
     v->total_len = v->main_len * lorder;
     NLG_HIP(hipSetDevice(mesh->ctx->device));
     hipError_t e = hipMalloc(&v->d, sizeof(double) * (size_t)v->total_len);
+    while (e != hipSuccess && g_pool_bytes > 0) {   // give released buffers back before failing
+        (void)hipGetLastError();
+        pool_free_oldest();
+        e = hipMalloc(&v->d, sizeof(double) * (size_t)v->total_len);
+    }
     if (e != hipSuccess) {
         delete v;
         set_error("nlg_vec_create: hipMalloc(%zu bytes) failed: %s", sizeof(double) * (size_t)v->total_len,
@@ -494,14 +533,70 @@ int nlg_vec_create(nlg_mesh *mesh, int nscal, int lorder, nlg_vec **out) {
         return 1;
     }
     NLG_HIP(hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)v->total_len, mesh->ctx->stream));
+    g_vecs[v].gen = g_next_gen++;
     *out = v;
     return 0;
 }
 
 int nlg_vec_destroy(nlg_vec *v) {
     if (!v) return 0;
+    auto it = g_vecs.find(v);
+    if (it != g_vecs.end()) {
+        if (it->second.released) g_pool_bytes -= (int64_t)sizeof(double) * v->total_len;
+        g_vecs.erase(it);
+    }
     if (v->owns && v->d) hipFree(v->d);   // hipFree synchronises; never touch the parent mesh here
     delete v;
+    return 0;
+}
+
+int nlg_vec_generation(const nlg_vec *v, int64_t *gen) {
+    NLG_CHECK(v && gen, "nlg_vec_generation: NULL argument");
+    auto it = g_vecs.find(v);
+    NLG_CHECK(it != g_vecs.end(), "nlg_vec_generation: unknown handle (freed, or not created by nlg_vec_create)");
+    *gen = (int64_t)it->second.gen;
+    return 0;
+}
+
+int nlg_vec_release(nlg_vec *v) {
+    if (!v) return 0;
+    auto it = g_vecs.find(v);
+    NLG_CHECK(it != g_vecs.end(), "nlg_vec_release: unknown handle");
+    if (it->second.released) return 0;
+    it->second.released = true;
+    it->second.released_at = ++g_release_tick;
+    g_pool_bytes += (int64_t)sizeof(double) * v->total_len;
+    while (g_pool_bytes > g_pool_limit) pool_free_oldest();
+    return 0;
+}
+
+int nlg_vec_adopt(nlg_vec *v, int64_t gen, int *status) {
+    NLG_CHECK(v && status, "nlg_vec_adopt: NULL argument");
+    auto it = g_vecs.find(v);
+    NLG_CHECK(it != g_vecs.end() && (int64_t)it->second.gen == gen,
+              "nlg_vec_adopt: the handle of this copy has been freed (a bitwise copy of a vector was used after more than "
+              "nlg_vec_pool_limit bytes of released vectors piled up, or after nlg_vec_pool_trim)");
+    if (it->second.released) {
+        it->second.released = false;
+        g_pool_bytes -= (int64_t)sizeof(double) * v->total_len;
+        *status = 1;   // the caller owns the handle now
+    } else {
+        *status = 0;   // owned by a live object: the caller clones
+    }
+    return 0;
+}
+
+int nlg_vec_pool_limit(int64_t bytes) {
+    NLG_CHECK(bytes >= 0, "nlg_vec_pool_limit: negative limit");
+    g_pool_limit = bytes;
+    while (g_pool_bytes > g_pool_limit) pool_free_oldest();
+    return 0;
+}
+
+int nlg_vec_pool_trim(int64_t *freed_bytes) {
+    const int64_t before = g_pool_bytes;
+    while (g_pool_bytes > 0) pool_free_oldest();
+    if (freed_bytes) *freed_bytes = before;
     return 0;
 }
 
@@ -530,7 +625,7 @@ int nlg_vec_zero(nlg_vec *self) {
 int nlg_vec_scal(nlg_vec *self, double alpha) {
     NLG_CHECK(self, "nlg_vec_scal: NULL vector");
     const int64_t n2 = self->main_len * (1 + self->nrst) / 2;
-    hipLaunchKernelGGL(k_scal, dim3(grid_for(n2)), dim3(NT), 0, self->mesh->ctx->stream,
+    NLG_LAUNCH(k_scal, dim3(grid_for(n2)), dim3(NT), 0, self->mesh->ctx->stream,
                        reinterpret_cast<double2 *>(self->d), alpha, n2);
     NLG_HIP(hipGetLastError());
     return 0;
@@ -539,7 +634,7 @@ int nlg_vec_scal(nlg_vec *self, double alpha) {
 int nlg_vec_axpby(double alpha, const nlg_vec *vec, double beta, nlg_vec *self) {
     NLG_TRY(check_same(self, vec, "nlg_vec_axpby"));
     const int64_t n2 = self->main_len / 2;
-    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n2)), dim3(NT), 0, self->mesh->ctx->stream,
+    NLG_LAUNCH(k_axpby, dim3(grid_for(n2)), dim3(NT), 0, self->mesh->ctx->stream,
                        reinterpret_cast<double2 *>(self->d), reinterpret_cast<const double2 *>(vec->d), alpha, beta, n2,
                        self->nrst, n2, g_axpby_consistent);
     NLG_HIP(hipGetLastError());
@@ -716,15 +811,15 @@ int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_o
     const int nper = nblk * v0->ncomp;
     NLG_TRY(reduce_ws_reserve(ctx, k));
     ProfScope ps(ctx, P_BLOCKDOT);
-    hipLaunchKernelGGL(k_block_dot<KB>, dim3(nblk, v0->ncomp, (k + KB - 1) / KB), dim3(NT), 0, ctx->stream, b->d,
+    NLG_LAUNCH(k_block_dot<KB>, dim3(nblk, v0->ncomp, (k + KB - 1) / KB), dim3(NT), 0, ctx->stream, b->d,
                        b->stride, k, w->d, b->mesh->d_bm1, b->mesh->lvs, nblk, nper, ctx->d_partial);
     if (ctx->distributed()) {
-        hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out, 0,
+        NLG_LAUNCH(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out, 0,
                            (double *)nullptr);
         NLG_TRY(allreduce_sum(ctx, d_out, k));
-        if (d_acc) hipLaunchKernelGGL(k_vadd, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, d_acc, d_out, k);
+        if (d_acc) NLG_LAUNCH(k_vadd, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, d_acc, d_out, k);
     } else {
-        hipLaunchKernelGGL(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out,
+        NLG_LAUNCH(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out,
                            d_acc ? 1 : 0, d_acc);
     }
     NLG_HIP(hipGetLastError());
@@ -740,10 +835,10 @@ int basis_block_axpy_dev(const nlg_basis *b, int k, const double *d_h, nlg_vec *
         // consistent history: main block and the nrst valid history blocks are one contiguous range in which every
         // entry receives the same linear combination -> one sweep through the unrolled path
         const int64_t n2all = main_only ? n2 : n2 * (1 + w->nrst);
-        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2all)), dim3(NT), sizeof(double) * 2 * k, ctx->stream, b->d, b->stride,
+        NLG_LAUNCH(k_block_axpy, dim3(grid_for(n2all)), dim3(NT), sizeof(double) * 2 * k, ctx->stream, b->d, b->stride,
                            k, d_h, w->d, n2all, 0, n2, 0, sign, d_hh);
     } else {
-        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * 2 * k, ctx->stream, b->d, b->stride, k,
+        NLG_LAUNCH(k_block_axpy, dim3(grid_for(n2)), dim3(NT), sizeof(double) * 2 * k, ctx->stream, b->d, b->stride, k,
                            d_h, w->d, n2, w->nrst, n2, 0, sign, (const double *)nullptr);
     }
     NLG_HIP(hipGetLastError());
@@ -776,23 +871,23 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
                 const double *Vf = b->d + (int64_t)k0 * b->stride;
                 {
                     ProfScope ps(ctx, P_AXPYDOT);
-                    hipLaunchKernelGGL(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, Vf, b->stride, kf,
+                    NLG_LAUNCH(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, Vf, b->stride, kf,
                                        (const double *)(h + k0), w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
                 }
                 {
                     ProfScope ps(ctx, P_BLOCKAXPY);
                     const int64_t np2 = (w->main_len - nv) / 2;        // pressure part of the main block: subtraction only
                     if (np2 > 0)
-                        hipLaunchKernelGGL(k_block_axpy, dim3(grid_for(np2)), dim3(NT), sizeof(double) * 2 * kf, ctx->stream,
+                        NLG_LAUNCH(k_block_axpy, dim3(grid_for(np2)), dim3(NT), sizeof(double) * 2 * kf, ctx->stream,
                                            Vf + nv, b->stride, kf, (const double *)(h + k0), w->d + nv, np2, 0, np2, 0, -1.0,
                                            (const double *)nullptr);
                 }
                 if (ctx->distributed()) {
-                    hipLaunchKernelGGL(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 0, (double *)nullptr);
+                    NLG_LAUNCH(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 0, (double *)nullptr);
                     NLG_TRY(allreduce_sum(ctx, h2 + k0, kf));
-                    hipLaunchKernelGGL(k_vadd, dim3((kf + 255) / 256), dim3(256), 0, ctx->stream, h + k0, h2 + k0, kf);
+                    NLG_LAUNCH(k_vadd, dim3((kf + 255) / 256), dim3(256), 0, ctx->stream, h + k0, h2 + k0, kf);
                 } else {
-                    hipLaunchKernelGGL(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 1, h + k0);
+                    NLG_LAUNCH(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 1, h + k0);
                 }
                 if (k0 > 0) NLG_TRY(basis_block_dot_dev(b, k0, w, h2, h));
             } else {
@@ -808,13 +903,13 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
     }
     // norm
     const int nblk = dot_nblk(w);
-    hipLaunchKernelGGL(k_dot_partial, dim3(nblk, w->ncomp), dim3(NT), 0, ctx->stream, w->d, w->d, b->mesh->d_bm1,
+    NLG_LAUNCH(k_dot_partial, dim3(nblk, w->ncomp), dim3(NT), 0, ctx->stream, w->d, w->d, b->mesh->d_bm1,
                        b->mesh->lvs, nblk, ctx->d_partial);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(NT), 0, ctx->stream, ctx->d_partial, nblk * w->ncomp, h + k, 0,
+    NLG_LAUNCH(k_reduce_rows, dim3(1), dim3(NT), 0, ctx->stream, ctx->d_partial, nblk * w->ncomp, h + k, 0,
                        (double *)nullptr);
     NLG_TRY(allreduce_sum(ctx, h + k, 1));
     const int64_t n2 = w->main_len * (1 + w->nrst) / 2;
-    hipLaunchKernelGGL(k_scal_dev, dim3(grid_for(n2)), dim3(NT), 0, ctx->stream, reinterpret_cast<double2 *>(w->d),
+    NLG_LAUNCH(k_scal_dev, dim3(grid_for(n2)), dim3(NT), 0, ctx->stream, reinterpret_cast<double2 *>(w->d),
                        h + k, 0, n2);
     NLG_HIP(hipGetLastError());
     return 0;
@@ -890,25 +985,25 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
     auto dots = [&](const double *V, int kk, double *out, double *acc) -> int {
         ProfScope ps(ctx, P_BLOCKDOT);
         const dim3 g(nblk, w0->ncomp, (kk + KB - 1) / KB);
-#define BD(S_) hipLaunchKernelGGL((k_block_dot_s<KB, S_>), g, dim3(NT), 0, st, V, b->stride, kk, (const double *)W, b->stride, \
+#define BD(S_) NLG_LAUNCH((k_block_dot_s<KB, S_>), g, dim3(NT), 0, st, V, b->stride, kk, (const double *)W, b->stride, \
                                   (const double *)b->mesh->d_bm1, b->mesh->lvs, nblk, nper, ctx->d_partial)
         if (s == 2) BD(2);
         else if (s == 3) BD(3);
         else BD(4);
 #undef BD
         if (ctx->distributed()) {
-            hipLaunchKernelGGL(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, 0, (double *)nullptr);
+            NLG_LAUNCH(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, 0, (double *)nullptr);
             NLG_TRY(allreduce_sum(ctx, out, kk * s));
-            if (acc) hipLaunchKernelGGL(k_vadd, dim3((kk * s + 255) / 256), dim3(256), 0, st, acc, out, kk * s);
+            if (acc) NLG_LAUNCH(k_vadd, dim3((kk * s + 255) / 256), dim3(256), 0, st, acc, out, kk * s);
         } else {
-            hipLaunchKernelGGL(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, acc ? 1 : 0, acc);
+            NLG_LAUNCH(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, acc ? 1 : 0, acc);
         }
         return 0;
     };
     auto axpy = [&](const double *h, const double *hh, int64_t n, int64_t blk2) -> int {
         ProfScope ps(ctx, P_BLOCKAXPY);
         const size_t lds = sizeof(double) * 2 * (size_t)k * s;
-#define BA(S_) hipLaunchKernelGGL((k_block_axpy_s<S_>), dim3(grid_for(n)), dim3(NT), lds, st, (const double *)b->d, b->stride, k, h, hh, W, \
+#define BA(S_) NLG_LAUNCH((k_block_axpy_s<S_>), dim3(grid_for(n)), dim3(NT), lds, st, (const double *)b->d, b->stride, k, h, hh, W, \
                                   b->stride, n, blk2, -1.0)
         if (s == 2) BA(2);
         else if (s == 3) BA(3);
@@ -961,7 +1056,7 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
         NLG_HIP(hipMemcpyAsync(dT, Tf, sizeof(double) * s * s, hipMemcpyHostToDevice, st));
         {
             ProfScope ps(ctx, P_BLOCKAXPY);
-#define BR(S_) hipLaunchKernelGGL((k_block_rmul<S_>), dim3(grid_for(n2all)), dim3(NT), 0, st, W, b->stride, (const double *)dT, n2all)
+#define BR(S_) NLG_LAUNCH((k_block_rmul<S_>), dim3(grid_for(n2all)), dim3(NT), 0, st, W, b->stride, (const double *)dT, n2all)
             if (s == 2) BR(2);
             else if (s == 3) BR(3);
             else BR(4);

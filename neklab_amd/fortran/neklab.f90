@@ -3,10 +3,11 @@
 module neklab
    use LightKrylov, only: dp
    use neklab_gpu_capi, only: neklab_gpu_init, neklab_gpu_set_mesh, neklab_gpu_set_case, neklab_gpu_finalize, nlg_check, &
-                              nlg_exptA_config, nek_case
+                              nlg_exptA_config, nek_case, nek_endtime
    use neklab_vectors
    use neklab_linops
    use neklab_utils
+   use neklab_systems
    use neklab_analysis
    implicit none
    public

@@ -1,82 +1,125 @@
-!> Drop-in for the hot-path driver of the reference's module of the same name:
-!! linear_stability_analysis_fixed_point, src/neklab_analysis.f90:38-105.  The body is the reference's call sequence
-!! (:77-93) line for line, with the same `use` names; logger / timer plumbing (LightKrylov_Logger, LightKrylov_Timing) is
-!! out of scope and left out.  `eigs` is LightKrylov's (here: the stand-in of lightkrylov_stub.f90, which drives the
-!! vectors and the operator through their type-bound procedures only); `device_eigs = .true.` switches to the device
-!! block path (nek_eigs -> nlg_eigs) with the same arguments.
+!> Analysis drivers over the device hot path: the two entry points of the reference's module of the same name that consume it,
+!!   linear_stability_analysis_fixed_point   (/root/reference/src/neklab_analysis.f90:38-105)
+!!   transient_growth_analysis_fixed_point   (/root/reference/src/neklab_analysis.f90:107-156)
+!! plus newton_fixed_point_iteration (:158-212) for the base-flow step upstream of them.  Same names, dummy arguments and
+!! files written (`dir|adj_eigenspectrum.npy`, `singular_spectrum.dat`, the `dir` / `adj` / `prt` / `rsp` / `nwt` field files),
+!! so a case file that calls them needs no edit.  With `device_eigs = .true.` the Krylov loop itself runs on the device
+!! (nek_eigs / nek_svds -> nlg_eigs / nlg_svds: basis in one allocation, one fused projection kernel and one all-reduce per
+!! Gram-Schmidt pass); with `.false.` LightKrylov's own eigs / svds drive the vectors and the operator through their
+!! type-bound procedures.  Logger and timer plumbing of the reference is LightKrylov's and is not repeated here.
+!! (In a build against the real LightKrylov the reference's own file works unchanged on top of neklab_vectors / neklab_linops;
+!!  this module exists for the device switch.)
 module neklab_analysis
-   use LightKrylov, only: dp, eigs, save_eigenspectrum
-   use LightKrylov, only: zero_basis
-   use LightKrylov_AbstractVectors, only: abstract_vector_rdp
-   use LightKrylov_AbstractLinops, only: abstract_exptA_linop_rdp
+   use LightKrylov, only: dp, eigs, svds, save_eigenspectrum, zero_basis, initialize_krylov_subspace, newton, gmres_rdp
+   use LightKrylov, only: abstract_vector_rdp, abstract_exptA_linop_rdp, abstract_system_rdp
    use neklab_vectors
    use neklab_linops
    use neklab_utils
+   use neklab_systems, only: nek_constant_tol, nek_dynamic_tol
    implicit none
    private
-   character(len=*), parameter, private :: this_module = 'neklab_analysis'
 
-   public :: linear_stability_analysis_fixed_point
+   public :: linear_stability_analysis_fixed_point, transient_growth_analysis_fixed_point, newton_fixed_point_iteration
+   !> .true.: Arnoldi / Lanczos on the device; .false.: LightKrylov's loops over the type-bound procedures
    logical, save, public :: device_eigs = .false.
 
 contains
 
+   !> Leading eigenpairs of exp(tau L) (adjoint: of its transpose) -> growth rates and frequencies log(mu) / tau.
    subroutine linear_stability_analysis_fixed_point(exptA, kdim, nev, adjoint, X0)
       class(abstract_exptA_linop_rdp), intent(inout) :: exptA
-      !! Operator whose stability properties are to be investigated.
-      integer, intent(in) :: kdim
-      !! Maximum dimension of the Krylov subspace.
-      integer, intent(in) :: nev
-      !! Desired number of eigenpairs to converge.
+      integer, intent(in) :: kdim, nev
       logical, intent(in), optional :: adjoint
-      !! Whether direct or adjoint analysis should be conducted.
       type(nek_dvector), optional, intent(in) :: X0
-      !! Initial guess for the eigenvectors
+      type(nek_dvector), allocatable :: modes(:)
+      complex(dp), allocatable :: spectrum(:)
+      real(dp), allocatable :: res(:)
+      character(len=3) :: tag
+      integer :: nmatvec
+      logical :: transposed, on_device
 
-      type(nek_dvector), allocatable :: eigvecs(:)
-      complex(kind=dp), allocatable :: eigvals(:)
-      real(kind=dp), allocatable :: residuals(:)
-      integer :: info
-      logical :: adjoint_
-      character(len=3) :: file_prefix
+      transposed = .false.
+      if (present(adjoint)) transposed = adjoint
+      tag = 'dir'
+      if (transposed) tag = 'adj'
 
-      ! Optional parameters.
-      if (present(adjoint)) then
-         adjoint_ = adjoint
-      else
-         adjoint_ = .false.
-      end if
+      allocate (modes(nev))
+      call zero_basis(modes)
 
-      ! Allocate eigenvectors and initialize Krylov basis.
-      allocate (eigvecs(nev)); call zero_basis(eigvecs)
-
-      ! Run the eigenvalue analysis.
+      on_device = .false.
       if (device_eigs) then
          select type (exptA)
          class is (exptA_linop)
-            call nek_eigs(exptA, eigvecs, eigvals, residuals, info, x0=X0, kdim=kdim, &
-                          transpose=adjoint_, write_intermediate=.true.)
+            on_device = .true.
+            call nek_eigs(exptA, modes, spectrum, res, nmatvec, x0=X0, kdim=kdim, transpose=transposed, write_intermediate=.true.)
          end select
-      else
-         call eigs(exptA, eigvecs, eigvals, residuals, info, x0=X0, kdim=kdim, &
-                   transpose=adjoint_, write_intermediate=.true.)
+      end if
+      if (.not. on_device) then
+         call eigs(exptA, modes, spectrum, res, nmatvec, x0=X0, kdim=kdim, transpose=transposed, write_intermediate=.true.)
       end if
 
-      ! Transform eigenspectrum to continuous-time representation.
-      eigvals = log(eigvals)/exptA%tau
-
-      ! Determine the file prefix.
-      file_prefix = merge("adj", "dir", adjoint_)
-
-      ! Save eigenspectrum to disk.
-      call save_eigenspectrum(eigvals, residuals, trim(file_prefix)//"_eigenspectrum.npy")
-
-      ! Export eigenfunctions to disk.
-      call outpost_dnek(eigvecs(:nev), file_prefix)
-
-      ! Finalize exptA timings
+      spectrum = log(spectrum)/exptA%tau                       ! multipliers of the propagator -> continuous-time eigenvalues
+      call save_eigenspectrum(spectrum, res, tag//'_eigenspectrum.npy')
+      call outpost_dnek(modes(:nev), tag)
       call exptA%finalize_timer()
-
    end subroutine linear_stability_analysis_fixed_point
+
+   !> Largest singular triplets of exp(tau L): optimal perturbations (V, prefix prt), optimal responses (U, prefix rsp).
+   subroutine transient_growth_analysis_fixed_point(exptA, nsv, kdim)
+      class(abstract_exptA_linop_rdp), intent(inout) :: exptA
+      integer, intent(in) :: nsv, kdim
+      type(nek_dvector), allocatable :: resp(:), pert(:)
+      real(dp), allocatable :: sigma(:), res(:)
+      integer :: nmatvec, u
+      logical :: on_device
+
+      allocate (resp(nsv), pert(nsv))
+      call initialize_krylov_subspace(resp)
+      call initialize_krylov_subspace(pert)
+
+      on_device = .false.
+      if (device_eigs) then
+         select type (exptA)
+         class is (exptA_linop)
+            on_device = .true.
+            call nek_svds(exptA, resp, sigma, pert, res, nmatvec, kdim=kdim, write_intermediate=.true.)
+         end select
+      end if
+      if (.not. on_device) call svds(exptA, resp, sigma, pert, res, nmatvec, kdim=kdim, write_intermediate=.true.)
+
+      open (newunit=u, file='singular_spectrum.dat', status='replace', action='write')
+      write (u, *) sigma
+      close (u)
+      call outpost_dnek(pert(:nsv), 'prt')
+      call outpost_dnek(resp(:nsv), 'rsp')
+      call exptA%finalize_timer()
+   end subroutine transient_growth_analysis_fixed_point
+
+   !> Newton-Krylov iteration for a fixed point of sys, at most 40 iterations, no bisection; tol_mode 1: constant solver
+   !! tolerance, otherwise tied to the residual (the two schedulers of neklab_systems).  The converged state is written with the
+   !! prefix nwt.
+   subroutine newton_fixed_point_iteration(sys, bf, tol, tol_mode, input_is_fixed_point)
+      class(abstract_system_rdp), intent(inout) :: sys
+      class(abstract_vector_rdp), intent(inout) :: bf
+      real(dp), intent(inout) :: tol
+      integer, optional, intent(in) :: tol_mode
+      logical, optional, intent(out) :: input_is_fixed_point
+      integer :: niter, mode
+      mode = 1
+      if (present(tol_mode)) mode = tol_mode
+      if (mode == 1) then
+         call newton(sys, bf, gmres_rdp, niter, atol=tol, maxiter=40, scheduler=nek_constant_tol)
+      else
+         call newton(sys, bf, gmres_rdp, niter, atol=tol, maxiter=40, scheduler=nek_dynamic_tol)
+      end if
+      if (niter < 0) write (*, '(A)') 'WARNING in newton_fixed_point_iteration: not converged after 40 iterations'
+      select type (bf)
+      type is (nek_dvector)
+         call outpost_dnek(bf, 'nwt')
+      end select
+      if (present(input_is_fixed_point)) input_is_fixed_point = niter == 0
+      call sys%finalize_timer()
+      call sys%jacobian%finalize_timer()
+   end subroutine newton_fixed_point_iteration
 
 end module neklab_analysis

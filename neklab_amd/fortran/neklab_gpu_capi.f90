@@ -47,6 +47,8 @@ module neklab_gpu_capi
    integer, save, public :: nek_nscal = 0, nek_lorder = 3
    integer(c_int64_t), save, public :: nek_lvn = 0, nek_lpn = 0
    integer, save, public :: nek_ldim = 0, nek_lx1 = 0
+   !> Nek5000's endTime (param(10)): the horizon the nonlinear map of the Newton systems integrates over (fixed_point.f90:14-24)
+   real(c_double), save, public :: nek_endtime = 1.0_c_double
 
    interface
       function c_last_error() bind(C, name="nlg_last_error") result(p)
@@ -87,6 +89,34 @@ module neklab_gpu_capi
          import c_int, c_ptr
          type(c_ptr), value :: v
          integer(c_int) :: rc
+      end function
+      function c_vec_generation(v, gen) bind(C, name="nlg_vec_generation") result(rc)
+         import c_int, c_ptr, c_int64_t
+         type(c_ptr), value :: v
+         integer(c_int64_t), intent(out) :: gen
+         integer(c_int) :: rc
+      end function
+      function c_vec_release(v) bind(C, name="nlg_vec_release") result(rc)
+         import c_int, c_ptr
+         type(c_ptr), value :: v
+         integer(c_int) :: rc
+      end function
+      function c_vec_adopt(v, gen, status) bind(C, name="nlg_vec_adopt") result(rc)
+         import c_int, c_ptr, c_int64_t
+         type(c_ptr), value :: v
+         integer(c_int64_t), value :: gen
+         integer(c_int), intent(out) :: status
+         integer(c_int) :: rc
+      end function
+      function c_vec_pool_trim(freed) bind(C, name="nlg_vec_pool_trim") result(rc)
+         import c_int, c_ptr
+         type(c_ptr), value :: freed
+         integer(c_int) :: rc
+      end function
+      pure function c_vec_has_rst_value(v) bind(C, name="nlg_vec_has_rst_value") result(flag)
+         import c_int, c_ptr
+         type(c_ptr), value :: v
+         integer(c_int) :: flag
       end function
       function c_vec_clone(src, v) bind(C, name="nlg_vec_clone") result(rc)
          import c_int, c_ptr
@@ -372,11 +402,12 @@ contains
    !! Reynolds number), |param(27)| = time order, param(21) / param(22) = pressure / velocity tolerances, ifheat with
    !! its properties, the number of active scalars and `lorder`.  Omitted arguments keep their current value.
    subroutine neklab_gpu_set_case(re, torder, ptol, vtol, dt, cfl_limit, ifheat, conductivity, rhocp, buoy, nscal, lorder, &
-                                  maxit_v, maxit_p, pprecond, pproj)
-      real(dp), optional, intent(in) :: re, ptol, vtol, dt, cfl_limit, conductivity, rhocp, buoy(3)
+                                  maxit_v, maxit_p, pprecond, pproj, endtime)
+      real(dp), optional, intent(in) :: re, ptol, vtol, dt, cfl_limit, conductivity, rhocp, buoy(3), endtime
       integer, optional, intent(in) :: torder, nscal, lorder, maxit_v, maxit_p, pprecond, pproj
       logical, optional, intent(in) :: ifheat
       if (present(re)) nek_case%re = re
+      if (present(endtime)) nek_endtime = endtime
       if (present(torder)) nek_case%torder = torder
       if (present(ptol)) nek_case%ptol = ptol
       if (present(vtol)) nek_case%vtol = vtol
@@ -398,6 +429,7 @@ contains
 
    subroutine neklab_gpu_finalize()
       integer(c_int) :: rc
+      rc = c_vec_pool_trim(c_null_ptr)      ! vectors released by finalisers and never adopted
       if (c_associated(nlg_mesh)) rc = c_mesh_destroy(nlg_mesh)
       if (c_associated(nlg_ctx)) rc = c_ctx_destroy(nlg_ctx)
       nlg_mesh = c_null_ptr; nlg_ctx = c_null_ptr

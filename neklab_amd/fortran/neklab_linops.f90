@@ -53,6 +53,18 @@ module neklab_linops
       final :: finalize_exptA
    end type exptA_linop
 
+   !> exptA_temp_linop (src/linops/neklab_linops.f90:82-93, exponential_propagator_temp.f90: the propagator of the temperature-
+   !! coupled equations; the reference's file is a clone of the plain one because the temperature already travels in
+   !! nek_dvector%theta) and, under the name the reference's umbrella module and its thermosyphon case use, exptA_linop_temp
+   !! (src/neklab.f90:45, examples/thermosyphon/baseflow/tsyphon.usr:13,52 `exptA_linop_temp(1.0_dp, bf)`).  Here the coupling
+   !! is a property of the case (neklab_gpu_set_case(ifheat=.true., ..)); the two types insist on it at init().
+   type, extends(exptA_linop), public :: exptA_temp_linop
+   contains
+      procedure, pass(self), public :: init => init_exptA_temp
+   end type exptA_temp_linop
+   type, extends(exptA_temp_linop), public :: exptA_linop_temp
+   end type exptA_linop_temp
+
    !> exptA_proj_linop(tau=.., baseflow=.., alpha=..) (examples/poiseuille/stability/direct_alpha_1/poiseuille.usr:24).
    !! `set_lines` hands over what Nek5000's gtpp_gs_setup derives from (nelx, nely, nelz): one label per velocity point
    !! naming its line along the homogeneous direction.
@@ -95,6 +107,17 @@ contains
       self%owner = loc(self)
       call nlg_check(c_linop_init(self%h), 'init_exptA')
       self%tau_built = self%tau
+   end subroutine
+
+   subroutine init_exptA_temp(self)
+      class(exptA_temp_linop), intent(inout) :: self
+      if (.not. self%cfg_set) self%cfg = nek_case
+      if (self%cfg%ifheat == 0) then
+         write (*, '(A)') 'ERROR in '//this_module//': exptA_temp_linop needs the temperature coupling of the case (neklab_gpu_set_case(ifheat=.true.))'
+         error stop 1
+      end if
+      self%cfg_set = .true.
+      call init_exptA(self)
    end subroutine
 
    subroutine sync_tau(self, where)

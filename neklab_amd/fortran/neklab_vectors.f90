@@ -9,11 +9,18 @@
 !!
 !! Object semantics.  The reference's vectors are plain static arrays: intrinsic assignment, sourced allocation and
 !! structure constructors deep-copy them (SURVEY.md 7.3 item 5).  Here the fields live in HBM behind an opaque handle, so
-!!   * `=` is a defined assignment (clone / copy) and the type has a finaliser (destroy);
-!!   * every object remembers the address it was created at (`owner`).  A bitwise copy made behind the type's back
-!!     (allocate(.., source=), a structure-constructor component, an array assignment) has the same handle but another
-!!     address: it is recognised on its first use as an inout argument and given its own clone, and a finaliser only
-!!     destroys the handle its object owns -- never a double free, never two vectors writing the same memory;
+!!   * `=` is a defined assignment (clone / copy) and the type has a finaliser;
+!!   * every object remembers the address it was created at (`owner`) and the generation number of its handle (`gen`).  A
+!!     bitwise copy made behind the type's back (allocate(.., source=), an array constructor, reallocation on assignment,
+!!     a structure-constructor component) has the same handle at another address.  It is recognised on its first use as an
+!!     inout argument and ADOPTS the handle (nlg_vec_adopt, include/neklab_gpu.h): if the original has been finalised in the
+!!     meantime -- `X = [X, v]` finalises the old X after the temporary has been built -- the copy simply becomes the owner
+!!     (no copy, no leak, no dangling pointer); if the original is alive, the copy gets a clone of its own.  A finaliser
+!!     therefore RELEASES its handle instead of destroying it; released buffers are freed by the library (oldest first above
+!!     nlg_vec_pool_limit, on allocation failure, at neklab_gpu_finalize).  move_alloc keeps the address: nothing to do.
+!!     What cannot be had: a copy READS through the original's handle until its first inout use, so it sees changes made
+!!     to the original in between (the reference's copies do not); copy, then modify the original, then read the copy is
+!!     the one sequence to avoid -- LightKrylov does not contain it;
 !!   * handles are created on first use, so `allocate(X(k))`, `intent(out)` dummies and `mold=` allocations cost nothing.
 !! A non-zero return code from the C ABI becomes `error stop` with nlg_last_error(), which is what stop_error does in the
 !! reference (src/neklab_nek_setup.f90:406-417); a wrong dynamic type calls type_error as the reference does.
@@ -30,6 +37,7 @@ module neklab_vectors
    type, extends(abstract_vector_rdp), public :: nek_dvector
       type(c_ptr) :: h = c_null_ptr
       integer(c_intptr_t) :: owner = 0
+      integer(c_int64_t) :: gen = 0
    contains
       private
       procedure, pass(self), public :: zero => nek_dzero
@@ -58,23 +66,37 @@ contains
    subroutine nek_dvector_ensure(self)
       class(nek_dvector), intent(inout) :: self
       type(c_ptr) :: hnew
+      integer(c_int) :: status
       if (.not. c_associated(self%h)) then
          call nlg_check(c_vec_create(nlg_mesh, int(nek_nscal, c_int), int(nek_lorder, c_int), self%h), 'nek_dvector allocate')
-         self%owner = loc(self)
-      else if (self%owner /= loc(self)) then
-         call nlg_check(c_vec_clone(self%h, hnew), 'nek_dvector copy-on-detect')
-         self%h = hnew
-         self%owner = loc(self)
+      else if (self%owner /= loc(self)) then      ! a bitwise copy: take over a released handle, clone a live one
+         call nlg_check(c_vec_adopt(self%h, self%gen, status), 'nek_dvector adopt')
+         if (status == 0) then
+            call nlg_check(c_vec_clone(self%h, hnew), 'nek_dvector copy-on-detect')
+            self%h = hnew
+         end if
+      else
+         return
       end if
+      self%owner = loc(self)
+      call nlg_check(c_vec_generation(self%h, self%gen), 'nek_dvector generation')
    end subroutine
 
    !> handle for a read-only use (a bitwise copy may read through the original's handle)
    function nek_dvector_handle(self) result(h)
       class(nek_dvector), intent(in) :: self
       type(c_ptr) :: h
+      integer(c_int64_t) :: gnow
       if (.not. c_associated(self%h)) then
          write (*, '(A)') 'ERROR in '//this_module//': use of a nek_dvector that holds no data yet'
          error stop 1
+      end if
+      if (self%owner /= loc(self)) then      ! a bitwise copy reads through the original's handle: it must still be that handle
+         call nlg_check(c_vec_generation(self%h, gnow), 'nek_dvector (bitwise copy whose original has been freed)')
+         if (gnow /= self%gen) then
+            write (*, '(A)') 'ERROR in '//this_module//': this nek_dvector is a bitwise copy of a vector that has been freed since'
+            error stop 1
+         end if
       end if
       h = self%h
    end function
@@ -97,8 +119,14 @@ contains
    !-----------------------------------------
    subroutine nek_dzero(self)
       class(nek_dvector), intent(inout) :: self
+      integer(c_int) :: status
       if (c_associated(self%h) .and. self%owner /= loc(self)) then      ! a bitwise copy about to be overwritten: no clone needed
-         self%h = c_null_ptr
+         call nlg_check(c_vec_adopt(self%h, self%gen, status), 'nek_dzero adopt')
+         if (status == 1) then
+            self%owner = loc(self)
+         else
+            self%h = c_null_ptr
+         end if
       end if
       call nek_dvector_ensure(self)
       call nlg_check(c_vec_zero(self%h), 'nek_dzero')
@@ -186,14 +214,11 @@ contains
       end select
    end subroutine
 
-   function dhas_rst_fields(self) result(has_rst_fields)
+   pure function dhas_rst_fields(self) result(has_rst_fields)      ! `pure` as in the reference (neklab_vectors.f90:107-110)
       class(nek_dvector), intent(in) :: self
       logical :: has_rst_fields
-      integer(c_int) :: flag
       has_rst_fields = .false.
-      if (.not. c_associated(self%h)) return
-      call nlg_check(c_vec_has_rst(self%h, flag), 'dhas_rst_fields')
-      has_rst_fields = flag /= 0
+      if (c_associated(self%h)) has_rst_fields = c_vec_has_rst_value(self%h) /= 0
    end function
 
    subroutine dclear_rst_fields(self)
@@ -206,28 +231,36 @@ contains
    subroutine assign_dvector(lhs, rhs)
       class(nek_dvector), intent(inout) :: lhs
       class(nek_dvector), intent(in) :: rhs
-      integer(c_int) :: rc
+      integer(c_int) :: rc, status
       if (loc(lhs) == loc(rhs)) return
-      if (c_associated(lhs%h) .and. lhs%owner /= loc(lhs)) lhs%h = c_null_ptr      ! lhs was a bitwise copy: drop the alias
+      if (c_associated(lhs%h) .and. lhs%owner /= loc(lhs)) then      ! lhs was a bitwise copy: own the handle or drop the alias
+         call nlg_check(c_vec_adopt(lhs%h, lhs%gen, status), 'nek_dvector assignment')
+         if (status == 1) then
+            lhs%owner = loc(lhs)
+         else
+            lhs%h = c_null_ptr
+         end if
+      end if
       if (.not. c_associated(rhs%h)) then      ! rhs holds nothing: lhs becomes empty too
-         if (c_associated(lhs%h)) rc = c_vec_destroy(lhs%h)
-         lhs%h = c_null_ptr; lhs%owner = 0
+         if (c_associated(lhs%h)) rc = c_vec_release(lhs%h)
+         lhs%h = c_null_ptr; lhs%owner = 0; lhs%gen = 0
          return
       end if
       if (c_associated(lhs%h)) then
-         if (c_associated(lhs%h, rhs%h)) return
+         if (c_associated(lhs%h, rhs%h)) return      ! rhs is a bitwise copy of lhs, which owns the handle: same data already
          call nlg_check(c_vec_copy(lhs%h, rhs%h), 'nek_dvector assignment')
       else
          call nlg_check(c_vec_clone(rhs%h, lhs%h), 'nek_dvector assignment')
-         lhs%owner = loc(lhs)
       end if
+      lhs%owner = loc(lhs)
+      call nlg_check(c_vec_generation(lhs%h, lhs%gen), 'nek_dvector assignment')
    end subroutine
 
    subroutine finalize_dvector(self)
       type(nek_dvector), intent(inout) :: self
       integer(c_int) :: rc
-      if (c_associated(self%h) .and. self%owner == loc(self)) rc = c_vec_destroy(self%h)
-      self%h = c_null_ptr; self%owner = 0
+      if (c_associated(self%h) .and. self%owner == loc(self)) rc = c_vec_release(self%h)      ! a bitwise copy may still adopt it
+      self%h = c_null_ptr; self%owner = 0; self%gen = 0
    end subroutine
 
    subroutine finalize_dvector_rank1(self)
@@ -235,8 +268,8 @@ contains
       integer :: i
       integer(c_int) :: rc
       do i = 1, size(self)
-         if (c_associated(self(i)%h) .and. self(i)%owner == loc(self(i))) rc = c_vec_destroy(self(i)%h)
-         self(i)%h = c_null_ptr; self(i)%owner = 0
+         if (c_associated(self(i)%h) .and. self(i)%owner == loc(self(i))) rc = c_vec_release(self(i)%h)
+         self(i)%h = c_null_ptr; self(i)%owner = 0; self(i)%gen = 0
       end do
    end subroutine
 

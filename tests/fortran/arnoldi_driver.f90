@@ -64,6 +64,25 @@ program arnoldi_driver
    call wrk%scal(2.0_dp)
    write (*, '(A,ES24.16)') 'ALIAS ', Xb(1)%norm()
    write (*, '(A,I0)') 'SIZE ', Xb(1)%get_size()
+   block      ! object lifetimes of the reference's by-value vectors: move_alloc, and reallocation on assignment -- where the old
+      !         elements are finalised AFTER the temporary holding their bitwise copies has been built (handle adoption)
+      type(nek_dvector), allocatable :: Y(:), Z(:)
+      type(nek_dvector) :: extra
+      real(dp) :: n1, n2
+      allocate (Y(2))
+      Y(1) = Xb(1); Y(2) = Xb(2)
+      call Y(2)%scal(3.0_dp)
+      n1 = Y(1)%norm(); n2 = Y(2)%norm()
+      call move_alloc(Y, Z)
+      call Z(1)%scal(1.0_dp)                  ! an inout use after the move: still the owner, nothing cloned
+      write (*, '(A,4ES24.16)') 'MOVE ', n1, n2, Z(1)%norm(), Z(2)%norm()
+      extra = Xb(1); call extra%scal(5.0_dp)
+      Z = [Z, extra]
+      call Z(1)%scal(2.0_dp)                  ! first inout use of a moved element: adopts the handle its old self released
+      call Z(3)%scal(2.0_dp)                  ! copy of the live `extra`: gets a clone, `extra` keeps its value
+      write (*, '(A,I0,4ES24.16)') 'REALLOC ', size(Z), Z(1)%norm(), Z(2)%norm(), Z(3)%norm(), extra%norm()
+      write (*, '(A,L1)') 'HASRST ', Z(1)%has_rst_fields()
+   end block
    deallocate (Xb, exptA, bf)
    call neklab_gpu_finalize()
 

@@ -8,6 +8,9 @@
 !!       /root/reference/src/linops/neklab_linops.f90:35-62, src/neklab_analysis.f90:84,98
 !!   zero_basis, eigs, save_eigenspectrum  as called at /root/reference/src/neklab_analysis.f90:77-90
 !!   type_error, stop_error (LightKrylov_Logger) as called at src/vectors/real_vectors.f90:202-204
+!!   abstract_system_rdp / abstract_jacobian_linop_rdp, newton, gmres_rdp : src/systems/neklab_systems.f90:42-55 (response,
+!!       %jacobian, %X), src/neklab_analysis.f90:186-192 (newton(sys, bf, gmres_rdp, info, atol=, options=, scheduler=))
+!!   svds(A, U, S, V, residuals, info, kdim=, write_intermediate=)  as called at src/neklab_analysis.f90:136
 !! `eigs` here is a plain Arnoldi iteration written against the ABSTRACT interfaces only -- k separate dot / axpby calls
 !! per Gram-Schmidt pass, exactly the loop structure LightKrylov imposes on neklab (SURVEY.md 3.1) -- with the Ritz values
 !! of the Hessenberg matrix from the library's dense helper.  It is test scaffolding for the drop-in boundary, not the
@@ -42,7 +45,8 @@ module LightKrylov
    private
    integer, parameter, public :: dp = real64
    real(dp), parameter, public :: rtol_dp = 1.4901161193847656e-08_dp, atol_dp = 1.0e-12_dp
-   public :: zero_basis, eigs, save_eigenspectrum, innerprod, type_error, stop_error
+   public :: zero_basis, eigs, svds, save_eigenspectrum, innerprod, type_error, stop_error, initialize_krylov_subspace
+   public :: newton, gmres_rdp
 
    type, abstract, public :: abstract_vector_rdp
    contains
@@ -102,6 +106,44 @@ module LightKrylov
       real(dp) :: tau = 1.0_dp
    end type
 
+   !> Jacobian of a nonlinear system about the state X (neklab_systems.f90:47-55: `self%X`)
+   type, abstract, extends(abstract_linop_rdp), public :: abstract_jacobian_linop_rdp
+      class(abstract_vector_rdp), allocatable :: X
+   end type
+
+   !> nonlinear system F(X) = 0 with its Jacobian (neklab_systems.f90:42-46: `response`; tsyphon.usr:38-40: `sys%jacobian`)
+   type, abstract, public :: abstract_system_rdp
+      class(abstract_jacobian_linop_rdp), allocatable :: jacobian
+   contains
+      procedure(abstract_response), pass(self), deferred, public :: response
+      procedure, pass(self), public :: finalize_timer => system_finalize_timer
+   end type
+
+   abstract interface
+      subroutine abstract_response(self, vec_in, vec_out, atol)
+         import abstract_system_rdp, abstract_vector_rdp, dp
+         class(abstract_system_rdp), intent(inout) :: self
+         class(abstract_vector_rdp), intent(in) :: vec_in
+         class(abstract_vector_rdp), intent(out) :: vec_out
+         real(dp), intent(in) :: atol
+      end subroutine
+      subroutine abstract_scheduler(tol, target_tol, rnorm, iter, info)
+         import dp
+         real(dp), intent(out) :: tol
+         real(dp), intent(in) :: target_tol, rnorm
+         integer, intent(in) :: iter
+         integer, intent(out) :: info
+      end subroutine
+      subroutine abstract_linear_solver(A, b, x, info, atol)
+         import abstract_linop_rdp, abstract_vector_rdp, dp
+         class(abstract_linop_rdp), intent(inout) :: A
+         class(abstract_vector_rdp), intent(in) :: b
+         class(abstract_vector_rdp), intent(inout) :: x
+         integer, intent(out) :: info
+         real(dp), intent(in) :: atol
+      end subroutine
+   end interface
+
    abstract interface
       subroutine abstract_matvec(self, vec_in, vec_out)
          import abstract_linop_rdp, abstract_vector_rdp
@@ -112,6 +154,13 @@ module LightKrylov
    end interface
 
    interface
+      function c_symtridiag_eig(n, d, e, Z) bind(C, name="nlg_symtridiag_eig") result(rc)
+         import c_int, c_double
+         integer(c_int), value :: n
+         real(c_double), intent(inout) :: d(*), e(*)
+         real(c_double), intent(out) :: Z(*)
+         integer(c_int) :: rc
+      end function
       function c_dense_eig(n, A, lda, wr, wi, vr, ldvr) bind(C, name="nlg_dense_eig") result(rc)
          import c_int, c_double
          integer(c_int), value :: n, lda, ldvr
@@ -144,6 +193,172 @@ contains
    subroutine linop_finalize_timer(self)
       class(abstract_linop_rdp), intent(inout) :: self
    end subroutine
+
+   subroutine system_finalize_timer(self)
+      class(abstract_system_rdp), intent(inout) :: self
+   end subroutine
+
+   subroutine initialize_krylov_subspace(X)
+      class(abstract_vector_rdp), intent(inout) :: X(:)
+      call zero_basis(X)
+   end subroutine
+
+   !> restarted GMRES(30) on A x = b from the x handed in, written against the abstract interfaces (Givens rotations, modified
+   !! Gram-Schmidt); stops at |r| < atol.  info = matvecs.
+   subroutine gmres_rdp(A, b, x, info, atol)
+      class(abstract_linop_rdp), intent(inout) :: A
+      class(abstract_vector_rdp), intent(in) :: b
+      class(abstract_vector_rdp), intent(inout) :: x
+      integer, intent(out) :: info
+      real(dp), intent(in) :: atol
+      integer, parameter :: kd = 30, maxcycle = 10
+      class(abstract_vector_rdp), allocatable :: V(:), w
+      real(dp) :: H(kd + 1, kd), cs(kd), sn(kd), g(kd + 1), y(kd), beta, t, d
+      integer :: k, i, j, cyc
+      info = 0
+      allocate (V(kd + 1), mold=b); allocate (w, mold=b)
+      do cyc = 1, maxcycle
+         call zero_basis(V)
+         call A%matvec(x, w); info = info + 1
+         call V(1)%add(b); call V(1)%sub(w)                 ! r = b - A x
+         beta = V(1)%norm()
+         if (beta < atol) return
+         call V(1)%scal(1.0_dp/beta)
+         H = 0.0_dp; g = 0.0_dp; g(1) = beta
+         k = 0
+         do j = 1, kd
+            call A%matvec(V(j), V(j + 1)); info = info + 1
+            do i = 1, j
+               H(i, j) = V(i)%dot(V(j + 1)); call V(j + 1)%axpby(-H(i, j), V(i), 1.0_dp)
+            end do
+            H(j + 1, j) = V(j + 1)%norm()
+            if (H(j + 1, j) > 0.0_dp) call V(j + 1)%scal(1.0_dp/H(j + 1, j))
+            do i = 1, j - 1
+               t = cs(i)*H(i, j) + sn(i)*H(i + 1, j); H(i + 1, j) = -sn(i)*H(i, j) + cs(i)*H(i + 1, j); H(i, j) = t
+            end do
+            d = hypot(H(j, j), H(j + 1, j)); cs(j) = H(j, j)/d; sn(j) = H(j + 1, j)/d
+            H(j, j) = d; H(j + 1, j) = 0.0_dp
+            g(j + 1) = -sn(j)*g(j); g(j) = cs(j)*g(j)
+            k = j
+            if (abs(g(j + 1)) < atol) exit
+         end do
+         do i = k, 1, -1
+            y(i) = (g(i) - dot_product(H(i, i + 1:k), y(i + 1:k)))/H(i, i)
+         end do
+         do i = 1, k
+            call x%axpby(y(i), V(i), 1.0_dp)
+         end do
+         if (abs(g(k + 1)) < atol) return
+      end do
+   end subroutine gmres_rdp
+
+   !> Newton iteration on sys%response(X) = 0: X <- X + dx with jacobian dx = -F(X) by `linear_solver`; the scheduler sets the
+   !! tolerance the residual and the linear solves are evaluated with (neklab_analysis.f90:186-192).  info = iterations, < 0: not converged.
+   subroutine newton(sys, X, linear_solver, info, atol, maxiter, scheduler)
+      class(abstract_system_rdp), intent(inout) :: sys
+      class(abstract_vector_rdp), intent(inout) :: X
+      procedure(abstract_linear_solver) :: linear_solver
+      integer, intent(out) :: info
+      real(dp), intent(in) :: atol
+      integer, optional, intent(in) :: maxiter
+      procedure(abstract_scheduler), optional :: scheduler
+      class(abstract_vector_rdp), allocatable :: r, dx
+      real(dp) :: tol, rnorm
+      integer :: it, nmax, sinfo, linfo
+      nmax = 40; if (present(maxiter)) nmax = maxiter
+      allocate (r, mold=X); allocate (dx, mold=X)
+      tol = atol
+      info = -1
+      do it = 0, nmax
+         call sys%response(X, r, tol)
+         rnorm = r%norm()
+         if (present(scheduler)) then
+            call scheduler(tol, atol, rnorm, it, sinfo)
+         end if
+         if (rnorm < atol) then
+            if (tol <= atol*(1.0_dp + 1.0e-12_dp)) then
+               info = it; return
+            end if
+            tol = atol; cycle                                ! converged at a loose solver tolerance: re-evaluate at the target
+         end if
+         if (it == nmax) exit
+         if (allocated(sys%jacobian%X)) deallocate (sys%jacobian%X)
+         allocate (sys%jacobian%X, source=X)
+         call dx%zero(); call r%scal(-1.0_dp)
+         call linear_solver(sys%jacobian, r, dx, linfo, 0.1_dp*max(rnorm, atol))
+         call X%add(dx)
+      end do
+   end subroutine newton
+
+   !> Golub-Kahan-Lanczos bidiagonalisation with full re-orthogonalisation through the abstract interfaces; singular values of
+   !! the bidiagonal matrix from the tridiagonal eigenproblem of B^T B (the structure of the device twin nlg_svds)
+   subroutine svds(A, U, S, V, residuals, info, kdim, tolerance, write_intermediate)
+      class(abstract_linop_rdp), intent(inout) :: A
+      class(abstract_vector_rdp), intent(inout) :: U(:), V(:)
+      real(dp), allocatable, intent(out) :: S(:), residuals(:)
+      integer, intent(out) :: info
+      integer, optional, intent(in) :: kdim
+      real(dp), optional, intent(in) :: tolerance
+      logical, optional, intent(in) :: write_intermediate
+      class(abstract_vector_rdp), allocatable :: Ub(:), Vb(:)
+      real(dp), allocatable :: al(:), be(:), d(:), e(:), Z(:), sig(:), res(:), p(:)
+      real(dp) :: tol, h
+      integer :: nsv, kd, k, i, j, pass, conv, src
+      nsv = size(U)
+      kd = 4*nsv; if (present(kdim)) kd = kdim
+      tol = rtol_dp; if (present(tolerance)) tol = tolerance
+      allocate (Ub(kd + 1), mold=U(1)); allocate (Vb(kd), mold=U(1))
+      call zero_basis(Ub); call zero_basis(Vb)
+      call Ub(1)%rand(.false.); h = Ub(1)%norm(); call Ub(1)%scal(1.0_dp/h)
+      allocate (al(kd), be(kd + 1)); al = 0.0_dp; be = 0.0_dp
+      info = 0
+      do k = 1, kd
+         call A%rmatvec(Ub(k), Vb(k))
+         do pass = 1, 2
+            do i = 1, k - 1
+               h = Vb(i)%dot(Vb(k)); call Vb(k)%axpby(-h, Vb(i), 1.0_dp)
+            end do
+         end do
+         al(k) = Vb(k)%norm(); call Vb(k)%scal(1.0_dp/al(k))
+         call A%matvec(Vb(k), Ub(k + 1))
+         do pass = 1, 2
+            do i = 1, k
+               h = Ub(i)%dot(Ub(k + 1)); call Ub(k + 1)%axpby(-h, Ub(i), 1.0_dp)
+            end do
+         end do
+         be(k + 1) = Ub(k + 1)%norm(); call Ub(k + 1)%scal(1.0_dp/be(k + 1))
+         info = info + 2
+         if (allocated(d)) deallocate (d, e, Z, sig, res)
+         allocate (d(k), e(k), Z(k*k), sig(k), res(k)); e = 0.0_dp
+         do i = 1, k
+            d(i) = al(i)**2; if (i < k) d(i) = d(i) + be(i + 1)**2
+            if (i > 1) e(i) = al(i)*be(i)
+         end do
+         if (c_symtridiag_eig(int(k, c_int), d, e, Z) /= 0) call stop_error('tridiagonal eigensolver failed', 'LightKrylov', 'svds')
+         conv = 0
+         do i = 1, k                                         ! descending singular values
+            src = k + 1 - i
+            sig(i) = sqrt(max(d(src), 0.0_dp))
+            res(i) = abs(be(k + 1)*Z((k - 1)*k + src))            ! Z row-major [component][eigenvector]
+            if (res(i) < tol) conv = conv + 1
+         end do
+         if (conv >= nsv .or. k == kd) exit
+      end do
+      k = min(k, kd)
+      allocate (S(nsv), residuals(nsv), p(k))
+      call zero_basis(U); call zero_basis(V)
+      do i = 1, min(nsv, k)
+         src = k + 1 - i
+         S(i) = sig(i); residuals(i) = res(i)
+         do j = 1, k
+            call V(i)%axpby(Z((j - 1)*k + src), Vb(j), 1.0_dp)
+         end do
+         do j = 1, k                                         ! p = B q / sigma
+            p(j) = al(j)*Z((j - 1)*k + src); if (j > 1) p(j) = p(j) + be(j)*Z((j - 2)*k + src)
+            call U(i)%axpby(p(j)/S(i), Ub(j), 1.0_dp)
+         end do
+      end do
+   end subroutine svds
 
    subroutine zero_basis(X)
       class(abstract_vector_rdp), intent(inout) :: X(:)

@@ -1,5 +1,6 @@
 """CPU suite: the C-ABI library loads, exports every declared symbol, and fails loudly without a GPU."""
 import ctypes as C
+import glob
 import os
 import re
 import subprocess
@@ -97,19 +98,23 @@ def test_mesh_generator_properties():
 
 
 def test_fortran_shim_compiles_against_the_abstract_types():
-    """amdflang builds the ISO_C_BINDING shim + the LightKrylov abstract-type stub + the demo driver."""
+    """amdflang builds the ISO_C_BINDING shim (neklab_amd/fortran) against the LightKrylov abstract-type stand-in, and the three
+    driver programs (tests/fortran)."""
     import shutil
     fdir = os.path.join(ROOT, "neklab_amd", "fortran")
+    tdir = os.path.join(ROOT, "tests", "fortran")
     if not (shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang")):
         pytest.skip("no Fortran compiler")
     from neklab_amd import build
     build.build_library()
-    r = subprocess.run(["make", "-s", "-C", fdir], capture_output=True, text=True)
+    r = subprocess.run(["make", "-s", "-C", tdir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert os.path.exists(os.path.join(fdir, "_build", "arnoldi_driver"))
-    assert os.path.exists(os.path.join(fdir, "_build", "stability_driver"))
+    for exe in ("arnoldi_driver", "stability_driver", "tsyphon_driver"):
+        assert os.path.exists(os.path.join(tdir, "_build", exe))
+    # nothing of the scaffolding lives in the product directory
+    assert not os.path.exists(os.path.join(fdir, "lightkrylov_stub.f90")) and not glob.glob(os.path.join(fdir, "*driver*.f90"))
     # the modules carry the reference's names (src/neklab_analysis.f90:16-18 `use`s them unchanged)
-    for mod in ("neklab_vectors", "neklab_linops", "neklab_utils", "neklab_analysis", "neklab"):
+    for mod in ("neklab_vectors", "neklab_linops", "neklab_utils", "neklab_systems", "neklab_analysis", "neklab"):
         assert re.search(r"^\s*module\s+%s\b" % mod, open(os.path.join(fdir, mod + ".f90")).read(), re.M | re.I), mod
     # every C symbol the shim binds is declared in the header
     txt = open(os.path.join(fdir, "neklab_gpu_capi.f90")).read()

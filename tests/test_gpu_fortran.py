@@ -1,4 +1,5 @@
-"""The Fortran 2008 shim (neklab_amd/fortran) driven like LightKrylov would drive it, on the GPU."""
+"""The Fortran 2008 shim (neklab_amd/fortran) driven like LightKrylov would drive it, on the GPU (drivers and the LightKrylov
+stand-in: tests/fortran)."""
 import os
 import subprocess
 import tempfile
@@ -10,7 +11,7 @@ from neklab_amd import host
 from neklab_amd.mesh import box_mesh
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FDIR = os.path.join(ROOT, "neklab_amd", "fortran")
+FDIR = os.path.join(ROOT, "tests", "fortran")
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +38,7 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
     r = subprocess.run([exe], cwd=tmp, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     H = np.zeros((kdim + 1, kdim))
-    alias = size = None
+    alias = size = move = realloc = None
     for ln in r.stdout.splitlines():
         p = ln.split()
         if p and p[0] == "H":
@@ -46,6 +47,10 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
             alias = float(p[1])
         elif p and p[0] == "SIZE":
             size = int(p[1])
+        elif p and p[0] == "MOVE":
+            move = [float(v) for v in p[1:]]
+        elif p and p[0] == "REALLOC":
+            realloc = [float(v) for v in p[1:]]
     # same computation through the C ABI's block path
     gb = host.nek_dvector(gm)
     for i in range(2):
@@ -60,11 +65,17 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
     assert np.max(np.abs(H - Href)) < 1e-9 * np.max(np.abs(Href))
     assert abs(alias - 1.0) < 1e-12          # wrk = X(1); wrk%scal(2) must not touch X(1)
     assert size == x0.get_size()
+    # move_alloc keeps the handles; Z = [Z, extra] moves the elements (their old selves are finalised after the temporary was
+    # built): values survive, the moved element adopts its released handle, the copy of a live vector gets a clone
+    n1, n2 = move[0], move[1]
+    assert abs(n1 - 1.0) < 1e-12 and abs(n2 - 3.0) < 1e-12 and abs(move[2] - n1) < 1e-12 and abs(move[3] - n2) < 1e-12
+    assert realloc[0] == 3 and abs(realloc[1] - 2.0 * n1) < 1e-12 and abs(realloc[2] - n2) < 1e-12
+    assert abs(realloc[3] - 10.0) < 1e-12 and abs(realloc[4] - 5.0) < 1e-12
 
 
 @pytest.mark.parametrize("device_eigs", [0, 1])
 def test_fortran_stability_driver_is_the_reference_call_sequence(gpu_ctx, device_eigs):
-    """neklab_amd/fortran/stability_driver.f90 = the userchk of 1cyl.usr:13-24 + linear_stability_analysis_fixed_point
+    """tests/fortran/stability_driver.f90 = the userchk of 1cyl.usr:13-24 + linear_stability_analysis_fixed_point
     (neklab_analysis.f90:77-93) with the reference's module names: `use neklab`, nek2vec / vec2nek, the positional
     constructor exptA_linop(tau, bf), init(), eigs, log(mu)/tau, save_eigenspectrum, outpost_dnek.  device_eigs = 0 runs
     LightKrylov's loop structure (stand-in) through the type-bound procedures, 1 the device block path (nlg_eigs)."""
@@ -151,3 +162,53 @@ def test_outpost_matches_python_writer(gpu_ctx, tmp_path):
                 assert np.array_equal(fa[key], fb[key])
             # pressure on the velocity mesh: interpolated on the device here, with numpy there
             assert np.max(np.abs(fa["p"] - fb["p"])) < 1e-13 * np.max(np.abs(fb["p"]))
+
+
+def test_fortran_thermosyphon_call_sequence(gpu_ctx):
+    """tests/fortran/tsyphon_driver.f90 = the userchk of examples/thermosyphon/baseflow/tsyphon.usr:29-70 with the reference's names:
+    nek_system_temp / nek_jacobian_temp, newton_fixed_point_iteration(sys, bf, tol, tol_mode = 2), exptA_linop_temp(tau, bf),
+    eigs through LightKrylov's loop structure (stand-in).  A heated box below the onset of convection: Newton must return to the
+    conduction state from a perturbed guess, and the spectrum of the temperature-coupled propagator about it must be the one the
+    C ABI gives through the Python mirror."""
+    subprocess.run(["make", "-s", "-C", FDIR], check=True)
+    exe = os.path.join(FDIR, "_build", "tsyphon_driver")
+    hm = box_mesh((4, 3), 6, lengths=(2.0158, 1.0), periodic=(True, False), deform=0.0)
+    kdim, nev, tau, re, vtol, ptol = 20, 2, 0.2, 1.0, 1e-11, 1e-11
+    cond, rhocp, buoy, endtime, tol = 1.0, 1.0, (0.0, 500.0, 0.0), 0.2, 1e-8
+    k = 2.0 * np.pi / 2.0158
+    T0 = 1.0 - hm.y
+    guess_t = T0 + 0.05 * hm.tmask * np.sin(np.pi * hm.y) * np.cos(k * hm.x)
+    guess_u = [1e-3 * hm.mask[0] * np.sin(k * hm.x) * np.cos(np.pi * hm.y), 1e-3 * hm.mask[1] * np.cos(k * hm.x) * np.sin(np.pi * hm.y)]
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "case.bin"), "wb") as f:
+        np.array([2, 6, hm.E, kdim, nev, 0], dtype=np.int32).tofile(f)
+        np.array([tau, re, vtol, ptol, cond, rhocp, *buoy, endtime, tol], dtype=np.float64).tofile(f)
+        for a in (hm.x, hm.y):
+            a.astype(np.float64).tofile(f)
+        hm.glo_num.astype(np.int64).tofile(f)
+        for a in (hm.mask[0], hm.mask[1], hm.tmask, guess_u[0], guess_u[1], guess_t):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    r = subprocess.run([exe], cwd=tmp, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.split()}
+    assert float(out["FNORM"][0]) < 10 * tol, out
+    umax, vmax, tmax = (float(v) for v in out["BFMAX"])
+    assert umax < 1e-6 and vmax < 1e-6 and abs(tmax - 1.0) < 1e-6, out          # the conduction state
+    from neklab_amd import nekio
+    bf = nekio.read_fld(os.path.join(tmp, "BF_neklab0.f00001"))
+    assert np.max(np.abs(bf["t"] - T0)) < 1e-6
+    assert os.path.exists(os.path.join(tmp, "nwtneklab0.f00001"))
+    # the same spectrum through the Python mirror, about the exact conduction state
+    gm = host.Mesh(gpu_ctx, hm)
+    gb = host.nek_dvector(gm, 1)
+    gb.set_field(host.THETA, T0)
+    A = host.exptA_linop(tau, gb, re=re, torder=3, vtol=vtol, ptol=ptol, maxit_v=600, maxit_p=4000, ifheat=1, conductivity=cond, rhocp=rhocp,
+                         buoy=buoy, dt=0.02)
+    A.init()
+    X = [host.nek_dvector(gm, 1) for _ in range(nev)]
+    mu, res, info = host.eigs(A, X, kdim=40, write_intermediate=False, seed=3)
+    lam = np.log(mu.astype(complex)) / tau
+    spec = np.load(os.path.join(tmp, "dir_eigenspectrum.npy"))
+    flam = spec[:, 0] + 1j * spec[:, 1]
+    assert spec.shape == (nev, 3)
+    assert lam[0].real < 0 and abs(flam[0] - lam[0]) < 1e-5 * abs(lam[0]), (flam, lam)
