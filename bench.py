@@ -6,8 +6,8 @@ launcher (WORLD_SIZE unset) and with N > 1 it starts the N rank processes itself
 before anything in this process touches the GPU) and relays rank 0's line.
 
 Scaling (`--scaling`): "strong" (default, BASELINE.json configs[2] "1 GPU vs 8 GPU element-partitioned") -- ONE global
-problem of E = 10 000 elements split into N contiguous element blocks; "weak" -- every GPU holds an E-element block of an
-N-times larger box.  In both, `value` is matvecs per second of the GLOBAL operator.
+problem of E = 10 000 elements split into N sub-boxes by recursive coordinate bisection; "weak" -- every GPU holds an
+E-element block of an N-times larger box.  In both, `value` is matvecs per second of the GLOBAL operator.
 
 A "step" is one Arnoldi iteration at full basis size on BASELINE.json's headline configuration
 (configs[2]: 3-D, E = 10 000 = 25x20x20 spectral elements, N = 7 i.e. lx1 = 8, Krylov dimension m = 64):
@@ -42,7 +42,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
-                    help="strong: the global --nel box is split into N contiguous element blocks; weak: every rank holds "
+                    help="strong: the global --nel box is split into N sub-boxes (recursive coordinate bisection); weak: every rank holds "
                          "a --nel block of an N times larger box")
     ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
                     help="shm: REHEARSAL of the N>1 path with all ranks on GPU 0 through the library's shared-memory "
@@ -144,24 +144,28 @@ def main():
 
     # ---- synthetic inputs: deformed box, wall-masked, C0 noise on a smooth shear flow
     t0 = time.time()
-    # Every rank generates only its own contiguous element block (Nek5000's block distribution: whole layers of the
-    # last direction) with the labels and element ids of the global mesh.  Shared faces are exchanged by the library's
-    # gather-scatter halo (RCCL send/recv); every reduction is a RCCL all-reduce.
-    # strong: the global box is --nel, its layers are dealt out as evenly as they divide (20 layers on 8 ranks: 3,3,3,3,
-    # 2,2,2,2); weak: the global box is `world` copies of --nel stacked in the last direction.
+    # Every rank generates only its own sub-box of elements with the labels and element ids of the global mesh.  Shared faces
+    # are exchanged by the library's gather-scatter halo (RCCL send/recv); every reduction is a RCCL all-reduce.
+    # strong: the global box is --nel, partitioned by recursive coordinate bisection; weak: the global box is `world` copies
+    # of --nel stacked in the last direction.
     if args.scaling == "strong":
+        # recursive coordinate bisection of the ONE global box: 25 x 20 x 20 on 8 ranks = 2 x 2 x 2 sub-boxes of
+        # 12|13 x 10 x 10 elements (max / mean 1.04, at most 3 face neighbours + edges / corners) instead of slabs of z layers
+        # (3,3,3,3,2,2,2,2 of 20: max / mean 1.2 and 2 x 500 element faces of halo per rank)
+        from neklab_amd.mesh import rcb_boxes
         gnel = nel
-        if nel[-1] < world:
-            raise SystemExit("bench.py: strong scaling splits the %d element layers of the last direction; %d ranks "
-                             "are too many" % (nel[-1], world))
-        base, rem = divmod(nel[-1], world)
-        k0 = rank * base + min(rank, rem)
-        k1 = k0 + base + (1 if rank < rem else 0)
+        try:
+            boxes = rcb_boxes(gnel, world)
+        except ValueError as exc:
+            raise SystemExit("bench.py: %s" % exc)
+        my_box = boxes[rank]
+        part_sizes = [int(np.prod([b - a for a, b in bx])) for bx in boxes]
     else:
         gnel = tuple(nel[:-1]) + (nel[-1] * world,)
-        k0, k1 = rank * nel[-1], (rank + 1) * nel[-1]
+        my_box = tuple((0, e) for e in nel[:-1]) + ((rank * nel[-1], (rank + 1) * nel[-1]),)
+        part_sizes = [E] * world
     E_global = int(np.prod(gnel))
-    hm = box_mesh(gnel, n, deform=0.05, last_range=(k0, k1))
+    hm = box_mesh(gnel, n, deform=0.05, ranges=my_box)
     E = hm.E                                   # local element count from here on
     gm = host.Mesh(ctx, hm)
     bf = host.nek_dvector(gm)
@@ -383,7 +387,8 @@ def main():
                                    "nsteps=%d(+2 history steps), tol 1e-9/1e-7, one Arnoldi iteration per step at k=m"
                                    % (E_global, "x".join(map(str, gnel)), n, n - 1, m, args.re, args.nsteps),
                        "vectors_per_step": sblk,
-                       "elements_per_gpu": E_global / world, "time_steps_per_matvec": steps_per_mv / sblk,
+                       "elements_per_gpu": E_global / world, "partition": "rcb" if args.scaling == "strong" else "stacked",
+                       "partition_sizes": part_sizes, "time_steps_per_matvec": steps_per_mv / sblk,
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,
                        # kernel launches and collective sites (all-reduce, all-gather, gather-scatter / Schwarz halo exchanges; counted on
                        # one rank too) per step, and per vector of a block step
@@ -404,7 +409,7 @@ def main():
                        "arnoldi_orthogonalisation_ms_at_k=m": None if u3_ms is None else round(u3_ms, 3),
                        "arnoldi_orthogonalisation_ms_vs_k": u3_vs_k,
                        "block_arnoldi": blk,
-                       "parallelism": "1 process per GPU, contiguous element blocks, RCCL all-reduce for every reduction, "
+                       "parallelism": "1 process per GPU, recursive-coordinate-bisection element blocks, RCCL all-reduce for every reduction, "
                                       "RCCL send/recv halo for the gather-scatter"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -251,6 +251,7 @@ struct nlg_pprec {
     // lanes of a block step: `lanes_cap` copies of W, tq, rc / x, ra, xa at these strides (pprec_reserve_lanes)
     int lanes_cap = 1;
     int64_t lW = 0, lt = 0, lv = 0, la = 0, la_x = 0;
+    bool coarse_pending = false;                 // pprec_coarse has left its chain (gather, restriction, dense solve) to the merged launches of pprec_fine
 };
 
 struct nlg_mesh {

@@ -215,6 +215,30 @@ __global__ __launch_bounds__(NT) void k_fdm(const double *__restrict__ flag, int
     }
 }
 
+// aggregate restriction of the coarse chain as a device function: it rides in the launch of k_fdm_ext (merged launches, below)
+struct AggArgs {
+    int na;
+    const int *ap, *am;
+    const double *rr;
+    double *ra;
+    int64_t lv, la;
+};
+// (as a part of a merged launch: `bx` = block index inside this part, any multiple of 64 threads per block)
+__device__ __forceinline__ void agg_restrict_body(int bx, const double *flag, int64_t ld, const AggArgs &g) {
+    if (flag) flag += (int64_t)blockIdx.y * ld;
+    if (flag && flag[0] != 0.0) return;
+    const double *rr = g.rr + (int64_t)blockIdx.y * g.lv;
+    double *ra = g.ra + (int64_t)blockIdx.y * g.la;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int a = bx * wpb + wid;
+    if (a >= g.na) return;
+    double s = 0.0;
+    for (int q = g.ap[a] + lane; q < g.ap[a + 1]; q += 64) s += rr[g.am[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) ra[a] = s;
+}
+
 // ---- overlapping variant (3-D) ---------------------------------------------------------------------------
 // Extended local problems: element e plus the layer of GL points of each face neighbour that is adjacent to the
 // shared face -> an N^3 grid (N = N2 + 2, the size of the velocity mesh), solved by fast diagonalisation with 1-D
@@ -239,10 +263,14 @@ template <int N, int WPB, int WPE = 1>
 __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                 const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                 const double *__restrict__ wq, double *__restrict__ W,
-                                                double *__restrict__ z, const int *__restrict__ tab, int64_t ld, int64_t lW) {
+                                                double *__restrict__ z, const int *__restrict__ tab, int64_t ld, int64_t lW, int nb_fdm, AggArgs ag) {
     constexpr int N2 = N - 2, NP = N * N * N, NP2 = N2 * N2 * N2;
     __shared__ double sL[WPB][3][N];
     __shared__ double sA[WPB][NP];   // the six transforms run in place (fdm_stage_inplace3)
+    if ((int)blockIdx.x >= nb_fdm) {   // merged launch: the blocks behind the elements restrict the coarse residual to the aggregates
+        agg_restrict_body((int)blockIdx.x - nb_fdm, flag, ld, ag);
+        return;
+    }
     {   // blockIdx.y = lane of a block step
         const int64_t lo = (int64_t)blockIdx.y * ld;
         if (flag) flag += lo;
@@ -776,6 +804,28 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
 
 // rc[v] = sum of t over the (element, corner) entries incident to vertex v (fixed order), and the first damped-Jacobi
 // sweep from a zero guess
+struct GatherArgs {
+    int nvert;
+    const int *vp, *vi;
+    const double *t;
+    double *rc;
+    const double *dinv;
+    double om;
+    double *x;
+    int64_t lt, lv;
+};
+__device__ __forceinline__ void q1_gather_body(int bx, const double *flag, int64_t ld, const GatherArgs &g) {
+    if (flag) flag += (int64_t)blockIdx.y * ld;
+    if (flag && flag[0] != 0.0) return;
+    const double *t = g.t + (int64_t)blockIdx.y * g.lt;
+    double *rc = g.rc + (int64_t)blockIdx.y * g.lv, *x = g.x + (int64_t)blockIdx.y * g.lv;
+    const int v = bx * NT + threadIdx.x;
+    if (v >= g.nvert) return;
+    double a = 0.0;
+    for (int q = g.vp[v]; q < g.vp[v + 1]; ++q) a += t[g.vi[q]];
+    rc[v] = a;
+    x[v] = g.om * g.dinv[v] * a;
+}
 __global__ __launch_bounds__(NT) void k_q1_gather(const double *__restrict__ flag, int nvert, const int *__restrict__ vp,
                                                   const int *__restrict__ vi, const double *__restrict__ t,
                                                   double *__restrict__ rc, const double *__restrict__ dinv, double om,
@@ -884,47 +934,115 @@ __global__ __launch_bounds__(NT) void k_agg_restrict(const double *flag, int na,
 // needs no more than single precision, and the symmetric matrix is rounded entry by entry, so it stays symmetric
 // across the ranks that hold its rows; sums in double.
 template <typename T>
-__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, int ncols, const T *__restrict__ Ainv,
-                                                   const double *__restrict__ ra, double *__restrict__ xa, int64_t ld = 0, int64_t la = 0,
-                                                   int na_max = 0, int nlanes = 1) {
-    // lanes of a block step (blockIdx.y): one rank -- ra, xa la doubles apart; several ranks -- ra is the all-gathered array
-    // [rank][lane][na_max] (na_max > 0), column c of the global aggregate level = entry c % na_max of rank c / na_max
+struct GemvArgs {
+    int na, ncols;
+    const T *Ainv;
+    const double *ra;
+    double *xa;
+    int64_t la;
+    int na_max, nlanes;
+};
+// lanes of a block step (blockIdx.y): one rank -- ra, xa la doubles apart; several ranks -- ra is the all-gathered array
+// [rank][lane][na_max] (na_max > 0), column c of the global aggregate level = entry c % na_max of rank c / na_max
+template <typename T>
+__device__ __forceinline__ void dense_gemv_body(int bx, const double *flag, int64_t ld, const GemvArgs<T> &g) {
     if (flag) flag += (int64_t)blockIdx.y * ld;
-    xa += (int64_t)blockIdx.y * la;
-    if (na_max == 0) ra += (int64_t)blockIdx.y * la;
     if (flag && flag[0] != 0.0) return;
+    double *xa = g.xa + (int64_t)blockIdx.y * g.la;
+    const double *ra = g.na_max == 0 ? g.ra + (int64_t)blockIdx.y * g.la : g.ra;
+    const int na = g.na, ncols = g.ncols;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wid;
+    const int row = bx * 4 + wid;
     if (row >= na) return;
-    if (na_max > 0 && nlanes > 1) {   // (strided gather of the lane's entries; set-up sizes: a few thousand columns)
-        double s = 0.0;
-        const T *__restrict__ Ar = Ainv + (size_t)row * ncols;
-        for (int j = lane; j < ncols; j += 64)
-            s += (double)Ar[j] * ra[((int64_t)(j / na_max) * nlanes + blockIdx.y) * na_max + j % na_max];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) xa[row] = s;
-        return;
-    }
-    // eight loads of the row in flight per lane (same summation order as the plain loop: the products are added one after the
-    // other); a wave per row gives only ~1.3 waves per SIMD at 1300 rows, so the loads of one wave must overlap themselves
+    const T *__restrict__ Ar = g.Ainv + (size_t)row * ncols;
     double s = 0.0;
-    const T *__restrict__ Ar = Ainv + (size_t)row * ncols;
-    int j = lane;
-    for (; j + 7 * 64 < ncols; j += 8 * 64) {
-        double av[8], rv[8];
+    if (g.na_max > 0 && g.nlanes > 1) {   // (strided gather of the lane's entries; set-up sizes: a few thousand columns)
+        for (int j = lane; j < ncols; j += 64)
+            s += (double)Ar[j] * ra[((int64_t)(j / g.na_max) * g.nlanes + blockIdx.y) * g.na_max + j % g.na_max];
+    } else {
+        // eight loads of the row in flight per lane (same summation order as the plain loop: the products are added one after the
+        // other); a wave per row gives only ~1.3 waves per SIMD at 1300 rows, so the loads of one wave must overlap themselves
+        int j = lane;
+        for (; j + 7 * 64 < ncols; j += 8 * 64) {
+            double av[8], rv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            av[u] = (double)Ar[j + 64 * u];
-            rv[u] = ra[j + 64 * u];
+            for (int u = 0; u < 8; ++u) {
+                av[u] = (double)Ar[j + 64 * u];
+                rv[u] = ra[j + 64 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += av[u] * rv[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += av[u] * rv[u];
+        for (; j < ncols; j += 64) s += (double)Ar[j] * ra[j];
     }
-    for (; j < ncols; j += 64) s += (double)Ar[j] * ra[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) xa[row] = s;
+}
+// xa = Ainv ra (dense, row-major), one wave per row.  T = float for the global aggregate level of several ranks: the
+// rows of the inverse are the largest per-iteration read there (2.4k x 19.6k at 8 x 10^4 elements), a preconditioner
+// needs no more than single precision, and the symmetric matrix is rounded entry by entry, so it stays symmetric
+// across the ranks that hold its rows; sums in double.
+template <typename T>
+__global__ __launch_bounds__(NT) void k_dense_gemv(const double *flag, int na, int ncols, const T *__restrict__ Ainv,
+                                                   const double *__restrict__ ra, double *__restrict__ xa, int64_t ld = 0, int64_t la = 0,
+                                                   int na_max = 0, int nlanes = 1) {
+    const GemvArgs<T> g = {na, ncols, Ainv, ra, xa, la, na_max, nlanes};
+    dense_gemv_body<T>((int)blockIdx.x, flag, ld, g);
+}
+
+// ---- merged launches: the coarse-grid chain rides in the launches of the fine level --------------------------------------
+// The vertex gather, the aggregate restriction and the dense solve are tiny (5 - 8 us each, one after the other); the three
+// fine-level launches they interleave with are independent of them.  One launch = the blocks of the fine kernel followed by the
+// blocks of a coarse kernel (block-uniform branch on blockIdx.x): the coarse work runs beside the fine work on otherwise idle
+// CUs and its three launches -- and their start-up latency on the stream -- disappear.
+// (a) pairs-only gather-scatter of the exchange array W + vertex gather
+__device__ __forceinline__ void pairs_body(int64_t bx, const int *__restrict__ idx, int64_t npairs, double *__restrict__ w,
+                                           const double *__restrict__ gate, int64_t ldw, int64_t ldg) {
+    if (gate && gate[(int64_t)blockIdx.y * ldg] != 0.0) return;
+    w += (int64_t)blockIdx.y * ldw;
+    const int64_t t = bx * (int64_t)NT + threadIdx.x;
+    const int64_t np2 = npairs >> 1;
+    if (t < np2) {
+        const int4 q = reinterpret_cast<const int4 *>(idx)[t];
+        if (q.z == q.x + 1 && q.w == q.y + 1 && !((q.x | q.y) & 1)) {
+            const double2 a = *reinterpret_cast<const double2 *>(w + q.x), b = *reinterpret_cast<const double2 *>(w + q.y);
+            double2 sv;
+            sv.x = a.x + b.x;
+            sv.y = a.y + b.y;
+            *reinterpret_cast<double2 *>(w + q.x) = sv;
+            *reinterpret_cast<double2 *>(w + q.y) = sv;
+        } else {
+            const double s0 = w[q.x] + w[q.y], s1 = w[q.z] + w[q.w];
+            w[q.x] = s0;
+            w[q.y] = s0;
+            w[q.z] = s1;
+            w[q.w] = s1;
+        }
+        return;
+    }
+    const int64_t g = 2 * np2 + (t - np2);
+    if (g >= npairs) return;
+    const int2 ab = reinterpret_cast<const int2 *>(idx)[g];
+    const double sv = w[ab.x] + w[ab.y];
+    w[ab.x] = sv;
+    w[ab.y] = sv;
+}
+__global__ __launch_bounds__(NT) void k_pairs_gather(int nb_pairs, const int *__restrict__ idx, int64_t npairs, double *__restrict__ w,
+                                                     int64_t ldw, const double *__restrict__ flag, int64_t ld, GatherArgs g) {
+    if ((int)blockIdx.x < nb_pairs)
+        pairs_body(blockIdx.x, idx, npairs, w, flag, ldw, ld);
+    else
+        q1_gather_body((int)blockIdx.x - nb_pairs, flag, ld, g);
+}
+// (c) the second pairs-only gather-scatter + the dense aggregate solve
+template <typename T>
+__global__ __launch_bounds__(NT) void k_pairs_gemv(int nb_pairs, const int *__restrict__ idx, int64_t npairs, double *__restrict__ w,
+                                                   int64_t ldw, const double *__restrict__ flag, int64_t ld, GemvArgs<T> g) {
+    if ((int)blockIdx.x < nb_pairs)
+        pairs_body(blockIdx.x, idx, npairs, w, flag, ldw, ld);
+    else
+        dense_gemv_body<T>((int)blockIdx.x - nb_pairs, flag, ld, g);
 }
 
 __global__ void k_to_float(int64_t n, const double *__restrict__ a, float *__restrict__ b) {
@@ -1844,6 +1962,14 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
     } else {
         NLG_LAUNCH(k_q1_restrict_local<2>, gq, dim3(NT), 0, st, flag, E, m->n2, hat, rw, P.d_tq, Wp, (const double *)P.d_wq, uu, ld, P.lt, P.lW);
     }
+    // 3-D overlapping variant: the rest of the coarse chain rides in the launches of the fine level (pprec_fine, merged launches)
+    static const bool hfuse = !(getenv("NLG_HFUSE") && atoi(getenv("NLG_HFUSE")) == 0);
+    P.coarse_pending = hfuse && overlap && m->dim == 3 && m->gs.d_indices_fg && m->gs.npairs > 0;
+    if (P.coarse_pending) {
+        NLG_HIP(hipGetLastError());
+        *xc = P.d_x;
+        return 0;
+    }
     NLG_LAUNCH(k_q1_gather, dim3((nv + NT - 1) / NT, nl), dim3(NT), 0, st, flag, nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, om, P.d_x, ld, P.lt, P.lv);
     NLG_LAUNCH(k_agg_restrict, dim3((P.na + 3) / 4, nl), dim3(NT), 0, st, flag, P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra, ld, P.lv, P.la);
     const double *ra = P.d_ra;
@@ -1933,19 +2059,55 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         // pprec_coarse has packed the adjacent layers into P.d_W (same stream)
         NLG_CHECK(P.overlap && m->dim == 3, "pprec: the overlapping variant is not set up for this mesh");
         const dim3 gb((unsigned)((E + 3) / 4), (unsigned)nl);
-        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag, nl, P.lW, ld));
+        const bool fused = P.coarse_pending;   // set by pprec_coarse: the coarse chain is still to run
+        P.coarse_pending = false;
+        const int nbp = (int)((m->gs.npairs + NT - 1) / NT);
+        const int nv = P.nvert;
+        const bool glob = P.ncols != P.na;
+        AggArgs ag = {0, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        int nb_agg = 0;
+        if (fused) {
+            // (a) pairs-only gather-scatter of W + vertex gather of the element-corner residuals
+            const GatherArgs gg = {nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, P.na == nv ? 0.0 : 0.7, P.d_x, P.lt, P.lv};
+            NLG_LAUNCH(k_pairs_gather, dim3((unsigned)(nbp + (nv + NT - 1) / NT), (unsigned)nl), dim3(NT), 0, st, nbp, (const int *)m->gs.d_indices_fg,
+                       m->gs.npairs, P.d_W, P.lW, flag, ld, gg);
+            ag = AggArgs{P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra, P.lv, P.la};
+        } else {
+            NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag, nl, P.lW, ld));
+        }
         NLG_TRY(overlap_halo(m, st, true, nl));
 #define FX_CASE(N_)                                                                                                   \
     case N_: {                                                                                                        \
         constexpr int WPE_ = (N_ * N_ + 63) / 64;   /* one column per lane: 1 wave up to lx1 = 8, 2 at 9 / 10, 3 at 12 */ \
-        NLG_LAUNCH((k_fdm_ext<N_, 1, WPE_>), dim3((unsigned)E, (unsigned)nl), dim3(64 * WPE_), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab, ld, P.lW); \
+        nb_agg = fused ? (P.na + WPE_ - 1) / WPE_ : 0;   /* (b) + aggregate restriction: one wave per aggregate */     \
+        NLG_LAUNCH((k_fdm_ext<N_, 1, WPE_>), dim3((unsigned)(E + nb_agg), (unsigned)nl), dim3(64 * WPE_), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab, ld, P.lW, (int)E, ag); \
     } break;
         switch (m->n) {
             FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(12)
             default: set_error("pprec: overlapping variant built for lx1 = 4..10 and 12, got %d", m->n); return 1;
         }
 #undef FX_CASE
-        NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag, nl, P.lW, ld));
+        if (fused) {
+            const double *ra = P.d_ra;
+            int na_max = 0;
+            if (glob) {   // several ranks: the aggregate level is global; ONE all-gather carries the lanes of every rank
+                NLG_CHECK(st == m->ctx->stream, "pprec: the global aggregate level runs on the context's stream");
+                NLG_TRY(allgather_f64(m->ctx, P.d_ra, P.d_rag, (int64_t)P.na_max * nl));
+                ra = P.d_rag;
+                na_max = nl > 1 ? P.na_max : 0;
+            }
+            // (c) second pairs-only gather-scatter of W + dense aggregate solve
+            const dim3 gc((unsigned)(nbp + (P.na + 3) / 4), (unsigned)nl);
+            if (P.d_Ainv32) {
+                const GemvArgs<float> gv = {P.na, P.ncols, (const float *)P.d_Ainv32, ra, P.d_xa, glob ? P.la_x : P.la, na_max, nl};
+                NLG_LAUNCH(k_pairs_gemv<float>, gc, dim3(NT), 0, st, nbp, (const int *)m->gs.d_indices_fg, m->gs.npairs, P.d_W, P.lW, flag, ld, gv);
+            } else {
+                const GemvArgs<double> gv = {P.na, P.ncols, (const double *)P.d_Ainv, ra, P.d_xa, glob ? P.la_x : P.la, na_max, nl};
+                NLG_LAUNCH(k_pairs_gemv<double>, gc, dim3(NT), 0, st, nbp, (const int *)m->gs.d_indices_fg, m->gs.npairs, P.d_W, P.lW, flag, ld, gv);
+            }
+        } else {
+            NLG_TRY(sem_gs_pairs_fg(m, P.d_W, flag, nl, P.lW, ld));
+        }
         NLG_TRY(overlap_halo(m, st, true, nl));
 #define FF_CASE(N_)                                                                                                   \
     case N_:                                                                                                          \

@@ -92,7 +92,7 @@ class BoxMesh:
 def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
              periodic: Sequence[bool] | None = None, deform: float = 0.05,
              origin: Sequence[float] | None = None, outflow_xmax: bool = False,
-             last_range: Sequence[int] | None = None) -> BoxMesh:
+             last_range: Sequence[int] | None = None, ranges: Sequence[Sequence[int]] | None = None) -> BoxMesh:
     """Structured, smoothly deformed box of `prod(nel)` elements with `n` GLL points/direction.
 
     Elements are numbered lexicographically (x fastest) so that contiguous element blocks are
@@ -101,6 +101,8 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
     `last_range=(k0, k1)` generates only the element layers k0 <= k < k1 of the LAST direction, with the
     labels, element ids, coordinates and deformation of the full box: the element block one rank owns
     under the contiguous block distribution, without ever building the global mesh.
+    `ranges=((i0, i1), (j0, j1), (k0, k1))` generates the sub-box of elements i0 <= i < i1, ... in every direction in the same way:
+    one part of a recursive-coordinate-bisection partition (`rcb_boxes`).
     """
     dim = len(nel)
     assert dim in (2, 3)
@@ -110,16 +112,22 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
     origin = tuple(float(o) for o in (origin if origin is not None else [0.0] * dim))
     xi = gll_points(n)
     N = n - 1
-    k0, k1 = (0, nel[-1]) if last_range is None else (int(last_range[0]), int(last_range[1]))
-    assert 0 <= k0 < k1 <= nel[-1]
-    nloc = tuple(nel[:-1]) + (k1 - k0,)
+    if ranges is None:
+        k0, k1 = (0, nel[-1]) if last_range is None else (int(last_range[0]), int(last_range[1]))
+        ranges = tuple((0, nel[d]) for d in range(dim - 1)) + ((k0, k1),)
+    else:
+        assert last_range is None and len(ranges) == dim
+    ranges = tuple((int(a), int(b)) for a, b in ranges)
+    for d in range(dim):
+        assert 0 <= ranges[d][0] < ranges[d][1] <= nel[d], ranges
+    nloc = tuple(b - a for a, b in ranges)
     E = int(np.prod(nloc))
 
     # 1-D global grid indices and undeformed coordinates per direction
     gidx, coord, ngrid = [], [], []
     for d in range(dim):
         h = lengths[d] / nel[d]
-        e = np.arange(nel[d]) if d < dim - 1 else np.arange(k0, k1)
+        e = np.arange(ranges[d][0], ranges[d][1])
         gi = e[:, None] * N + np.arange(n)[None, :]              # (nel_d, n)
         c = origin[d] + h * (e[:, None] + 0.5 * (xi[None, :] + 1.0))
         ng = nel[d] * N + (0 if periodic[d] else 1)
@@ -184,9 +192,38 @@ def box_mesh(nel: Sequence[int], n: int, lengths: Sequence[float] | None = None,
         glo_num=np.ascontiguousarray(glo.reshape(E, -1)),
         mask=[m.copy() for _ in range(dim)], tmask=m.copy(),
         periodic=periodic, lengths=lengths, has_outflow=bool(outflow_xmax),
-        elem_gid=np.arange(E, dtype=np.int64) + k0 * int(np.prod(nel[:-1])),
+        elem_gid=_global_element_ids(nel, ranges),
     )
     return mesh
+
+
+def _global_element_ids(nel, ranges) -> np.ndarray:
+    """Lexicographic (x fastest) ids in the full box of the elements of a sub-box, in the sub-box's own lexicographic order."""
+    dim = len(nel)
+    ax = [np.arange(a, b, dtype=np.int64) for a, b in ranges]
+    if dim == 2:
+        return (ax[0][None, :] + nel[0] * ax[1][:, None]).ravel()
+    return (ax[0][None, None, :] + nel[0] * (ax[1][None, :, None] + nel[1] * ax[2][:, None, None])).ravel()
+
+
+def rcb_boxes(nel: Sequence[int], nparts: int) -> list:
+    """Recursive coordinate bisection of a structured box of elements into `nparts` sub-boxes (what genmap's
+    bisection gives on a box): cut the longest direction (in elements) where the element count splits in the ratio of the part
+    counts floor(n/2) : ceil(n/2), recurse.  Returns one ((i0, i1), (j0, j1)[, (k0, k1)]) per part, in bisection order."""
+    def rec(box, n):
+        if n == 1:
+            return [box]
+        d = max(range(len(box)), key=lambda q: (box[q][1] - box[q][0], -q))
+        a, b = box[d]
+        nlo = n // 2
+        cut = a + int(round((b - a) * nlo / n))
+        cut = min(max(cut, a + 1), b - 1)
+        if b - a < 2:
+            raise ValueError("rcb_boxes: more parts than elements along every direction")
+        lo = tuple((a, cut) if q == d else box[q] for q in range(len(box)))
+        hi = tuple((cut, b) if q == d else box[q] for q in range(len(box)))
+        return rec(lo, nlo) + rec(hi, n - nlo)
+    return rec(tuple((0, int(e)) for e in nel), int(nparts))
 
 
 def partition_elements(E: int, nranks: int) -> list:

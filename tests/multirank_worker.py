@@ -21,6 +21,8 @@ CASES = {
     "box2d": ((3, 2), 7, (False, False), 0),
     # with NLG_COARSE_EXACT_MAX=50 in the environment: aggregated (not exact) coarse level, as on production meshes
     "agg3d": ((4, 4, 3), 5, (False, False, False), 0),
+    # the block propagator across ranks: three lanes in every launch, ONE halo exchange / all-reduce carrying all of them
+    "blk3d": ((2, 2, 2), 6, (False, True, False), 0),
 }
 
 
@@ -153,6 +155,7 @@ def run(rank, world, segment, outdir, case):
     if case.startswith("cyl"):
         return run_cylinder(rank, world, segment, outdir, case)
     base, _, mult = case.partition("@")          # "box3d@2" with world 1: the global mesh of the 2-rank run
+    base = base.replace("+ovl", "")              # "+ovl": the same case with NLG_HALO_OVERLAP=1 in the environment (set by the test)
     nel, n, periodic, pprecond = CASES[base]
     nel = tuple(nel[:-1]) + (nel[-1] * int(mult or 1),)
     dim = len(nel)
@@ -176,8 +179,16 @@ def run(rank, world, segment, outdir, case):
     A = host.exptA_linop(0.03, bf, re=40.0, dt=0.01, vtol=1e-13, ptol=1e-13, maxit_p=2000, pprecond=pprecond)
     A.init()
     out, outT = host.nek_dvector(gm), host.nek_dvector(gm)
-    A.matvec(v, out)
-    A.rmatvec(v, outT)
+    if base == "blk3d":
+        # three vectors advanced together (nlg_linop_matvec_block); `out` / `outT` = the first and the last lane
+        w.scal(1.0 / w.norm())
+        mid, outm = host.nek_dvector(gm), host.nek_dvector(gm)
+        mid.rand(True, seed=13)
+        A.matvec_block([v, mid, w], [out, outm, outT])
+        scal += [outm.norm(), outm.dot(v)]
+    else:
+        A.matvec(v, out)
+        A.rmatvec(v, outT)
     scal += [out.norm(), outT.norm(), out.dot(w)]
     m = 6
     B = host.KrylovBasis(gm, m + 1)

@@ -95,6 +95,21 @@ def test_mesh_generator_properties():
     # ragged / degenerate inputs
     with pytest.raises(AssertionError):
         box_mesh((3,), 5)
+    # recursive coordinate bisection: a partition into sub-boxes; every part generated on its own equals its share of the full mesh
+    from neklab_amd.mesh import rcb_boxes
+    boxes = rcb_boxes((25, 20, 20), 8)
+    sizes = [int(np.prod([b - a for a, b in bx])) for bx in boxes]
+    assert sum(sizes) == 10000 and max(sizes) <= 1.04 * 1250 and sorted(set(sizes)) == [1200, 1300]
+    full = box_mesh((5, 4, 3), 4, periodic=(True, False, False), deform=0.05)
+    seen = []
+    for bx in rcb_boxes((5, 4, 3), 3):
+        part = box_mesh((5, 4, 3), 4, periodic=(True, False, False), deform=0.05, ranges=bx)
+        g = part.elem_gid
+        assert np.array_equal(part.x, full.x[g]) and np.array_equal(part.glo_num, full.glo_num[g]) and np.array_equal(part.mask[2], full.mask[2][g])
+        seen += list(g)
+    assert sorted(seen) == list(range(full.E))
+    with pytest.raises(ValueError):
+        rcb_boxes((2, 1), 3)
 
 
 def test_fortran_shim_compiles_against_the_abstract_types():

@@ -25,11 +25,12 @@ def run_bench(*extra):
 
 
 def test_bench_strong_scaling_uneven_partition():
-    """Three ranks on four element layers (2, 1, 1): the strong-scaling split of BASELINE.json's 20 layers over 8 GPUs is
-    uneven too (3, 3, 3, 3, 2, 2, 2, 2)."""
+    """Three ranks on the 6 x 6 x 4 box: recursive coordinate bisection gives uneven sub-boxes (2 x 6 x 4 and two of 4 x 3 x 4), with
+    neighbours across faces and an edge, as the bisection of BASELINE.json's 25 x 20 x 20 box over 8 GPUs does (12|13 x 10 x 10)."""
     one = run_bench("--gpus", "1", "--scaling", "strong")
     three = run_bench("--gpus", "3", "--transport", "shm", "--scaling", "strong")
     assert three["n_gpus"] == 3 and three["config"]["global_elements"] == one["config"]["global_elements"] == 144
+    assert three["config"]["partition"] == "rcb" and sorted(three["config"]["partition_sizes"]) == [48, 48, 48]
     assert abs(three["config"]["dt"] - one["config"]["dt"]) < 1e-12 * one["config"]["dt"]
     assert abs(three["config"]["pressure_iters_per_time_step"] - one["config"]["pressure_iters_per_time_step"]) <= 0.3 * one["config"]["pressure_iters_per_time_step"] + 2
 

@@ -23,6 +23,10 @@ def case_env(case):
     env = dict(os.environ)
     if case.startswith("agg"):
         env["NLG_COARSE_EXACT_MAX"] = "50"
+    if "+ovl" in case:
+        # the halo send / receive on the side stream beside the interior groups of the gather-scatter: under the validation
+        # transport the staging copies are ordered by the same two events as the RCCL group (csrc/halo.hip halo_begin / halo_finish)
+        env["NLG_HALO_OVERLAP"] = "1"
     return env
 
 
@@ -61,11 +65,12 @@ def record(case, world, fields, hess, ritz):
 
 
 @pytest.mark.parametrize("case,world", [("box3d", 2), ("per3d", 2), ("box3d", 3), ("jac3d", 2), ("box2d", 2),
-                                        ("agg3d", 2), ("cyl", 2), ("cyl", 3), ("heat", 2), ("proj", 2), ("proj", 3)])
+                                        ("agg3d", 2), ("cyl", 2), ("cyl", 3), ("heat", 2), ("proj", 2), ("proj", 3),
+                                        ("blk3d", 2), ("blk3d", 3), ("box3d+ovl", 2), ("per3d+ovl", 2), ("cyl+ovl", 3), ("blk3d+ovl", 2)])
 def test_partition_independent(tmp_path, case, world):
     parts = launch(world, tmp_path, case)
     # the single-rank run of the same global mesh (`world` times the elements in the last direction)
-    gcase = "%s@%d" % (case, world)       # (the cylinder case ignores the multiplier: the mesh is the global one)
+    gcase = "%s@%d" % (case.replace("+ovl", ""), world)       # (the cylinder case ignores the multiplier: the mesh is the global one)
     r = subprocess.run([sys.executable, WORKER, "0", "1", "", str(tmp_path), gcase], cwd=ROOT, capture_output=True,
                        text=True, timeout=420, env=case_env(case))
     assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
