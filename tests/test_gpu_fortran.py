@@ -173,7 +173,7 @@ def test_fortran_thermosyphon_call_sequence(gpu_ctx):
     subprocess.run(["make", "-s", "-C", FDIR], check=True)
     exe = os.path.join(FDIR, "_build", "tsyphon_driver")
     hm = box_mesh((4, 3), 6, lengths=(2.0158, 1.0), periodic=(True, False), deform=0.0)
-    kdim, nev, tau, re, vtol, ptol = 20, 2, 0.2, 1.0, 1e-11, 1e-11
+    kdim, nev, tau, re, vtol, ptol = 48, 2, 0.2, 1.0, 1e-11, 1e-11      # (kdim: LightKrylov's loop does not restart; the two leading modes lie 1.5 % apart)
     cond, rhocp, buoy, endtime, tol = 1.0, 1.0, (0.0, 500.0, 0.0), 0.2, 1e-8
     k = 2.0 * np.pi / 2.0158
     T0 = 1.0 - hm.y
@@ -214,5 +214,5 @@ def test_fortran_thermosyphon_call_sequence(gpu_ctx):
     lam = np.log(mu.astype(complex)) / tau
     spec = np.load(os.path.join(tmp, "dir_eigenspectrum.npy"))
     flam = spec[:, 0] + 1j * spec[:, 1]
-    assert spec.shape == (nev, 3)
+    assert spec.shape == (nev, 3) and np.all(spec[:, 2] < 1e-6), spec
     assert lam[0].real < 0 and abs(flam[0] - lam[0]) < 1e-4 * abs(lam[0]), (flam, lam)
