@@ -390,6 +390,153 @@ __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__rest
     }
 }
 
+// ---- the same extended local solve with the six 1-D transforms on the matrix pipe (lx1 = 8) --------------------------------
+// One wave per element.  A transform along one axis is the GEMM  out(8 x 64 columns) = S(8 x 8) in(8 x 64 columns), issued as
+// v_mfma_f64_16x16x4_f64 tiles: M = output index (8 of the 16 rows used), N = 16 data columns, K = 8 in two steps -> 8 MFMA per
+// stage and 48 per element instead of 384 vector FMAs per lane, with 8 LDS reads and 8 LDS writes per lane and stage as the only
+// other work.  Operand layout (guide, "f64 MFMA"): A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
+// D[row = (lane >> 4) + 4 reg][col = lane & 15]: registers 0 and 1 of a lane are outputs o = lane >> 4 and o + 4 of its column,
+// registers 2 and 3 belong to the unused rows 8 .. 15.  The cube is stored with the x rows padded to 9 doubles (index
+// a + 9 (b + 8 c)) so that the 16 columns of a tile fall into different LDS banks for all three axes.
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+template <int AX>
+__device__ __forceinline__ void fdm_stage_mfma8(double *__restrict__ buf, double a0, double a1, int l15, int lg) {
+    int base[4], str;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = 16 * t + l15;
+        if (AX == 0) {
+            base[t] = 9 * col;                              // column (b, c): a = l
+        } else if (AX == 1) {
+            base[t] = (col & 7) + 72 * (col >> 3);          // column (a, c): b = l
+        } else {
+            base[t] = (col & 7) + 9 * (col >> 3);           // column (a, b): c = l
+        }
+    }
+    str = AX == 0 ? 1 : (AX == 1 ? 9 : 72);
+    double b0[4], b1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        b0[t] = buf[base[t] + str * lg];
+        b1[t] = buf[base[t] + str * (lg + 4)];
+    }
+    const v4f64_t zero = {0.0, 0.0, 0.0, 0.0};
+    v4f64_t d[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[t], zero, 0, 0, 0);
+        d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[t], d[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        buf[base[t] + str * lg] = d[t][0];
+        buf[base[t] + str * (lg + 4)] = d[t][1];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fdm_ext_mfma8(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
+                                                      const double *__restrict__ lam, double thr, const double *__restrict__ r,
+                                                      const double *__restrict__ wq, double *__restrict__ W,
+                                                      double *__restrict__ z, const int *__restrict__ tab, int64_t ld, int64_t lW, int nb_fdm,
+                                                      AggArgs ag) {
+    constexpr int N = 8, N2 = 6, NP = 512, NP2 = 216, NPAD = 9 * 64;
+    __shared__ double sL[3][N];
+    __shared__ double sA[NPAD];
+    if ((int)blockIdx.x >= nb_fdm) {   // merged launch: the blocks behind the elements restrict the coarse residual to the aggregates
+        agg_restrict_body((int)blockIdx.x - nb_fdm, flag, ld, ag);
+        return;
+    }
+    {   // blockIdx.y = lane of a block step
+        const int64_t lo = (int64_t)blockIdx.y * ld;
+        if (flag) flag += lo;
+        r += lo, z += lo, W += (int64_t)blockIdx.y * lW;
+    }
+    if (flag && flag[0] != 0.0) return;
+    const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
+    const int64_t e = blockIdx.x;
+    const double *__restrict__ Sg = S + e * (3 * N * N);
+    // A operands of the six transforms: forward = S^T (out[o] = sum_l S[l][o] in[l]), backward = S; rows 8 .. 15 are zero
+    double aF[3][2], aB[3][2];
+    {
+        const int o = l15 & 7;
+        const double live = l15 < 8 ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                aF[m][ks] = live * Sg[m * N * N + (lg + 4 * ks) * N + o];
+                aB[m][ks] = live * Sg[m * N * N + o * N + lg + 4 * ks];
+            }
+    }
+    if (lane < 3 * N) sL[lane / N][lane % N] = lam[e * (3 * N) + lane];
+    const double *re = r + e * NP2;
+    double *We = W + e * NP;
+    int te[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) te[u] = tab[lane + 64 * u];
+    {
+        double own[8], gw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int nb = te[u] & 3;
+            const int q2 = nb <= 1 ? ((te[u] >> 13) & 1023) : 0;
+            const int sl = nb == 1 ? ((te[u] >> 2) & 2047) : 0;
+            own[u] = re[q2] * wq[e * NP2 + q2];
+            gw[u] = We[sl];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = lane + 64 * u;
+            const int nb = te[u] & 3;
+            sA[q + (q >> 3)] = nb == 0 ? own[u] : (nb == 1 ? gw[u] - own[u] : 0.0);
+        }
+    }
+    __syncthreads();
+    fdm_stage_mfma8<0>(sA, aF[0][0], aF[0][1], l15, lg);
+    __syncthreads();
+    fdm_stage_mfma8<1>(sA, aF[1][0], aF[1][1], l15, lg);
+    __syncthreads();
+    fdm_stage_mfma8<2>(sA, aF[2][0], aF[2][1], l15, lg);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = lane + 64 * u;
+        const double den = sL[0][q % N] + sL[1][(q / N) % N] + sL[2][q / (N * N)];
+        const double v = sA[q + (q >> 3)];
+        sA[q + (q >> 3)] = den > thr ? v / den : 0.0;
+    }
+    __syncthreads();
+    fdm_stage_mfma8<2>(sA, aB[2][0], aB[2][1], l15, lg);
+    __syncthreads();
+    fdm_stage_mfma8<1>(sA, aB[1][0], aB[1][1], l15, lg);
+    __syncthreads();
+    fdm_stage_mfma8<0>(sA, aB[0][0], aB[0][1], l15, lg);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = lane + 64 * u;
+        const int nb = te[u] & 3;
+        const int fl = nb == 0 ? (te[u] >> 23) : 0;
+        const int pq = q + (q >> 3);
+        // (LDS reads unconditional with clamped indices, selected afterwards: no divergent branches around them)
+        const double c0 = sA[pq];
+        const double m1 = sA[pq >= 1 ? pq - 1 : pq], p1 = sA[pq + 1 < NPAD ? pq + 1 : pq];
+        const double mN = sA[pq >= 9 ? pq - 9 : pq], pN = sA[pq + 9 < NPAD ? pq + 9 : pq];
+        const double mM = sA[pq >= 72 ? pq - 72 : pq], pM = sA[pq + 72 < NPAD ? pq + 72 : pq];
+        double v = c0;
+        v -= (fl & 1) ? m1 : 0.0;
+        v -= (fl & 2) ? p1 : 0.0;
+        v -= (fl & 4) ? mN : 0.0;
+        v -= (fl & 8) ? pN : 0.0;
+        v -= (fl & 16) ? mM : 0.0;
+        v -= (fl & 32) ? pM : 0.0;
+        if (nb == 1)
+            We[(te[u] >> 2) & 2047] = c0;   // ghost value: belongs to the neighbour's adjacent layer
+        else if (nb == 0)
+            z[e * NP2 + ((te[u] >> 13) & 1023)] = v;
+    }
+}
+
 // z += (own + neighbours' ghost values at this point, from W after QQ^T) + prolonged coarse correction; r.z and z sums
 template <int N>
 __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ flag, int64_t E, const double *__restrict__ W,
@@ -2082,6 +2229,13 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
         nb_agg = fused ? (P.na + WPE_ - 1) / WPE_ : 0;   /* (b) + aggregate restriction: one wave per aggregate */     \
         NLG_LAUNCH((k_fdm_ext<N_, 1, WPE_>), dim3((unsigned)(E + nb_agg), (unsigned)nl), dim3(64 * WPE_), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (const int *)P.d_exttab, ld, P.lW, (int)E, ag); \
     } break;
+        // lx1 = 8: the six transforms on the matrix pipe (k_fdm_ext_mfma8); NLG_FDM_MFMA=0 selects the vector-pipe kernel (A/B runs)
+        static const bool fdm_mfma = !(getenv("NLG_FDM_MFMA") && atoi(getenv("NLG_FDM_MFMA")) == 0);
+        if (m->n == 8 && fdm_mfma) {
+            nb_agg = fused ? P.na : 0;
+            NLG_LAUNCH(k_fdm_ext_mfma8, dim3((unsigned)(E + nb_agg), (unsigned)nl), dim3(64), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z,
+                       (const int *)P.d_exttab, ld, P.lW, (int)E, ag);
+        } else
         switch (m->n) {
             FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(12)
             default: set_error("pprec: overlapping variant built for lx1 = 4..10 and 12, got %d", m->n); return 1;
