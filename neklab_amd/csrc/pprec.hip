@@ -399,42 +399,45 @@ __global__ __launch_bounds__(64 * WPB * WPE) void k_fdm_ext(const double *__rest
 // registers 2 and 3 belong to the unused rows 8 .. 15.  The cube is stored with the x rows padded to 9 doubles (index
 // a + 9 (b + 8 c)) so that the 16 columns of a tile fall into different LDS banks for all three axes.
 typedef double v4f64_t __attribute__((ext_vector_type(4)));
-template <int AX>
-__device__ __forceinline__ void fdm_stage_mfma8(double *__restrict__ buf, double a0, double a1, int l15, int lg) {
-    int base[4], str;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = 16 * t + l15;
-        if (AX == 0) {
-            base[t] = 9 * col;                              // column (b, c): a = l
-        } else if (AX == 1) {
-            base[t] = (col & 7) + 72 * (col >> 3);          // column (a, c): b = l
-        } else {
-            base[t] = (col & 7) + 9 * (col >> 3);           // column (a, b): c = l
-        }
-    }
-    str = AX == 0 ? 1 : (AX == 1 ? 9 : 72);
-    double b0[4], b1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        b0[t] = buf[base[t] + str * lg];
-        b1[t] = buf[base[t] + str * (lg + 4)];
-    }
+template <int AX, bool FWD>
+__device__ __forceinline__ void fdm_stage_mfma8(double *__restrict__ buf, const double *__restrict__ sS, int l15, int lg) {
+    // A operand of this stage from the element's matrices in LDS: forward = S^T (out[o] = sum_l S[l][o] in[l]), backward = S;
+    // rows 8 .. 15 of the tile are zero.  (Held in registers for all six stages they cost 24 VGPRs and a wave per SIMD.)
+    const int o = l15 & 7;
+    const double live = l15 < 8 ? 1.0 : 0.0;
+    const double a0 = live * (FWD ? sS[AX * 64 + lg * 8 + o] : sS[AX * 64 + o * 8 + lg]);
+    const double a1 = live * (FWD ? sS[AX * 64 + (lg + 4) * 8 + o] : sS[AX * 64 + o * 8 + lg + 4]);
+    constexpr int str = AX == 0 ? 1 : (AX == 1 ? 9 : 72);
     const v4f64_t zero = {0.0, 0.0, 0.0, 0.0};
-    v4f64_t d[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[t], zero, 0, 0, 0);
-        d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[t], d[t], 0, 0, 0);
-    }
+    for (int h = 0; h < 2; ++h) {   // two tiles (32 columns) at a time: half the operand / result registers
+        int base[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        buf[base[t] + str * lg] = d[t][0];
-        buf[base[t] + str * (lg + 4)] = d[t][1];
+        for (int t = 0; t < 2; ++t) {
+            const int col = 16 * (2 * h + t) + l15;
+            base[t] = AX == 0 ? 9 * col : (AX == 1 ? (col & 7) + 72 * (col >> 3) : (col & 7) + 9 * (col >> 3));
+        }
+        double b0[2], b1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            b0[t] = buf[base[t] + str * lg];
+            b1[t] = buf[base[t] + str * (lg + 4)];
+        }
+        v4f64_t d[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[t], zero, 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[t], d[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            buf[base[t] + str * lg] = d[t][0];
+            buf[base[t] + str * (lg + 4)] = d[t][1];
+        }
     }
 }
 
-__global__ __launch_bounds__(64) void k_fdm_ext_mfma8(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
+__global__ __launch_bounds__(64, 4) void k_fdm_ext_mfma8(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                       const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                       const double *__restrict__ wq, double *__restrict__ W,
                                                       double *__restrict__ z, const int *__restrict__ tab, int64_t ld, int64_t lW, int nb_fdm,
@@ -455,19 +458,9 @@ __global__ __launch_bounds__(64) void k_fdm_ext_mfma8(const double *__restrict__
     const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
     const int64_t e = blockIdx.x;
     const double *__restrict__ Sg = S + e * (3 * N * N);
-    // A operands of the six transforms: forward = S^T (out[o] = sum_l S[l][o] in[l]), backward = S; rows 8 .. 15 are zero
-    double aF[3][2], aB[3][2];
-    {
-        const int o = l15 & 7;
-        const double live = l15 < 8 ? 1.0 : 0.0;
+    __shared__ double sS[3 * N * N];
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                aF[m][ks] = live * Sg[m * N * N + (lg + 4 * ks) * N + o];
-                aB[m][ks] = live * Sg[m * N * N + o * N + lg + 4 * ks];
-            }
-    }
+    for (int m = 0; m < 3; ++m) sS[m * N * N + lane] = Sg[m * N * N + lane];
     if (lane < 3 * N) sL[lane / N][lane % N] = lam[e * (3 * N) + lane];
     const double *re = r + e * NP2;
     double *We = W + e * NP;
@@ -492,11 +485,11 @@ __global__ __launch_bounds__(64) void k_fdm_ext_mfma8(const double *__restrict__
         }
     }
     __syncthreads();
-    fdm_stage_mfma8<0>(sA, aF[0][0], aF[0][1], l15, lg);
+    fdm_stage_mfma8<0, true>(sA, sS, l15, lg);
     __syncthreads();
-    fdm_stage_mfma8<1>(sA, aF[1][0], aF[1][1], l15, lg);
+    fdm_stage_mfma8<1, true>(sA, sS, l15, lg);
     __syncthreads();
-    fdm_stage_mfma8<2>(sA, aF[2][0], aF[2][1], l15, lg);
+    fdm_stage_mfma8<2, true>(sA, sS, l15, lg);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -506,11 +499,11 @@ __global__ __launch_bounds__(64) void k_fdm_ext_mfma8(const double *__restrict__
         sA[q + (q >> 3)] = den > thr ? v / den : 0.0;
     }
     __syncthreads();
-    fdm_stage_mfma8<2>(sA, aB[2][0], aB[2][1], l15, lg);
+    fdm_stage_mfma8<2, false>(sA, sS, l15, lg);
     __syncthreads();
-    fdm_stage_mfma8<1>(sA, aB[1][0], aB[1][1], l15, lg);
+    fdm_stage_mfma8<1, false>(sA, sS, l15, lg);
     __syncthreads();
-    fdm_stage_mfma8<0>(sA, aB[0][0], aB[0][1], l15, lg);
+    fdm_stage_mfma8<0, false>(sA, sS, l15, lg);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
