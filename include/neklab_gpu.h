@@ -216,6 +216,11 @@ int nlg_basis_cgs2(const nlg_basis *b, int k, nlg_vec *w, double *h, double *bet
  * (both passes summed), rows k .. k+s-1 the upper-triangular factor R with  W_old = V(:,0:k) coef(0:k,:) + W_new R.
  * Restart history and pressure follow as in axpby / scal (consistent history update only). */
 int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef);
+/* Number of columns the last nlg_basis_block_cgs2 on this basis kept.  A column of the block that is numerically dependent on
+ * the basis and the columns before it (squared norm reduced below 1e-14 of what it entered the block factorisation with: the block
+ * Krylov space has reached an invariant subspace, or the block was badly conditioned) is deflated, not an error: its coefficients
+ * are returned as for any column with a zero diagonal entry in R, and the column becomes the zero vector. */
+int nlg_basis_last_block_rank(const nlg_basis *b, int *rank);
 /* out = sum_j c[j] V(:,j)  over ALL fields (eigenvector reconstruction, LightKrylov eigs tail) */
 int nlg_basis_combine(const nlg_basis *b, int k, const double *c, nlg_vec *out);
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "nlg_prof_reset": (C.c_int, [vp]),
     "nlg_prof_get": (C.c_int, [vp, C.c_char_p, c_int64_p, c_double_p]),
     "nlg_counters": (C.c_int, [c_int64_p, c_int64_p]),
+    "nlg_basis_last_block_rank": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "nlg_vec_generation": (C.c_int, [vp, c_int64_p]),
     "nlg_vec_release": (C.c_int, [vp]),
     "nlg_vec_adopt": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int)]),

@@ -322,6 +322,7 @@ struct nlg_basis {
     std::vector<nlg_vec *> views;
     double *d_h = nullptr;     // [2 * nvec + 8] device coefficients
     double *d_hb = nullptr;    // block orthogonalisation: [2 * nvec * 4 + 64] coefficients of up to 4 vectors (lazy)
+    int last_block_rank = 0;   // columns kept by the last nlg_basis_block_cgs2 (< s: dependent columns were deflated)
 };
 
 namespace nlg {

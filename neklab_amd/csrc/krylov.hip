@@ -301,6 +301,9 @@ int nlg_eigs(nlg_linop *op, nlg_vec **X, int nev, double *eig_re, double *eig_im
                 if (r.res[i] < tol) ++conv;
             if (o.write_intermediate) write_log(logfile, nmv, r, tol);
             if (conv >= nev) break;
+            // a deflated column in the new block: the block Krylov space has (numerically) reached an invariant subspace -- the block
+            // counterpart of beta = 0.  The Ritz pairs of the space built so far are returned instead of an error.
+            if (V->last_block_rank < bs) break;
         }
     } else
     for (int restart = 0; restart <= o.max_restarts; ++restart) {

@@ -975,7 +975,15 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
     nlg_vec *w0 = b->views[k];
     int nrst = 0;
     for (int v = 0; v < s; ++v) nrst = std::max(nrst, b->views[k + v]->nrst);
-    for (int v = 0; v < s; ++v) b->views[k + v]->nrst = nrst;
+    for (int v = 0; v < s; ++v) {
+        // the sweeps below run over the main block and `nrst` history blocks of EVERY column: a column that carries fewer (a
+        // freshly drawn one next to an x0 with a restart history) gets zeros there, not whatever its memory held
+        nlg_vec *c = b->views[k + v];
+        if (c->nrst < nrst)
+            NLG_HIP(hipMemsetAsync(c->d + (int64_t)(1 + c->nrst) * c->main_len, 0, sizeof(double) * (size_t)((nrst - c->nrst) * c->main_len), st));
+        c->nrst = nrst;
+    }
+    b->last_block_rank = s;
     double *W = w0->d;
     double *H1 = b->d_hb, *H2 = b->d_hb + (size_t)b->nvec * 4, *dG = b->d_hb + (size_t)2 * b->nvec * 4, *dT = dG + 16;
     const int nblk = dot_nblk(w0), nper = nblk * w0->ncomp;
@@ -1017,35 +1025,56 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
         NLG_TRY(dots(b->d, k, H2, H1));              // H1 <- H1 + H2
         NLG_TRY(axpy(H2, H1, n2all, n2));            // second pass: H2 on the main block, the sum on the history blocks
     }
+    // Cholesky QR among the s new columns, twice.  A (numerically) dependent column -- a block Krylov space that has reached an
+    // invariant subspace, the "lucky breakdown" of converged eigenvalues, or a drawn column close to x0 -- is not an error: what is
+    // left of it after the projections is below the rounding level of what it was, so it is DEFLATED: its coefficients on the
+    // columns before it go into R as for any column, its diagonal entry of R is 0 and the column itself becomes the zero vector
+    // (harmless in every later projection).  b->last_block_rank = number of columns kept; nlg_eigs stops expanding the space when
+    // it falls below s, as it does at beta = 0 in the single-vector iteration.
     double R[4][4] = {};
     for (int a = 0; a < s; ++a) R[a][a] = 1.0;
+    bool dep[4] = {false, false, false, false};
+    double g0[4] = {0.0, 0.0, 0.0, 0.0};   // squared norms of the columns when they entered the factorisation
     for (int round = 0; round < 2; ++round) {
         NLG_TRY(dots(W, s, dG, nullptr));
         double G[16];
         NLG_HIP(hipMemcpyAsync(G, dG, sizeof(double) * s * s, hipMemcpyDeviceToHost, st));
         NLG_HIP(hipStreamSynchronize(st));
         double L[4][4] = {};
-        for (int i = 0; i < s; ++i)
+        for (int i = 0; i < s; ++i) {
+            NLG_CHECK(std::isfinite(G[i * s + i]), "nlg_basis_block_cgs2: column %d is not finite", k + i);
+            if (round == 0) g0[i] = G[i * s + i];
             for (int j = 0; j <= i; ++j) {
                 double a = G[i * s + j];
                 for (int q = 0; q < j; ++q) a -= L[i][q] * L[j][q];
                 if (i == j) {
-                    NLG_CHECK(a > 0.0 && std::isfinite(a), "nlg_basis_block_cgs2: the block is rank deficient (column %d, pivot %.3e)", k + i, a);
-                    L[i][i] = std::sqrt(a);
+                    // the pivot is the squared norm of column i after the columns before it have been projected out: a block with
+                    // condition number above ~1e7 loses it to rounding (CholQR works on the SQUARED condition number)
+                    if (dep[i] || !(a > 1e-14 * g0[i]) || !(g0[i] > 0.0)) {
+                        dep[i] = true;
+                        L[i][i] = 0.0;
+                    } else {
+                        L[i][i] = std::sqrt(a);
+                    }
                 } else {
-                    L[i][j] = a / L[j][j];
+                    L[i][j] = dep[j] ? 0.0 : a / L[j][j];
                 }
             }
-        // Rr = L^T (upper); T = Rr^-1 (upper, back substitution column by column); W <- W T; R <- Rr R
+        }
+        // Rr = L^T (upper); T = Rr^-1 (upper, back substitution column by column); W <- W T; R <- Rr R.  A deflated column takes a
+        // unit pivot in the inverse and a zero column in T afterwards: W T then holds the zero vector in its place.
         double T[4][4] = {};
         for (int c = 0; c < s; ++c) {
-            T[c][c] = 1.0 / L[c][c];
+            T[c][c] = dep[c] ? 1.0 : 1.0 / L[c][c];
             for (int r = c - 1; r >= 0; --r) {
                 double a = 0.0;
                 for (int q = r + 1; q <= c; ++q) a += L[q][r] * T[q][c];
-                T[r][c] = -a / L[r][r];
+                T[r][c] = dep[r] ? -a : -a / L[r][r];
             }
         }
+        for (int c = 0; c < s; ++c)
+            if (dep[c])
+                for (int r = 0; r < s; ++r) T[r][c] = 0.0;
         double Tf[16], Rn[4][4] = {};
         for (int a = 0; a < s; ++a)
             for (int c = 0; c < s; ++c) {
@@ -1064,6 +1093,8 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
         }
         NLG_HIP(hipStreamSynchronize(st));   // Tf lives on this stack frame
     }
+    for (int v = 0; v < s; ++v)
+        if (dep[v]) --b->last_block_rank;
     std::vector<double> hs((size_t)std::max(k, 1) * s);
     if (k > 0) {
         NLG_HIP(hipMemcpyAsync(hs.data(), H1, sizeof(double) * (size_t)k * s, hipMemcpyDeviceToHost, st));
@@ -1074,6 +1105,12 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
         for (int a = 0; a < s; ++a) coef[(size_t)v * ld + k + a] = R[a][v];
     }
     NLG_HIP(hipGetLastError());
+    return 0;
+}
+
+int nlg_basis_last_block_rank(const nlg_basis *b, int *rank) {
+    NLG_CHECK(b && rank, "nlg_basis_last_block_rank: NULL argument");
+    *rank = b->last_block_rank;
     return 0;
 }
 

@@ -278,6 +278,12 @@ class KrylovBasis:
         check(self.lib.nlg_basis_block_cgs2(self.h, int(k), int(s), dptr(coef)))
         return coef
 
+    def last_block_rank(self) -> int:
+        """columns the last block_cgs2 kept (< s: numerically dependent columns were deflated to zero vectors)"""
+        r = C.c_int()
+        check(self.lib.nlg_basis_last_block_rank(self.h, C.byref(r)))
+        return r.value
+
     def combine(self, k: int, c, out: nek_dvector):
         a = np.ascontiguousarray(c, dtype=np.float64)
         check(self.lib.nlg_basis_combine(self.h, k, dptr(a), out.h))

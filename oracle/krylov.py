@@ -63,10 +63,32 @@ def block_cgs2(V, k, s):
             W[v].axpby(-1.0, lincomb(V, h[:, v], k), 1.0)
         coef[:k] += h
     R = np.eye(s)
+    dep = [False] * s          # deflated (numerically dependent) columns, as in nlg_basis_block_cgs2: zero vector, zero diagonal of R
+    g0 = None
     for _ in range(2):
         G = np.array([[W[a].dot(W[b]) for b in range(s)] for a in range(s)])
-        Rr = np.linalg.cholesky(G).T
-        T = np.linalg.inv(Rr)
+        if g0 is None:
+            g0 = np.diag(G).copy()
+        L = np.zeros((s, s))
+        for i in range(s):
+            for j in range(i + 1):
+                a = G[i, j] - np.dot(L[i, :j], L[j, :j])
+                if i == j:
+                    if dep[i] or not (a > 1e-14 * g0[i]) or not (g0[i] > 0.0):
+                        dep[i] = True
+                    else:
+                        L[i, i] = np.sqrt(a)
+                else:
+                    L[i, j] = 0.0 if dep[j] else a / L[j, j]
+        Rr = L.T
+        Linv = L.copy()
+        for i in range(s):
+            if dep[i]:
+                Linv[i, i] = 1.0
+        T = np.linalg.inv(Linv.T)
+        for c in range(s):
+            if dep[c]:
+                T[:, c] = 0.0
         Wn = []
         for b in range(s):
             w = lincomb(W, T[:, b], s)

@@ -85,6 +85,54 @@ def test_block_cgs2_matches_oracle(gpu_ctx, dim, n, s):
         B.block_cgs2(k, 5)
 
 
+def test_block_cgs2_deflates_a_dependent_column(gpu_ctx):
+    """A block whose third column is a combination of a basis vector and the first new column (a block Krylov space that has reached
+    an invariant subspace; a drawn column next to x0): not an error -- the column is deflated (zero vector, zero diagonal entry of R,
+    its coefficients on the others as for any column), the other columns come out orthonormal, the rank is reported, and the oracle
+    twin does the same.  A block in which only one column carries a restart history leaves zeros, not stale memory, in the others."""
+    hm = box_mesh((3, 2, 2), 5, periodic=(True, False, False), deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    k, s = 4, 3
+    B = host.KrylovBasis(gm, k + s)
+    oV = []
+    for j in range(k):
+        ov = pair(sem, gm, 10 + j, with_history=False)
+        upload(B[j], ov, 3)
+        B.cgs2(j, B[j])
+        if j:
+            cgs2_step(oV, ov)
+        ov.scal(1.0 / ov.norm())
+        oV.append(ov)
+    new = [pair(sem, gm, 60, with_history=True), pair(sem, gm, 61, with_history=False)]
+    dep = new[0].copy()
+    dep.nrst = 0
+    dep.scal(0.7)
+    dep.axpby(0.4, oV[1], 1.0)                       # 0.7 w_0 + 0.4 v_1: in the span of the basis and the first new column
+    new.append(dep)
+    # stale data in the history slots of a column that declares none: must not leak into the result
+    junk = host.nek_dvector(gm)
+    junk.rand(False, seed=5)
+    for v in range(s):
+        B[k + v].save_rst(junk, 1)
+        B[k + v].save_rst(junk, 2)
+        B[k + v].clear_rst_fields()
+        upload(B[k + v], new[v], 3)
+        oV.append(new[v])
+    coef = B.block_cgs2(k, s)
+    ocoef = o_block_cgs2(oV, k, s)
+    assert B.last_block_rank() == 2
+    assert coef[k + 2, 2] == 0.0 and ocoef[k + 2, 2] == 0.0
+    assert np.max(np.abs(coef - ocoef)) < 1e-11 * np.max(np.abs(ocoef)), np.max(np.abs(coef - ocoef))
+    assert B[k + 2].norm() == 0.0 and abs(coef[1, 2] - (0.4 + 0.7 * coef[1, 0])) < 1e-12 and abs(coef[k, 2] - 0.7 * coef[k, 0]) < 1e-12
+    G = np.array([[B[i].dot(B[j]) for j in range(k + 2)] for i in range(k + 2)])
+    assert np.max(np.abs(G - np.eye(k + 2))) < 1e-13
+    # history: column k carried one, the others get the zero history blocks they declared (combined consistently), not `junk`
+    for v in range(2):
+        for r in (1, 2):
+            d = max(np.max(np.abs(B[k + v].get_field(i, r) - oV[k + v].v_rst[r - 1][i].ravel())) for i in range(3))
+            assert d < 1e-10, (v, r, d)
+
+
 def test_block_arnoldi_matches_oracle_and_single_vector_spectrum(gpu_ctx):
     hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), periodic=(True, False), deform=0.04)
     sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
