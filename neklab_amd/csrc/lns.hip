@@ -906,6 +906,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     const Red rd_std = {{partial, partial + NB, partial + 2 * NB}, {g, g, g}};
     auto reduce_post = [&](const Red &rd, int nsums, int gate, int mode) -> int {
         if (!ctx->distributed()) {
+            ++g_collectives;   // (the all-reduce a partitioned run issues here; counted on one rank too, nlg_counters)
             NLG_LAUNCH(k_cg_final_post, lgrid(1, nl), dim3(NTF), 0, st, s, rd, nsums, gate, mode, P.tol2, P.use_tol, P.maxit,
                        P.inv_n, 1, ld, (double *)nullptr);
         } else {

@@ -2948,6 +2948,7 @@ int sem_ortho(nlg_mesh *m, double *p, int nl, int64_t ld) {
         NLG_LAUNCH(k_sub_mean, dim3(grid_for(m->lpn), nl), dim3(NT), 0, ctx->stream, p, m->lpn, (const double *)d_sum, (const double *)nullptr, 0,
                    1.0 / (double)m->lpn_global, ld);
     } else {
+        ++g_collectives;
         NLG_LAUNCH(k_sub_mean, dim3(grid_for(m->lpn), nl), dim3(NT), 0, ctx->stream, p, m->lpn, (const double *)nullptr, (const double *)ctx->d_partial,
                    NPART, 1.0 / (double)m->lpn_global, ld);
     }

@@ -819,6 +819,7 @@ int basis_block_dot_dev(const nlg_basis *b, int k, const nlg_vec *w, double *d_o
         NLG_TRY(allreduce_sum(ctx, d_out, k));
         if (d_acc) NLG_LAUNCH(k_vadd, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, d_acc, d_out, k);
     } else {
+        ++g_collectives;   // (counted on one rank too, nlg_counters)
         NLG_LAUNCH(k_reduce_rows, dim3(k), dim3(NT), 0, ctx->stream, ctx->d_partial, nper, d_out,
                            d_acc ? 1 : 0, d_acc);
     }
@@ -887,6 +888,7 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
                     NLG_TRY(allreduce_sum(ctx, h2 + k0, kf));
                     NLG_LAUNCH(k_vadd, dim3((kf + 255) / 256), dim3(256), 0, ctx->stream, h + k0, h2 + k0, kf);
                 } else {
+                    ++g_collectives;
                     NLG_LAUNCH(k_reduce_rows, dim3(kf), dim3(NT), 0, ctx->stream, ctx->d_partial, G, h2 + k0, 1, h + k0);
                 }
                 if (k0 > 0) NLG_TRY(basis_block_dot_dev(b, k0, w, h2, h));
@@ -1004,6 +1006,7 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
             NLG_TRY(allreduce_sum(ctx, out, kk * s));
             if (acc) NLG_LAUNCH(k_vadd, dim3((kk * s + 255) / 256), dim3(256), 0, st, acc, out, kk * s);
         } else {
+            ++g_collectives;
             NLG_LAUNCH(k_reduce_rows, dim3(kk * s), dim3(NT), 0, st, ctx->d_partial, nper, out, acc ? 1 : 0, acc);
         }
         return 0;
