@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--no-units", action="store_true", help="skip the U1+U2 / U3 unit timings after the timed region (profiling runs)")
     ap.add_argument("--pproj", type=int, default=1, help="pressure residual projection (1 default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--ifheat", action="store_true", help="Boussinesq coupling with one scalar (BASELINE config 4 shape)")
+    ap.add_argument("--no-history", action="store_true",
+                    help="vectors without restart-history copies (cfg.no_history, lorder = 1): a third of the basis memory; "
+                         "the memory plan for BASELINE configs 4 / 5 (DESIGN.md)")
     ap.add_argument("--block", type=int, default=1,
                     help="> 1: a step is one BLOCK Arnoldi step with this many vectors (<= 4) advanced together "
                          "(nlg_block_arnoldi_step); value counts every vector's matvec")
@@ -168,7 +172,9 @@ def main():
     hm = box_mesh(gnel, n, deform=0.05, ranges=my_box)
     E = hm.E                                   # local element count from here on
     gm = host.Mesh(ctx, hm)
-    bf = host.nek_dvector(gm)
+    nscal = 1 if args.ifheat else 0
+    lorder = 1 if args.no_history else 3
+    bf = host.nek_dvector(gm, nscal)
     L = hm.lengths
     X = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
     ph = [2 * np.pi * X[d] / L[d] for d in range(dim)]
@@ -178,7 +184,9 @@ def main():
         U = [np.sin(ph[1]), 0.5 * np.sin(ph[0])]
     for i in range(dim):
         bf.set_field(i, U[i] * hm.mask[i])
-    noise = host.nek_dvector(gm)
+    if args.ifheat:
+        bf.set_field(host.THETA, 1.0 - X[1] / L[1])      # conduction profile between the walls y = 0, Ly
+    noise = host.nek_dvector(gm, nscal)
     noise.rand(False, seed=0)
     bf.axpby(0.05, noise, 1.0)
     # tau such that the CFL rule (cfl_limit 0.5) gives exactly args.nsteps steps
@@ -186,14 +194,15 @@ def main():
     host.check(lib.nlg_op_cfl(gm.h, bf.h, 1.0, C.byref(cfl1)))
     dt0 = 0.5 / cfl1.value
     tau = dt0 * (args.nsteps - 0.5)
+    heat = dict(ifheat=1, conductivity=1.0 / args.re, rhocp=1.0, buoy=(0.0, 1.0, 0.0)) if args.ifheat else {}
     A = host.exptA_linop(tau, bf, re=args.re, torder=3, vtol=1e-9, ptol=1e-7, maxit_v=200, maxit_p=4000,
-                         pprecond=args.pprecond, pproj=args.pproj)
+                         pprecond=args.pprecond, pproj=args.pproj, no_history=int(args.no_history), **heat)
     A.init()
     info = A.info()
     assert info["nsteps"] == args.nsteps, info
 
     # ---- Krylov basis of m orthonormal vectors + one work column, resident in HBM
-    B = host.KrylovBasis(gm, m + 1)
+    B = host.KrylovBasis(gm, m + 1, nscal, lorder)
     for j in range(m):
         v = B[j]
         v.rand(False, seed=100 + j)
@@ -274,7 +283,7 @@ def main():
     nshared = int(np.sum(counts[inv] > 1))
     lvs = -(-gm.lvn // 32) * 32
     lps = -(-gm.lpn // 32) * 32
-    abytes = algorithmic_bytes(dominant, E, n, dim, m, dim, lvs, lps, nshared, dim * lvs + lps)
+    abytes = algorithmic_bytes(dominant, E, n, dim, m, dim + nscal, lvs, lps, nshared, (dim + nscal) * lvs + lps, lorder)
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None, "traffic": None, "launches": cnt.value, "timed_every": PROF_STRIDE, "avg_ms": avg_ms,
                 "algorithmic_bytes_per_launch": abytes,
@@ -307,7 +316,7 @@ def main():
     # U1+U2 = element-local Helmholtz operator + gather-scatter per scalar field; U3 = CGS2 + norm + scale at k = m
     u12_per_s, u3_ms, u3_vs_k = None, None, None
     if not args.no_units:
-        va, vb = host.nek_dvector(gm), host.nek_dvector(gm)
+        va, vb = host.nek_dvector(gm, nscal), host.nek_dvector(gm, nscal)
         va.rand(False, seed=7)
         nrep = 20
         host.check(lib.nlg_op_helmholtz(gm.h, va.h, vb.h, 1.0 / args.re, 1.0, 1))
@@ -386,7 +395,8 @@ def main():
             "config": {"workload": "3-D deformed box E=%d (%s) lx1=%d (N=%d), Krylov dim m=%d, exptA: Re=%g bdf3/ext3 "
                                    "nsteps=%d(+2 history steps), tol 1e-9/1e-7, one Arnoldi iteration per step at k=m"
                                    % (E_global, "x".join(map(str, gnel)), n, n - 1, m, args.re, args.nsteps),
-                       "vectors_per_step": sblk,
+                       "vectors_per_step": sblk, "restart_history": not args.no_history, "ifheat": bool(args.ifheat),
+                       "basis_bytes": (m + 1) * ((dim + nscal) * lvs + lps) * lorder * 8,
                        "elements_per_gpu": E_global / world, "partition": "rcb" if args.scaling == "strong" else "stacked",
                        "partition_sizes": part_sizes, "time_steps_per_matvec": steps_per_mv / sblk,
                        "pressure_iters_per_time_step": p_iters, "helmholtz_iters_per_time_step": v_iters,

@@ -253,6 +253,14 @@ typedef struct nlg_exptA_config {
     double conductivity;
     double rhocp;
     double buoy[3];
+    int no_history;    /* 1: no restart history -- every matvec starts impulsively (BDF1, then BDF2, ...) from vec_in alone and
+                          fills no history slots: vec_in's slots are ignored, vec_out%nrst = 0, vectors of lorder = 1 are accepted.
+                          The reference always carries lorder - 1 history copies (src/vectors/neklab_vectors.f90:26-36,
+                          exponential_propagator.f90:44,52), which triples the memory of every Krylov vector; this switch is the
+                          memory plan for bases that do not fit otherwise (DESIGN.md "memory plan"): the propagator it defines is a
+                          slightly different discretisation of exp(tau L) (start-up at first order: +4e-5 in the cylinder's leading
+                          multiplier), but ONE linear map for every column of the Arnoldi relation.  0 (default): the reference's
+                          protocol. */
 } nlg_exptA_config;
 
 int nlg_exptA_config_default(nlg_exptA_config *cfg);

@@ -37,6 +37,7 @@ class ExptAConfig(C.Structure):
         ("torder", C.c_int), ("maxit_v", C.c_int), ("maxit_p", C.c_int),
         ("fixed_iters_v", C.c_int), ("fixed_iters_p", C.c_int), ("pprecond", C.c_int), ("pproj", C.c_int),
         ("ifheat", C.c_int), ("conductivity", C.c_double), ("rhocp", C.c_double), ("buoy", C.c_double * 3),
+        ("no_history", C.c_int),
     ]
 
 

@@ -1647,10 +1647,11 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
               "exptA matvec: vector on a different mesh (reference: type_error, exponential_propagator.f90:53-58)");
     NLG_CHECK(vin->nscal == (op->cfg.ifheat ? 1 : 0) && vout->nscal == vin->nscal,
               "exptA matvec: the vectors carry %d scalar(s), the operator expects %d (cfg.ifheat)", vin->nscal, op->cfg.ifheat ? 1 : 0);
-    NLG_CHECK(vin->lorder >= op->cfg.torder && vout->lorder >= op->cfg.torder,
+    const bool nohist = op->cfg.no_history != 0;
+    NLG_CHECK(nohist || (vin->lorder >= op->cfg.torder && vout->lorder >= op->cfg.torder),
               "exptA matvec: vector lorder %d < time order %d", vin->lorder, op->cfg.torder);
     NLG_CHECK(vin != vout, "exptA matvec: vec_in and vec_out must be distinct (intent(in) / intent(out))");
-    const int nrst = op->cfg.torder - 1;
+    const int nrst = nohist ? 0 : op->cfg.torder - 1;   // no_history: impulsive start, no history steps (include/neklab_gpu.h)
     NLG_TRY(reset_state(op, 1));
     op->istep = 0;
     op->adjoint = adjoint;
@@ -1777,6 +1778,7 @@ int nlg_exptA_config_default(nlg_exptA_config *c) {
     c->conductivity = 1.0;
     c->rhocp = 1.0;
     c->pproj = 1;   // residualProj = yes for the pressure, as in the reference's cylinder case (1cyl.par:23)
+    c->no_history = 0;
     return 0;
 }
 
@@ -2167,7 +2169,7 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
     for (int v = 0; v < s; ++v) {
         NLG_CHECK(vin[v] && vout[v] && vin[v]->mesh == m && vout[v]->mesh == m, "exptA block matvec: vector %d NULL or on a different mesh", v);
         NLG_CHECK(vin[v]->nscal == 0 && vout[v]->nscal == 0, "exptA block matvec: vector %d carries scalars", v);
-        NLG_CHECK(vin[v]->lorder >= op->cfg.torder && vout[v]->lorder >= op->cfg.torder, "exptA block matvec: vector lorder < time order");
+        NLG_CHECK(op->cfg.no_history || (vin[v]->lorder >= op->cfg.torder && vout[v]->lorder >= op->cfg.torder), "exptA block matvec: vector lorder < time order");
         for (int u = 0; u < s; ++u) NLG_CHECK(vin[v] != vout[u], "exptA block matvec: an input vector is also an output vector");
         for (int u = 0; u < v; ++u) NLG_CHECK(vout[v] != vout[u], "exptA block matvec: the same output vector twice");
     }
@@ -2179,7 +2181,7 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
     }
     NLG_TRY(slab_ensure(op, s));
     NLG_TRY(reset_state(op, s));
-    const int nrst = op->cfg.torder - 1;
+    const int nrst = op->cfg.no_history ? 0 : op->cfg.torder - 1;
     for (int v = 0; v < s; ++v) {
         nlg_linop *ln = ops[v];
         ln->istep = 0;

@@ -31,6 +31,7 @@ module neklab_gpu_capi
       integer(c_int) :: torder = 3, maxit_v = 200, maxit_p = 2000, fixed_iters_v = 0, fixed_iters_p = 0, pprecond = 0, pproj = 1
       integer(c_int) :: ifheat = 0
       real(c_double) :: conductivity = 1.0_c_double, rhocp = 1.0_c_double, buoy(3) = 0.0_c_double
+      integer(c_int) :: no_history = 0
    end type
 
    type, bind(C), public :: nlg_eigs_opts

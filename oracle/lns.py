@@ -51,6 +51,7 @@ class LNSConfig:
     conductivity: float = 1.0
     rhocp: float = 1.0
     buoy: tuple = (0.0, 0.0, 0.0)
+    no_history: bool = False    # no restart history: impulsive start of every matvec, no history steps (nlg_exptA_config.no_history)
 
 
 def dt_rule(tau, cfl_at_unit_dt, cfl_limit):
@@ -324,7 +325,7 @@ class ExptA:
 
     # ---------------- reference: exponential_propagator.f90:15-60 / :62-107 ----------------
     def matvec(self, vec_in: NekDVector, adjoint=False) -> NekDVector:
-        nrst = self.cfg.torder - 1
+        nrst = 0 if self.cfg.no_history else self.cfg.torder - 1
         vec_out = NekDVector(self.sem, vec_in.nscal, vec_in.lorder)   # intent(out): default-initialised
         self._reset_state(vec_in, adjoint)
         if getattr(self, "proj_lab", None) is not None:

@@ -229,6 +229,44 @@ def test_eigs_against_oracle(gpu_ctx):
     assert abs(float(rows[0][3]) - abs(mu[0])) < 1e-12
 
 
+def test_no_history_mode_matches_oracle(gpu_ctx):
+    """cfg.no_history (the memory plan for bases that do not fit with lorder - 1 history copies per vector): vectors of lorder = 1, every
+    matvec starts impulsively, no history steps -- against the oracle twin (LNSConfig.no_history): matvec fields, Hessenberg matrix
+    of a 6-step Arnoldi run and its Ritz values to the north_star tolerance 1e-10; and against the reference's protocol on the same
+    vectors: a different start-up, hence a slightly different propagator."""
+    hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), periodic=(True, False), deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    U = [sem.mask[0] * (1.0 + np.sin(sem.X[0]) * np.cos(sem.X[1])), sem.mask[1] * np.sin(2 * sem.X[0]) * np.cos(sem.X[1])]
+    kw = dict(re=10.0, torder=3, tau=0.3, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    oA = ExptA(sem, U, LNSConfig(no_history=True, **kw))
+    gb = host.nek_dvector(gm, 0, 1)
+    for i in range(2):
+        gb.set_field(i, U[i])
+    gA = host.exptA_linop(kw["tau"], gb, no_history=1, **{k: v for k, v in kw.items() if k != "tau"})
+    gA.init()
+    ov = NekDVector(sem)
+    ov.rand(ifnorm=True, seed=3)
+    m = 6
+    B = host.KrylovBasis(gm, m + 1, 0, 1)                # lorder = 1: a third of the memory
+    for i in range(2):
+        B[0].set_field(i, ov.v[i])
+    H, oH = np.zeros((m + 1, m), order="F"), np.zeros((m + 1, m))
+    oV = [ov] + [None] * m
+    for k in range(m):
+        host.arnoldi_step(gA, B, k, H)
+        o_arnoldi_step(oA.matvec, oV, oH, k)
+    assert B[m].nrst == 0 and not oV[m].has_rst_fields()
+    assert np.max(np.abs(H - oH)) < 1e-10 * np.max(np.abs(oH))
+    ev, oev = np.sort_complex(np.linalg.eigvals(H[:m])), np.sort_complex(np.linalg.eigvals(oH[:m]))
+    assert np.max(np.abs(ev - oev)) < 1e-10 * np.max(np.abs(oev))
+    cmp_vec(B[m], oV[m], 1e-9, "last basis vector")
+    # lorder = 1 vectors are refused by the reference's protocol
+    gA3 = host.exptA_linop(kw["tau"], gb, **{k: v for k, v in kw.items() if k != "tau"})
+    gA3.init()
+    with pytest.raises(host.NlgError):
+        gA3.matvec(B[0], B[1])
+
+
 def test_pressure_residual_projection(gpu_ctx):
     """residualProj (1cyl.par:23): the projection onto the previous increments changes the starting guess of the
     pressure solve, not the answer; it saves iterations once the matvec has several time steps."""
