@@ -649,11 +649,15 @@ template <int N>
 __global__ __launch_bounds__(NT) void k_fdm_ext2(const double *__restrict__ flag, int64_t E, const double *__restrict__ S,
                                                  const double *__restrict__ lam, double thr, const double *__restrict__ r,
                                                  const double *__restrict__ wq, double *__restrict__ W,
-                                                 double *__restrict__ z) {
+                                                 double *__restrict__ z, int nb_fdm, AggArgs ag) {
     static_assert(N * N <= 64, "one lane per extended point");
     constexpr int N2 = N - 2, NP = N * N, NP2 = N2 * N2;
     __shared__ double sS[4][2][N * N];
     __shared__ double sA[4][NP], sB[4][NP];
+    if ((int)blockIdx.x >= nb_fdm) {   // merged launch: the aggregate restriction of the coarse chain (see k_fdm_ext)
+        agg_restrict_body((int)blockIdx.x - nb_fdm, flag, 0, ag);
+        return;
+    }
     if (flag && flag[0] != 0.0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 4 + wv;
@@ -2104,7 +2108,7 @@ int pprec_coarse(nlg_mesh *m, hipStream_t st, const double *flag, const double *
     }
     // 3-D overlapping variant: the rest of the coarse chain rides in the launches of the fine level (pprec_fine, merged launches)
     static const bool hfuse = !(getenv("NLG_HFUSE") && atoi(getenv("NLG_HFUSE")) == 0);
-    P.coarse_pending = hfuse && overlap && m->dim == 3 && m->gs.d_indices_fg && m->gs.npairs > 0;
+    P.coarse_pending = hfuse && overlap && m->gs.npairs > 0 && (m->dim == 2 ? nl == 1 : m->gs.d_indices_fg != nullptr);
     if (P.coarse_pending) {
         NLG_HIP(hipGetLastError());
         *xc = P.d_x;
@@ -2169,18 +2173,51 @@ int pprec_fine(nlg_mesh *m, hipStream_t st, const double *flag, const double *r,
     if (overlap && m->dim == 2) {
         NLG_CHECK(P.overlap, "pprec: the overlapping variant is not set up for this mesh");
         const unsigned gb = (unsigned)((E + 3) / 4);
-        NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        // merged launches as in 3-D (below): the vertex gather rides with the first pairs-only gather-scatter (natural layout here),
+        // the aggregate restriction with the local solves, the dense solve with the second gather-scatter
+        const bool fused = P.coarse_pending;
+        P.coarse_pending = false;
+        const int nbp = (int)((m->gs.npairs + NT - 1) / NT);
+        const int nv = P.nvert;
+        const bool glob = P.ncols != P.na;
+        AggArgs ag = {0, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        if (fused) {
+            const GatherArgs gg = {nv, P.d_v2e_p, P.d_v2e_i, P.d_tq, P.d_rc, P.d_dinv, P.na == nv ? 0.0 : 0.7, P.d_x, P.lt, P.lv};
+            NLG_LAUNCH(k_pairs_gather, dim3((unsigned)(nbp + (nv + NT - 1) / NT)), dim3(NT), 0, st, nbp, (const int *)m->gs.d_indices, m->gs.npairs, P.d_W,
+                       (int64_t)0, flag, (int64_t)0, gg);
+            ag = AggArgs{P.na, P.d_ap, P.d_am, P.d_rc, P.d_ra, P.lv, P.la};
+        } else {
+            NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        }
         NLG_TRY(overlap_halo(m, st, false, 1));
+        const unsigned nb_agg = fused ? (unsigned)((P.na + 3) / 4) : 0u;
 #define FX2_CASE(N_)                                                                                                  \
     case N_:                                                                                                          \
-        NLG_LAUNCH((k_fdm_ext2<N_>), dim3(gb), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z); \
+        NLG_LAUNCH((k_fdm_ext2<N_>), dim3(gb + nb_agg), dim3(NT), 0, st, flag, E, P.d_Sx, P.d_lamx, P.thrx, r, P.d_wq, P.d_W, z, (int)gb, ag); \
         break;
         switch (m->n) {
             FX2_CASE(4) FX2_CASE(5) FX2_CASE(6) FX2_CASE(7) FX2_CASE(8)
             default: set_error("pprec: overlapping variant built for lx1 = 4..8, got %d", m->n); return 1;
         }
 #undef FX2_CASE
-        NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        if (fused) {
+            const double *ra = P.d_ra;
+            if (glob) {
+                NLG_CHECK(st == m->ctx->stream, "pprec: the global aggregate level runs on the context's stream");
+                NLG_TRY(allgather_f64(m->ctx, P.d_ra, P.d_rag, (int64_t)P.na_max));
+                ra = P.d_rag;
+            }
+            const dim3 gc((unsigned)(nbp + (P.na + 3) / 4));
+            if (P.d_Ainv32) {
+                const GemvArgs<float> gv = {P.na, P.ncols, (const float *)P.d_Ainv32, ra, P.d_xa, 0, 0, 1};
+                NLG_LAUNCH(k_pairs_gemv<float>, gc, dim3(NT), 0, st, nbp, (const int *)m->gs.d_indices, m->gs.npairs, P.d_W, (int64_t)0, flag, (int64_t)0, gv);
+            } else {
+                const GemvArgs<double> gv = {P.na, P.ncols, (const double *)P.d_Ainv, ra, P.d_xa, 0, 0, 1};
+                NLG_LAUNCH(k_pairs_gemv<double>, gc, dim3(NT), 0, st, nbp, (const int *)m->gs.d_indices, m->gs.npairs, P.d_W, (int64_t)0, flag, (int64_t)0, gv);
+            }
+        } else {
+            NLG_TRY(sem_gs_pairs(m, P.d_W, flag));
+        }
         NLG_TRY(overlap_halo(m, st, false, 1));
         const unsigned gf = (unsigned)((E * m->np2 + NT - 1) / NT);
 #define FF2_CASE(N_)                                                                                                  \
