@@ -400,7 +400,7 @@ void halo_free(nlg_mesh *m);
 // nl / ld / ldg (everywhere below): nl lanes of a block step in ONE launch (gridDim.y = nl): lane v's fields sit v * ld doubles
 // behind the given (lane-0) pointers, its gate v * ldg doubles behind `gate`
 int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate = nullptr, int layout = 0, int nl = 1, int64_t ld = 0, int64_t ldg = 0);   // in place QQ^T; gate: device flag, non-zero = skip; layout: LAYOUT_NAT or LAYOUT_XP
-int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl = 1, int64_t ld = 0);     // natural -> x-planes-first (out of place)
+int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl = 1, int64_t ld = 0, double *const *wts = nullptr);     // natural -> x-planes-first (out of place); wts: dst = wts * src
 int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl = 1, int64_t ld = 0);
 int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr, int nl = 1, int64_t ld = 0, int64_t ldg = 0);
 int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr, int nl = 1, int64_t ld = 0, int64_t ldg = 0);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout

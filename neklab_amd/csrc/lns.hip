@@ -604,8 +604,10 @@ struct Hist {
     double ab[3], bd[3];
     int k;
 };
+// `gp` / `w` non-null: the residual form of the tentative-velocity problem in the same pass, rhs_i += gp_i - w_i (D^T p - H u)
 template <int NF>
-__global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1, double rdt, F3 rhs, int64_t ld) {
+__global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1, double rdt, F3 rhs, int64_t ld, CF3 gp = CF3{{nullptr, nullptr, nullptr}},
+                                            CF3 w = CF3{{nullptr, nullptr, nullptr}}) {
     // (the lane offset is added at the loads: writing it into `h` would move the by-value struct from the kernel-argument segment,
     //  where the runtime index j costs a scalar load, into scratch memory -- measured 123 -> 315 us)
     const int64_t lo = lane_lo(ld);
@@ -619,7 +621,9 @@ __global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1
                 a += h.ab[j] * h.f[j][c][lo + i];
                 u += h.bd[j] * h.u[j][c][lo + i];
             }
-            rhs.p[c][i] = a + b * u;
+            double v = a + b * u;
+            if (gp.p[c]) v = (v + gp.p[c][lo + i]) - w.p[c][lo + i];
+            rhs.p[c][i] = v;
         }
     }
 }
@@ -637,6 +641,31 @@ __global__ __launch_bounds__(NT) void k_lin3(int64_t n, F3 y, CF3 a, CF3 b, doub
             if (c.p[q]) v += s2 * c.p[q][i];
             y.p[q][i] = v;
         }
+    }
+}
+
+// y_c = a_c + b_c with b stored in the slab-permuted element layout (the solution of the velocity PCG): the un-permutation rides in
+// the update of the velocity instead of being a pass of its own
+template <int NF>
+__global__ __launch_bounds__(NT) void k_add_xp(int64_t n, int np, const int *__restrict__ slot, F3 y, CF3 a, CF3 b, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    y = lane_f3(y, lo), a = lane_f3(a, lo), b = lane_f3(b, lo);
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int64_t e = i / np;
+        const int64_t q = e * np + slot[(int)(i - e * np)];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) y.p[c][i] = a.p[c][i] + b.p[c][q];
+    }
+}
+
+// y_c += s * wt_c * x_c  (velocity correction: the inverse mass / mask weights of opbinv ride in the update)
+template <int NF>
+__global__ __launch_bounds__(NT) void k_axpy_w(int64_t n, F3 y, CF3 x, CF3 wt, double s, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    y = lane_f3(y, lo), x = lane_f3(x, lo);
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+#pragma unroll
+        for (int c = 0; c < NF; ++c) y.p[c][i] += s * (wt.p[c][i] * x.p[c][i]);
     }
 }
 
@@ -695,6 +724,7 @@ struct nlg_linop {
     // work
     double *rhs[3] = {}, *x[3] = {}, *z[3] = {}, *pv[3] = {}, *w[3] = {}, *gp[3] = {};
     double *pr_r = nullptr, *pr_x = nullptr, *pr_z = nullptr, *pr_p = nullptr, *pr_w = nullptr;
+    double *pr_b = nullptr;    // the right-hand side the pressure PCG started from (after the projection): A x = b - r afterwards
     double *pcv[4][3] = {};    // mask_i / diag(H) per BDF order
     // velocity PCG in the x-planes-first layout (3-D, lx1 <= 8: internal.h xp_slot): the preconditioners and the residual
     // weight permuted once; 0 = natural layout (2-D, lx1 > 8, NLG_XP=0)
@@ -780,7 +810,7 @@ void lane_buffers(nlg_linop *op, F f) {
     }
     if (op->cfg.ifheat)
         for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) f(v, m->lvs);
-    for (double **q : {&op->p, &op->pr_r, &op->pr_x, &op->pr_z, &op->pr_p, &op->pr_w}) f(q, m->lps);
+    for (double **q : {&op->p, &op->pr_r, &op->pr_x, &op->pr_z, &op->pr_p, &op->pr_w, &op->pr_b}) f(q, m->lps);
     if (op->cfg.pproj) {
         f(&op->prX, (int64_t)PROJ_L * m->lps);
         f(&op->prB, (int64_t)PROJ_L * m->lps);
@@ -1016,7 +1046,7 @@ int helm_problem(const Lanes &L, int order, double h2, HelmSolve &H) {
     const bool xp = op->use_xp > 0;
     H.xp = xp;
     H.h2 = h2;
-    if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim, L.nl, L.ld()));
+    if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim, L.nl, L.ld(), m->d_mask));   // ... and masked on the way (adv_a leaves the mask to this pass)
     P.nf = dim;
     P.n = m->lvn;
     P.x = op->x;
@@ -1066,7 +1096,7 @@ int helm_apply(const Lanes &L, const HelmSolve &H) {
 
 int helm_finish(const Lanes &L, const HelmSolve &H, const int *iters) {
     nlg_linop *op = L.op();
-    if (H.xp) NLG_TRY(sem_from_xp(op->mesh, op->x, op->rhs, op->mesh->dim, L.nl, L.ld()));   // the increment, natural layout
+    (void)op;   // (slab-permuted solve: the increment stays in that layout, adv_b reads it through the slot table)
     for (int v = 0; v < L.nl; ++v) {
         nlg_linop *ln = L.ops[v];
         ln->st_viters += iters[v];
@@ -1279,6 +1309,9 @@ int pres_problem(const Lanes &L, double scale, PresSolve &Q) {
         NLG_LAUNCH(k_proj_comb, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->pr_r, (const double *)op->prB, m->lps,
                    Q.nold, (const double *)alpha, -1.0, ld);               // b <- b - B alpha
     }
+    if (Q.proj)   // the right-hand side of the PCG, kept for the update of the projection space: A d = b - r_final
+        NLG_HIP(hipMemcpy2DAsync(op->pr_b, sizeof(double) * (size_t)std::max<int64_t>(ld, m->lpn), op->pr_r, sizeof(double) * (size_t)std::max<int64_t>(ld, m->lpn),
+                                 sizeof(double) * (size_t)m->lpn, (size_t)nl, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -1329,16 +1362,14 @@ int pres_finish(const Lanes &L, const PresSolve &Q, const int *iters) {
             for (int v = 0; v < nl; ++v) NLG_TRY(allreduce_sum(m->ctx, out + v * ld, nvec));
             return 0;
         };
-        // new member from the increment d = pr_x: w = A d, A-orthogonalised against the old members, normalised
-        if (nl == 1) {
-            NLG_TRY(sem_cdabdtp(m, op->pr_x, op->pr_w));
-        } else {
-            const double *pp[kMaxLanes];
-            double *ww[kMaxLanes], *none[kMaxLanes] = {};
-            for (int v = 0; v < nl; ++v) pp[v] = op->pr_x + v * ld, ww[v] = op->pr_w + v * ld;
-            NLG_TRY(sem_cdabdtp_lanes(m, nl, pp, ww, none, nullptr, nullptr));
+        // new member from the increment d = pr_x: w = A d, A-orthogonalised against the old members, normalised.  A d is not
+        // computed by another application of E (three launches, 4 % of a time step): the PCG started from r = b and updated
+        // r <- r - alpha A p with x <- x + alpha p, so A d = b - r_final, mean-free like b and r (A = P E P)
+        {
+            F3 y = {{op->pr_w, nullptr, nullptr}};
+            CF3 a = {{op->pr_b, nullptr, nullptr}}, b = {{op->pr_r, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
+            NLG_LAUNCH(k_lin3<1>, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, y, a, b, -1.0, none, 0.0, ld);
         }
-        if (!m->has_outflow) NLG_TRY(sem_ortho(m, op->pr_w, nl, ld));                // A = P E P
         ProfScope ps(m->ctx, P_VECOPS);
         NLG_HIP(hipMemcpy2DAsync(op->pr_z, sizeof(double) * (size_t)std::max<int64_t>(ld, m->lpn), op->pr_x, sizeof(double) * (size_t)std::max<int64_t>(ld, m->lpn),
                                  sizeof(double) * (size_t)m->lpn, (size_t)nl, hipMemcpyDeviceToDevice, st));   // v = d (all lanes)
@@ -1441,9 +1472,7 @@ int adv_a(const Lanes &L) {
             h.u[j][c] = op->ubuf[j][c];
         }
     }
-    launch_nf(dim, k_rhs<1>, k_rhs<2>, k_rhs<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, h, (const double *)m->d_bm1, 1.0 / dt,
-              f3(op->rhs, dim), ld);
-    // residual form: res = mask QQ^T (rhs + D^T p - H u)
+    // residual form: res = mask QQ^T (rhs + D^T p - H u); the history sums and the two operator terms in ONE pass over the fields
     const double h2 = b0 / dt;
     if (nl == 1) {
         NLG_TRY(sem_opgradt(m, op->p, op->gp));
@@ -1454,10 +1483,10 @@ int adv_a(const Lanes &L) {
         NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, false, nullptr));
     }
     NLG_TRY(sem_axhelm(m, op->ubuf[0], op->w, dim, nu, h2, nullptr, nullptr, nullptr, nullptr, false, nl, ld));
-    launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(op->rhs, dim), cf3(op->rhs, dim),
-              cf3(op->gp, dim), 1.0, cf3(op->w, dim), -1.0, ld);
+    launch_nf(dim, k_rhs<1>, k_rhs<2>, k_rhs<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, h, (const double *)m->d_bm1, 1.0 / dt,
+              f3(op->rhs, dim), ld, cf3(op->gp, dim), cf3(op->w, dim));
     NLG_TRY(sem_gs(m, op->rhs, dim, nullptr, LAYOUT_NAT, nl, ld, 0));
-    {
+    if (op->use_xp <= 0) {   // (slab-permuted velocity solve: the mask is applied by the permutation of the right-hand side, helm_problem)
         CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
         launch_nf(dim, k_colmul_gated<1>, k_colmul_gated<2>, k_colmul_gated<3>, lgrid(grid_for(m->lvn), nl), st,
                   (const double *)nullptr, f3(op->rhs, dim), mk, m->lvn, ld);
@@ -1474,10 +1503,13 @@ int adv_b(const Lanes &L) {
     const double dt = op->dt, b0 = op->adv_b0;
     // uh = u + du -> into the oldest velocity buffer (slot 2), which becomes the new current after rotation
     double **unew = op->ubuf[2];
-    {
+    if (op->use_xp > 0) {
+        launch_nf(dim, k_add_xp<1>, k_add_xp<2>, k_add_xp<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, m->np1, (const int *)m->d_slot_xp, f3(unew, dim),
+                  cf3(op->ubuf[0], dim), cf3(op->x, dim), ld);
+    } else {
         CF3 none = {{nullptr, nullptr, nullptr}};
         launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(op->ubuf[0], dim),
-                  cf3(op->use_xp > 0 ? op->rhs : op->x, dim), 1.0, none, 0.0, ld);
+                  cf3(op->x, dim), 1.0, none, 0.0, ld);
     }
     // pressure correction
     if (nl == 1) {
@@ -1509,11 +1541,11 @@ int adv_c(const Lanes &L) {
         for (int v = 0; v < nl; ++v) pp[v] = L.ops[v]->pr_x, gl[v] = L.ops[v]->gp;
         NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, false, nullptr));
     }
-    NLG_TRY(sem_opbinv(m, op->gp, nl, ld));
+    // u = uh + (dt / b0) mask binv QQ^T D^T dp: gather-scatter, then weights and update in one pass
+    NLG_TRY(sem_gs(m, op->gp, dim, nullptr, LAYOUT_NAT, nl, ld, 0));
     {
-        CF3 none = {{nullptr, nullptr, nullptr}};
-        launch_nf(dim, k_lin3<1>, k_lin3<2>, k_lin3<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(unew, dim),
-                  cf3(op->gp, dim), dt / b0, none, 0.0, ld);
+        CF3 wt = {{m->d_mbinv[0], m->d_mbinv[1], m->d_mbinv[2]}};
+        launch_nf(dim, k_axpy_w<1>, k_axpy_w<2>, k_axpy_w<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(op->gp, dim), wt, dt / b0, ld);
     }
     NLG_HIP(hipGetLastError());
     // rotate velocity history: new -> current, current -> lag1, lag1 -> lag2

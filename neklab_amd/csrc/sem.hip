@@ -2467,7 +2467,8 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int l
 
 // natural <-> x-planes-first, out of place, one thread per point
 template <int NF, bool TO>
-__global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__restrict__ slot, CF3 src, F3 dst, int64_t ld) {
+__global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__restrict__ slot, CF3 src, F3 dst, int64_t ld, CF3 wt) {
+    // wt (natural layout, TO only; may be null): dst = wt * src -- the Dirichlet mask of a right-hand side rides in its permutation
 #pragma unroll
     for (int c = 0; c < NF; ++c) src.p[c] += (int64_t)blockIdx.y * ld, dst.p[c] += (int64_t)blockIdx.y * ld;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -2476,24 +2477,25 @@ __global__ __launch_bounds__(NT) void k_xp_perm(int64_t n, int np, const int *__
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             if (TO)
-                dst.p[c][q] = src.p[c][i];
+                dst.p[c][q] = wt.p[c] ? wt.p[c][i] * src.p[c][i] : src.p[c][i];
             else
                 dst.p[c][i] = src.p[c][q];
         }
     }
 }
 
-static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, bool to, int nl, int64_t ld) {
+static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, bool to, int nl, int64_t ld, double *const *wts = nullptr) {
     NLG_CHECK(m->d_slot_xp && nf >= 1 && nf <= 3, "sem_to_xp: no x-planes-first table (3-D only) or bad field count");
     CF3 a = {{src[0], nf > 1 ? src[1] : nullptr, nf > 2 ? src[2] : nullptr}};
     F3 b = {{dst[0], nf > 1 ? dst[1] : nullptr, nf > 2 ? dst[2] : nullptr}};
     const dim3 g(grid_for(m->lvn), nl), t(NT);
     hipStream_t st = m->ctx->stream;
+    CF3 wt = {{wts ? wts[0] : nullptr, (wts && nf > 1) ? wts[1] : nullptr, (wts && nf > 2) ? wts[2] : nullptr}};
 #define XPL(NF_)                                                                                               \
     if (to)                                                                                                    \
-        NLG_LAUNCH((k_xp_perm<NF_, true>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b, ld);  \
+        NLG_LAUNCH((k_xp_perm<NF_, true>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b, ld, wt);  \
     else                                                                                                       \
-        NLG_LAUNCH((k_xp_perm<NF_, false>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b, ld);
+        NLG_LAUNCH((k_xp_perm<NF_, false>), g, t, 0, st, m->lvn, m->np1, (const int *)m->d_slot_xp, a, b, ld, wt);
     if (nf == 1) {
         XPL(1)
     } else if (nf == 2) {
@@ -2505,7 +2507,7 @@ static int xp_perm(nlg_mesh *m, double *const *src, double *const *dst, int nf, 
     NLG_HIP(hipGetLastError());
     return 0;
 }
-int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl, int64_t ld) { return xp_perm(m, src, dst, nf, true, nl, ld); }
+int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl, int64_t ld, double *const *wts) { return xp_perm(m, src, dst, nf, true, nl, ld, wts); }
 int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl, int64_t ld) { return xp_perm(m, src, dst, nf, false, nl, ld); }
 
 // (element, field) slots per block of k_axhelm3: bounded by 512 threads and by 64 KB of dynamic LDS
