@@ -14,7 +14,7 @@
 !!   integrate_forced                     src/linops/resolvent.f90:80-111, :133-166
 module neklab_linops
    use iso_c_binding
-   use LightKrylov, only: dp, abstract_vector_rdp, abstract_exptA_linop_rdp, type_error
+   use LightKrylov, only: dp, abstract_vector_rdp, abstract_exptA_linop_rdp, abstract_vector_cdp, abstract_linop_cdp, type_error
    use neklab_gpu_capi
    use neklab_vectors
    implicit none
@@ -75,6 +75,22 @@ module neklab_linops
       procedure, pass(self), public :: set_lines => proj_set_lines
       procedure, pass(self), public :: proj => proj_apply
    end type exptA_proj_linop
+
+   !--------------------------------------
+   !-----     RESOLVENT OPERATOR     -----
+   !--------------------------------------
+   !> resolvent_linop(omega, baseflow) (src/linops/neklab_linops.f90:198-205, resolvent.f90): R(omega) f by time stepping -- one
+   !! forcing period from rest (nlg_linop_integrate_forced), the real part from (I - exp(T L)) x = b by GMRES(64) at rtol 1e-6
+   !! (resolvent.f90:113-131; restated here on the type-bound procedures, LightKrylov's gmres options are not in the reference
+   !! tree), the imaginary part = the state a quarter period later; rmatvec integrates the adjoint equations.
+   type, extends(abstract_linop_cdp), public :: resolvent_linop
+      real(kind=dp) :: omega = 0.0_dp
+      type(nek_dvector) :: baseflow
+   contains
+      private
+      procedure, pass(self), public :: matvec => resolvent_matvec
+      procedure, pass(self), public :: rmatvec => resolvent_rmatvec
+   end type
 
 contains
 
@@ -284,6 +300,112 @@ contains
       type(nek_dvector), intent(inout) :: vec
       call nek_dvector_ensure(vec)
       call nlg_check(c_linop_project(exptA_handle(self), vec%h), 'exptA_proj proj')
+   end subroutine
+
+   !---- resolvent ------------------------------------------------------------------------------------------------------
+   subroutine resolvent_apply(self, vec_in, vec_out, adjoint)
+      class(resolvent_linop), intent(inout) :: self
+      class(abstract_vector_cdp), intent(in) :: vec_in
+      class(abstract_vector_cdp), intent(out) :: vec_out
+      logical, intent(in) :: adjoint
+      real(dp), parameter :: two_pi = 8.0_dp*atan(1.0_dp)
+      type(exptA_linop) :: exptA
+      type(nek_dvector) :: b
+      real(dp) :: tau
+      tau = 1.0_dp
+      if (self%omega /= 0.0_dp) tau = two_pi/abs(self%omega)
+      exptA%tau = tau; exptA%baseflow = self%baseflow
+      call exptA%init()
+      select type (vec_in)
+      type is (nek_zvector)
+         select type (vec_out)
+         type is (nek_zvector)
+            call exptA%integrate_forced(vec_in%re, self%omega, b, f_im=vec_in%im, adjoint=adjoint)      ! evaluate_rhs
+            call solve_real_part(exptA, b, vec_out%re, adjoint)
+            exptA%tau = 0.25_dp*tau                                                                      ! resolvent.f90:35
+            call exptA%integrate_forced(vec_in%re, self%omega, vec_out%im, ic=vec_out%re, f_im=vec_in%im, adjoint=adjoint)
+         class default
+            call type_error('vec_out', 'nek_zvector', 'OUT', this_module, 'resolvent_matvec')
+         end select
+      class default
+         call type_error('vec_in', 'nek_zvector', 'IN', this_module, 'resolvent_matvec')
+      end select
+   end subroutine
+
+   subroutine resolvent_matvec(self, vec_in, vec_out)
+      class(resolvent_linop), intent(inout) :: self
+      class(abstract_vector_cdp), intent(in) :: vec_in
+      class(abstract_vector_cdp), intent(out) :: vec_out
+      call resolvent_apply(self, vec_in, vec_out, .false.)
+   end subroutine
+
+   subroutine resolvent_rmatvec(self, vec_in, vec_out)
+      class(resolvent_linop), intent(inout) :: self
+      class(abstract_vector_cdp), intent(in) :: vec_in
+      class(abstract_vector_cdp), intent(out) :: vec_out
+      call resolvent_apply(self, vec_in, vec_out, .true.)
+   end subroutine
+
+   !> (I - exp(T L)) x = b, x0 = 0, restarted GMRES(64) with Givens rotations, |r| <= max(1e-6 |b|, 1e-12).  Krylov vectors lose their
+   !! restart history (each application starts impulsively, like the forced integration whose periodic state is sought).
+   subroutine solve_real_part(exptA, b, x, adjoint)
+      type(exptA_linop), intent(inout) :: exptA
+      type(nek_dvector), intent(in) :: b
+      type(nek_dvector), intent(inout) :: x
+      logical, intent(in) :: adjoint
+      integer, parameter :: kd = 64, maxcycle = 10
+      type(nek_dvector), allocatable :: V(:)
+      type(nek_dvector) :: w
+      real(dp) :: H(kd + 1, kd), cs(kd), sn(kd), g(kd + 1), y(kd), beta, t, d, tol
+      integer :: k, i, j, cyc
+      tol = max(1.0e-6_dp*b%norm(), 1.0e-12_dp)
+      call x%zero()
+      allocate (V(kd + 1))
+      do cyc = 1, maxcycle
+         call V(1)%zero(); call V(1)%axpby(1.0_dp, b, 0.0_dp)
+         if (cyc > 1) then                                   ! r = b - (x - A x)
+            if (adjoint) then
+               call exptA%rmatvec(x, w)
+            else
+               call exptA%matvec(x, w)
+            end if
+            call w%clear_rst_fields()
+            call V(1)%axpby(-1.0_dp, x, 1.0_dp); call V(1)%axpby(1.0_dp, w, 1.0_dp)
+         end if
+         beta = V(1)%norm()
+         if (beta <= tol) return
+         call V(1)%scal(1.0_dp/beta)
+         H = 0.0_dp; g = 0.0_dp; g(1) = beta; k = 0
+         do j = 1, kd
+            if (adjoint) then
+               call exptA%rmatvec(V(j), V(j + 1))
+            else
+               call exptA%matvec(V(j), V(j + 1))
+            end if
+            call V(j + 1)%clear_rst_fields()
+            call V(j + 1)%axpby(1.0_dp, V(j), -1.0_dp)         ! (I - A) v_j
+            do i = 1, j
+               H(i, j) = V(i)%dot(V(j + 1)); call V(j + 1)%axpby(-H(i, j), V(i), 1.0_dp)
+            end do
+            H(j + 1, j) = V(j + 1)%norm()
+            if (H(j + 1, j) > 0.0_dp) call V(j + 1)%scal(1.0_dp/H(j + 1, j))
+            do i = 1, j - 1
+               t = cs(i)*H(i, j) + sn(i)*H(i + 1, j); H(i + 1, j) = -sn(i)*H(i, j) + cs(i)*H(i + 1, j); H(i, j) = t
+            end do
+            d = hypot(H(j, j), H(j + 1, j)); cs(j) = H(j, j)/d; sn(j) = H(j + 1, j)/d
+            H(j, j) = d; H(j + 1, j) = 0.0_dp
+            g(j + 1) = -sn(j)*g(j); g(j) = cs(j)*g(j)
+            k = j
+            if (abs(g(j + 1)) <= tol) exit
+         end do
+         do i = k, 1, -1
+            y(i) = (g(i) - dot_product(H(i, i + 1:k), y(i + 1:k)))/H(i, i)
+         end do
+         do i = 1, k
+            call x%axpby(y(i), V(i), 1.0_dp)
+         end do
+         if (abs(g(k + 1)) <= tol) return
+      end do
    end subroutine
 
    !---- eigs / svds on the device block path ---------------------------------------------------------------------------

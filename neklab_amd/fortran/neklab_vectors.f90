@@ -26,7 +26,7 @@
 !! reference (src/neklab_nek_setup.f90:406-417); a wrong dynamic type calls type_error as the reference does.
 module neklab_vectors
    use iso_c_binding
-   use LightKrylov, only: dp, abstract_vector_rdp, type_error
+   use LightKrylov, only: dp, abstract_vector_rdp, abstract_vector_cdp, type_error
    use neklab_gpu_capi
    implicit none
    private
@@ -54,6 +54,21 @@ module neklab_vectors
       generic, public :: assignment(=) => assign_dvector
       final :: finalize_dvector, finalize_dvector_rank1
    end type nek_dvector
+
+   !> Complex vector as a (re, im) pair of real ones (reference: type nek_zvector, src/vectors/neklab_vectors.f90, complex_vectors.f90:
+   !! the forcing and the response of the resolvent operator).  The inner product is <a, b> = sum conj(a) b in the mass-weighted
+   !! velocity inner product of nek_dvector.
+   type, extends(abstract_vector_cdp), public :: nek_zvector
+      type(nek_dvector) :: re, im
+   contains
+      private
+      procedure, pass(self), public :: zero => nek_zzero
+      procedure, pass(self), public :: rand => nek_zrand
+      procedure, pass(self), public :: scal => nek_zscal
+      procedure, pass(self), public :: axpby => nek_zaxpby
+      procedure, pass(self), public :: dot => nek_zdot
+      procedure, pass(self), public :: get_size => nek_zsize
+   end type nek_zvector
 
    ! --> Constructor (reference: construct_nek_dvector, neklab_vectors.f90:53-61; not pure: it allocates device memory)
    interface nek_dvector
@@ -226,6 +241,70 @@ contains
       call nek_dvector_ensure(self)
       call nlg_check(c_vec_clear_rst(self%h), 'dclear_rst_fields')
    end subroutine
+
+   !---- nek_zvector: every operation is the complex arithmetic of the pair, through the real vector's procedures ------------
+   subroutine nek_zzero(self)
+      class(nek_zvector), intent(inout) :: self
+      call self%re%zero(); call self%im%zero()
+   end subroutine
+
+   subroutine nek_zrand(self, ifnorm)
+      class(nek_zvector), intent(inout) :: self
+      logical, optional, intent(in) :: ifnorm
+      real(dp) :: nrm
+      call self%re%rand(.false.); call self%im%rand(.false.)
+      if (present(ifnorm)) then
+         if (ifnorm) then
+            nrm = sqrt(self%re%dot(self%re) + self%im%dot(self%im))
+            call self%re%scal(1.0_dp/nrm); call self%im%scal(1.0_dp/nrm)
+         end if
+      end if
+   end subroutine
+
+   subroutine nek_zscal(self, alpha)
+      class(nek_zvector), intent(inout) :: self
+      complex(dp), intent(in) :: alpha
+      type(nek_dvector) :: old_re
+      old_re = self%re
+      call self%re%axpby(-aimag(alpha), self%im, real(alpha, dp))      ! re <- Re(a) re - Im(a) im
+      call self%im%axpby(aimag(alpha), old_re, real(alpha, dp))        ! im <- Re(a) im + Im(a) re
+   end subroutine
+
+   subroutine nek_zaxpby(alpha, vec, beta, self)
+      class(nek_zvector), intent(inout) :: self
+      complex(dp), intent(in) :: alpha
+      class(abstract_vector_cdp), intent(in) :: vec
+      complex(dp), intent(in) :: beta
+      select type (vec)
+      type is (nek_zvector)
+         call nek_zscal(self, beta)
+         call self%re%axpby(real(alpha, dp), vec%re, 1.0_dp); call self%re%axpby(-aimag(alpha), vec%im, 1.0_dp)
+         call self%im%axpby(real(alpha, dp), vec%im, 1.0_dp); call self%im%axpby(aimag(alpha), vec%re, 1.0_dp)
+      class default
+         write (*, '(A)') 'ERROR in '//this_module//"::nek_zaxpby: the intent [IN] argument 'vec' must be of type 'nek_zvector'"
+         error stop 1
+      end select
+   end subroutine
+
+   function nek_zdot(self, vec) result(alpha)
+      class(nek_zvector), intent(in) :: self
+      class(abstract_vector_cdp), intent(in) :: vec
+      complex(dp) :: alpha
+      alpha = (0.0_dp, 0.0_dp)
+      select type (vec)
+      type is (nek_zvector)
+         alpha = cmplx(self%re%dot(vec%re) + self%im%dot(vec%im), self%re%dot(vec%im) - self%im%dot(vec%re), kind=dp)
+      class default
+         write (*, '(A)') 'ERROR in '//this_module//"::nek_zdot: the intent [IN] argument 'vec' must be of type 'nek_zvector'"
+         error stop 1
+      end select
+   end function
+
+   pure function nek_zsize(self) result(n)
+      class(nek_zvector), intent(in) :: self
+      integer :: n
+      n = 2*self%re%get_size()
+   end function
 
    !> intrinsic-assignment semantics of the reference's by-value vectors: deep copy
    subroutine assign_dvector(lhs, rhs)

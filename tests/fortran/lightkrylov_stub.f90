@@ -106,6 +106,67 @@ module LightKrylov
       real(dp) :: tau = 1.0_dp
    end type
 
+   !> complex vectors and operators (src/vectors/neklab_vectors.f90: nek_zvector; src/linops/neklab_linops.f90:198-205: resolvent_linop)
+   type, abstract, public :: abstract_vector_cdp
+   contains
+      procedure(abstract_zzero), pass(self), deferred, public :: zero
+      procedure(abstract_zrand), pass(self), deferred, public :: rand
+      procedure(abstract_zscal), pass(self), deferred, public :: scal
+      procedure(abstract_zaxpby), pass(self), deferred, public :: axpby
+      procedure(abstract_zdot), pass(self), deferred, public :: dot
+      procedure(abstract_zsize), pass(self), deferred, public :: get_size
+      procedure, pass(self), public :: norm => zvec_norm
+   end type
+
+   abstract interface
+      subroutine abstract_zzero(self)
+         import abstract_vector_cdp
+         class(abstract_vector_cdp), intent(inout) :: self
+      end subroutine
+      subroutine abstract_zrand(self, ifnorm)
+         import abstract_vector_cdp
+         class(abstract_vector_cdp), intent(inout) :: self
+         logical, optional, intent(in) :: ifnorm
+      end subroutine
+      subroutine abstract_zscal(self, alpha)
+         import abstract_vector_cdp, dp
+         class(abstract_vector_cdp), intent(inout) :: self
+         complex(dp), intent(in) :: alpha
+      end subroutine
+      subroutine abstract_zaxpby(alpha, vec, beta, self)
+         import abstract_vector_cdp, dp
+         class(abstract_vector_cdp), intent(inout) :: self
+         complex(dp), intent(in) :: alpha
+         class(abstract_vector_cdp), intent(in) :: vec
+         complex(dp), intent(in) :: beta
+      end subroutine
+      function abstract_zdot(self, vec) result(alpha)
+         import abstract_vector_cdp, dp
+         class(abstract_vector_cdp), intent(in) :: self, vec
+         complex(dp) :: alpha
+      end function
+      pure function abstract_zsize(self) result(n)
+         import abstract_vector_cdp
+         class(abstract_vector_cdp), intent(in) :: self
+         integer :: n
+      end function
+   end interface
+
+   type, abstract, public :: abstract_linop_cdp
+   contains
+      procedure(abstract_zmatvec), pass(self), deferred, public :: matvec
+      procedure(abstract_zmatvec), pass(self), deferred, public :: rmatvec
+   end type
+
+   abstract interface
+      subroutine abstract_zmatvec(self, vec_in, vec_out)
+         import abstract_linop_cdp, abstract_vector_cdp
+         class(abstract_linop_cdp), intent(inout) :: self
+         class(abstract_vector_cdp), intent(in) :: vec_in
+         class(abstract_vector_cdp), intent(out) :: vec_out
+      end subroutine
+   end interface
+
    !> Jacobian of a nonlinear system about the state X (neklab_systems.f90:47-55: `self%X`)
    type, abstract, extends(abstract_linop_rdp), public :: abstract_jacobian_linop_rdp
       class(abstract_vector_rdp), allocatable :: X
@@ -171,6 +232,12 @@ module LightKrylov
    end interface
 
 contains
+
+   function zvec_norm(self) result(alpha)
+      class(abstract_vector_cdp), intent(in) :: self
+      real(dp) :: alpha
+      alpha = sqrt(real(self%dot(self), dp))
+   end function
 
    function vec_norm(self) result(alpha)
       class(abstract_vector_rdp), intent(in) :: self
@@ -518,13 +585,13 @@ contains
 end module LightKrylov
 
 module LightKrylov_AbstractVectors
-   use LightKrylov, only: abstract_vector_rdp
+   use LightKrylov, only: abstract_vector_rdp, abstract_vector_cdp
    implicit none
    public
 end module
 
 module LightKrylov_AbstractLinops
-   use LightKrylov, only: abstract_linop_rdp, abstract_exptA_linop_rdp
+   use LightKrylov, only: abstract_linop_rdp, abstract_exptA_linop_rdp, abstract_linop_cdp
    implicit none
    public
 end module

@@ -124,7 +124,7 @@ def test_fortran_shim_compiles_against_the_abstract_types():
     build.build_library()
     r = subprocess.run(["make", "-s", "-C", tdir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    for exe in ("arnoldi_driver", "stability_driver", "tsyphon_driver"):
+    for exe in ("arnoldi_driver", "stability_driver", "tsyphon_driver", "resolvent_driver"):
         assert os.path.exists(os.path.join(tdir, "_build", exe))
     # nothing of the scaffolding lives in the product directory
     assert not os.path.exists(os.path.join(fdir, "lightkrylov_stub.f90")) and not glob.glob(os.path.join(fdir, "*driver*.f90"))
