@@ -16,6 +16,10 @@ Launches issued after a PCG has converged return at once (device-side done flag)
 of its class maximum is counted as "gated" and left out of the statistics.
 Corrections (MI355X_MICROARCH.md, section HBM): the counters are in KB; FETCH_SIZE reports half the bytes of wide
 coalesced reads on gfx950 and is doubled; WRITE_SIZE is exact:  traffic = (2 * FETCH + WRITE) * 1024 bytes.
+Calibrated in round 3 for the gather-scatter's own access shape (scripts/pmc_calibrate.hip, profiles/r03_pmc_calibration.txt):
+FETCH_SIZE * 1024 = 0.500 of the bytes for coalesced 8-byte loads as for 16-byte ones, and 0.51 of the bytes of the whole
+128-byte lines touched by k_gs's 8- and 16-byte pair accesses; WRITE_SIZE * 1024 = 1.000 of the bytes written.  The factor 2
+therefore holds for every kernel here.
 """
 import argparse
 import csv
@@ -29,7 +33,7 @@ import sys
 CLASSES = {      # bench.py kernel class -> regex on the demangled kernel name
     "gs": r"^k_gs<3>", "axhelm": r"^k_axhelm3[rc]?<", "opgradt": r"^k_opgradt3(<\d+, \d+|n<\d+), true", "opdiv": r"^k_opdiv3(<\d+, \d+|n<\d+), true",
     "block_dot": r"^k_block_dot<", "axpy_dot": r"^k_block_axpy_dot<", "block_axpy": r"^k_block_axpy$", "cg_vec": r"^k_cg_update<3>",
-    "conv": r"^k_conv3<", "fdm": r"^k_fdm_ext<",
+    "conv": r"^k_conv3<", "fdm": r"^k_fdm_ext(<|_mfma8)",
 }
 
 
@@ -93,7 +97,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch")
     ap.add_argument("write")
-    ap.add_argument("--outdir", default="profiles/r02_pmc")
+    ap.add_argument("--outdir", default="profiles/r03_pmc")
     ap.add_argument("--E", type=int, required=True)
     ap.add_argument("--lx1", type=int, required=True)
     ap.add_argument("--dim", type=int, default=3)
