@@ -2133,6 +2133,252 @@ __global__ __launch_bounds__(NTC, (DYN && N > 10) ? 1 : 2) void k_conv3(int64_t 
     }
 }
 
+// Plane-sweep form of the fused convective term for lx1 >= 9 (round 3).  k_conv3 above keeps the whole fine-mesh image of one
+// component in LDS (134 KB at lx1 = 12: ONE six-wave block per CU, every stage waiting on the one before it, eighteen
+// serialised round trips to HBM per element).  Here the z direction goes FIRST and LAST: for every fine level c
+//   S1  Z0_m = (J_z u_m)(c), Z1_m = (DJ_z u_m)(c) on the coarse (i, j) plane         thread (i, j, m) holds its column u_m(i, j, :)
+//   S2  x stage: J_x Z0, DJ_x Z0, J_x Z1 -> (a, j)                                    lanes (j, m), waves over a
+//   S3  y stage: value and three derivatives at (a, b), all three components; combination with the twelve base-flow
+//       values of the level (prefetched into registers one level ahead) -> acc_m(a, b)   lanes (a, m), waves over b
+//   S4  J_y^T acc -> (a, j)                                                           lanes (a, m), waves over j
+//   S5  J_x^T     -> (i, j)                                                           lanes (j, m), waves over i
+//   S6  out_m(i, j, :) += J[c][:] P_m(i, j)                                           thread (i, j, m), 12 accumulators
+// so that the LDS image is the planes of ONE level (40 KB at lx1 = 12), the value interpolation of phase A is a by-product
+// of S3, and the base-flow stream is requested a level ahead of its use.  In every stage the matrix entry a wave needs has a
+// wave-uniform address (scalar operand) and a lane reuses the row it read for all the outputs of its wave.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load (s_waitcnt vmcnt(0)
+// before s_barrier), which turns a prefetch issued ahead of it into a blocking load; with the fences restricted to the LDS address
+// space only the LDS counter is drained.  (An inline-asm barrier with a "memory" clobber does the same to the waits but makes the
+// compiler fetch the wave-uniform matrix rows with VECTOR loads: a clobber between two loads forbids the scalar path.)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int N, int ND, int NW, int MINB>
+__global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, const double *__restrict__ Jt, CF3 Ur, CF9 GU,
+                                                          CF3L ul, F3L outl, int nl, int adjoint) {
+    constexpr int NN = N * N, NP = NN * N, NDD = ND * ND, NPD = NDD * ND;
+    constexpr int NQ = N | 1, NDQ = ND | 1;   // odd leading dimensions where lanes walk the slow index
+    constexpr int OB = (ND + NW - 1) / NW, OJ = (N + NW - 1) / NW;
+    static_assert(3 * NN <= NW * 64 && 3 * ND <= 64, "one thread per coarse column and component; (a, m) in one wave");
+    __shared__ double sZ[2][3][NQ * N];
+    __shared__ double sX[3][3][NDQ * N];
+    __shared__ double sAc[3][NDQ * ND];
+    __shared__ double sY[3][NDQ * N];
+    __shared__ double sP[3][NN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the vectors of a block step are consecutive blocks of the same element (the base flow of the element is then served by L2 for
+    // every lane after the first); no lane loop: with the stores of one lane ahead of the loads of the next the compiler could not
+    // prove the matrix rows unclobbered and fetched them with vector loads
+    const int64_t e = blockIdx.x / nl;
+    const int lv = (int)(blockIdx.x - e * nl);
+    if (e >= E) return;
+    const bool r1 = tid < 3 * NN;                    // coarse column (i, j) of component m1
+    const int m1 = r1 ? tid / NN : 0, ij = r1 ? tid % NN : 0;
+    const int zidx = (ij % N) + NQ * (ij / N);
+    const bool r2 = lane < 3 * N;                    // (j, m)
+    const int j2 = r2 ? lane % N : 0, m2 = r2 ? lane / N : 0;
+    const bool r3 = lane < 3 * ND;                   // (a, m)
+    const int a3 = r3 ? lane % ND : 0, m3 = r3 ? lane / ND : 0;
+    const double sgn = adjoint ? -1.0 : 1.0;
+    const double *__restrict__ g0 = adjoint ? GU.p[0 * 3 + m3] : GU.p[m3 * 3 + 0];
+    const double *__restrict__ g1 = adjoint ? GU.p[1 * 3 + m3] : GU.p[m3 * 3 + 1];
+    const double *__restrict__ g2 = adjoint ? GU.p[2 * 3 + m3] : GU.p[m3 * 3 + 2];
+    const double *__restrict__ u0 = Ur.p[0], *__restrict__ u1 = Ur.p[1], *__restrict__ u2 = Ur.p[2];
+    double uc[N], oacc[N];
+    {
+        const double *__restrict__ up = ul.p[lv][m1] + e * NP + ij;   // (threads without a column read column 0: in bounds, unused)
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            uc[k] = up[NN * k];
+            oacc[k] = 0.0;
+        }
+    }
+    double bf[OB][6];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) {
+        const int b = wave + NW * o;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bf[o][q] = 0.0;
+        if (r3 && b < ND) {
+            const int64_t q = e * NPD + a3 + ND * b;
+            bf[o][0] = u0[q], bf[o][1] = u1[q], bf[o][2] = u2[q], bf[o][3] = g0[q], bf[o][4] = g1[q], bf[o][5] = g2[q];
+        }
+    }
+    // the column must have arrived BEFORE the loop: a use inside it makes the compiler drain the load counter at the top of every
+    // level, and with it the base-flow prefetch of the level before
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" ::"v"(uc[k]));
+
+    auto S1 = [&](int c) {   // z stage of level c
+        if (r1) {
+            const double *__restrict__ r0 = Jg + c * N, *__restrict__ rd = DJg + c * N;
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                z0 += r0[k] * uc[k];
+                z1 += rd[k] * uc[k];
+            }
+            sZ[0][m1][zidx] = z0;
+            sZ[1][m1][zidx] = z1;
+        }
+    };
+    auto S2 = [&]() {        // x stage
+        if (r2) {
+            double z0[N], z1[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                z0[i] = sZ[0][m2][i + NQ * j2];
+                z1[i] = sZ[1][m2][i + NQ * j2];
+            }
+#pragma unroll
+            for (int o = 0; o < OB; ++o) {
+                const int a = wave + NW * o;
+                if (a < ND) {
+                    const double *__restrict__ r0 = Jg + a * N, *__restrict__ rd = DJg + a * N;
+                    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        x0 += r0[i] * z0[i];
+                        x1 += rd[i] * z0[i];
+                        x2 += r0[i] * z1[i];
+                    }
+                    sX[0][m2][a + NDQ * j2] = x0;
+                    sX[1][m2][a + NDQ * j2] = x1;
+                    sX[2][m2][a + NDQ * j2] = x2;
+                }
+            }
+        }
+    };
+    auto S3 = [&](int c) {   // y stage, combination with the base flow of level c, request of level c + 1
+        double val[OB], us[OB], ur[OB], ut[OB];
+#pragma unroll
+        for (int o = 0; o < OB; ++o) val[o] = us[o] = ur[o] = ut[o] = 0.0;
+        if (r3) {   // the three rows stay in registers: ONE fetch of the matrix rows J[b], DJ[b] per output b (scalar-cache round trip)
+            double x0[N], x1[N], x2[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                x0[j] = sX[0][m3][a3 + NDQ * j];
+                x1[j] = sX[1][m3][a3 + NDQ * j];
+                x2[j] = sX[2][m3][a3 + NDQ * j];
+            }
+#pragma unroll
+            for (int o = 0; o < OB; ++o) {
+                const int b = wave + NW * o;
+                if (b < ND) {
+                    const double *__restrict__ r0 = Jg + b * N, *__restrict__ rd = DJg + b * N;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        val[o] += r0[j] * x0[j];
+                        us[o] += rd[j] * x0[j];
+                        ur[o] += r0[j] * x1[j];
+                        ut[o] += r0[j] * x2[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const int b = wave + NW * o;
+            if (b < ND) {   // wave-uniform: every lane takes part in the exchanges
+                const double v0 = __shfl(val[o], a3, 64), v1 = __shfl(val[o], a3 + ND, 64), v2 = __shfl(val[o], a3 + 2 * ND, 64);
+                if (r3)
+                    sAc[m3][a3 + NDQ * b] = sgn * (bf[o][0] * ur[o] + bf[o][1] * us[o] + bf[o][2] * ut[o]) +
+                                            (v0 * bf[o][3] + v1 * bf[o][4] + v2 * bf[o][5]);
+            }
+        }
+        // the base-flow values of the next level, requested only after every value of this one has been used (loads issued
+        // between the uses make the compiler wait for ALL outstanding loads at the next use: vmcnt counts in order)
+        if (r3 && c + 1 < ND) {
+#pragma unroll
+            for (int o = 0; o < OB; ++o) {
+                const int b = wave + NW * o;
+                if (b < ND) {
+                    const int64_t q = e * NPD + (int64_t)(c + 1) * NDD + a3 + ND * b;
+                    bf[o][0] = u0[q], bf[o][1] = u1[q], bf[o][2] = u2[q], bf[o][3] = g0[q], bf[o][4] = g1[q], bf[o][5] = g2[q];
+                }
+            }
+        }
+    };
+    auto S4 = [&]() {        // J_y^T
+        if (r3) {
+            double col[ND];
+#pragma unroll
+            for (int b = 0; b < ND; ++b) col[b] = sAc[m3][a3 + NDQ * b];
+#pragma unroll
+            for (int o = 0; o < OJ; ++o) {
+                const int j = wave + NW * o;
+                if (j < N) {
+                    double y = 0.0;
+#pragma unroll
+                    for (int b = 0; b < ND; ++b) y += Jt[j * ND + b] * col[b];
+                    sY[m3][a3 + NDQ * j] = y;
+                }
+            }
+        }
+    };
+    auto S5 = [&]() {        // J_x^T
+        if (r2) {
+            double row[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) row[a] = sY[m2][a + NDQ * j2];
+#pragma unroll
+            for (int o = 0; o < OJ; ++o) {
+                const int i = wave + NW * o;
+                if (i < N) {
+                    double p = 0.0;
+#pragma unroll
+                    for (int a = 0; a < ND; ++a) p += Jt[i * ND + a] * row[a];
+                    sP[m2][i + N * j2] = p;
+                }
+            }
+        }
+    };
+    auto S6 = [&](int c) {   // J_z^T of level c into the accumulators of the coarse column
+        if (r1) {
+            const double p = sP[m1][ij];
+            const double *__restrict__ r0 = Jg + c * N;
+#pragma unroll
+            for (int k = 0; k < N; ++k) oacc[k] += r0[k] * p;
+        }
+    };
+    // Software pipeline over the levels, three barrier intervals per level: the forward stages of level c share their intervals with
+    // the backward stages of level c - 1 (independent instruction streams inside a wave, three barriers instead of five):
+    //   [S1(c) S4(c-1)] | [S2(c) S5(c-1)] | [S3(c) S6(c-1)] |
+    S1(0);
+    lds_barrier();
+    S2();
+    lds_barrier();
+    S3(0);
+    lds_barrier();
+#pragma unroll 1
+    for (int cv = 1; cv < ND; ++cv) {
+        const int c = __builtin_amdgcn_readfirstlane(cv);   // (the counter also feeds per-lane addresses: keep a scalar copy for the matrix rows)
+        S1(c);
+        S4();
+        lds_barrier();
+        S2();
+        S5();
+        lds_barrier();
+        S3(c);
+        S6(c - 1);
+        lds_barrier();
+    }
+    S4();
+    lds_barrier();
+    S5();
+    lds_barrier();
+    S6(ND - 1);
+    if (r1) {
+        double *__restrict__ op = outl.p[lv][m1] + e * NP + ij;
+#pragma unroll
+        for (int k = 0; k < N; ++k) op[NN * k] = oacc[k];
+    }
+}
+
 // =================================================================================================
 // Dealiasing interpolation on the matrix cores: one velocity-mesh field -> its value and its three reference-space
 // derivatives on the fine (Gauss) mesh,
@@ -3143,18 +3389,29 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
         NLG_LAUNCH((k_conv3<N_, ND_, NTC_, ULDS_, true>), dim3((unsigned)m->E), dim3(NTC_), lds, m->ctx->stream, m->E, \
                            (const double *)m->d_Jd, (const double *)m->d_DJd, cur, cg, cu, co, nl, adjoint);          \
     }
+#define CV3S(N_, NW_, MINB_)                                                                                                    \
+    NLG_LAUNCH((k_conv3s<N_, (3 * N_) / 2, NW_, MINB_>), dim3((unsigned)(m->E * nl)), dim3(NW_ * 64), 0, m->ctx->stream, m->E, (const double *)m->d_Jd, \
+               (const double *)m->d_DJd, (const double *)m->d_Jdt, cur, cg, cu, co, nl, adjoint);
+        static const int sweep = getenv("NLG_CONV_SWEEP") ? atoi(getenv("NLG_CONV_SWEEP")) : 1;   // A/B: 0 = the LDS-image kernel k_conv3
         switch (m->n) {
             case 4: CV3(4); break;
             case 5: CV3(5); break;
             case 6: CV3(6); break;
             case 7: CV3(7); break;
-            case 8: CV3(8); break;
+            case 8:
+                if (sweep == 3) CV3S(8, 3, 3) else CV3(8);   // (measured: see DESIGN.md section 5)
+                break;
             case 9: CV3D(9, 256, true); break;
-            case 10: CV3D(10, 256, false); break;   // u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU
-            default: CV3D(12, 384, false); break;
+            case 10:
+                if (sweep == 2) CV3S(10, 5, 4) else if (sweep) CV3S(10, 5, 2) else CV3D(10, 256, false);   // (u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU)
+                break;
+            default:
+                if (sweep == 2) CV3S(12, 7, 4) else if (sweep) CV3S(12, 7, 1) else CV3D(12, 384, false);
+                break;
         }
 #undef CV3
 #undef CV3D
+#undef CV3S
         NLG_HIP(hipGetLastError());
         return 0;
     }
