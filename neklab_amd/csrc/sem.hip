@@ -2197,17 +2197,26 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const doubl
             oacc[k] = 0.0;
         }
     }
-    double bf[OB][6];
+    // base-flow values of TWO levels in flight (one level = 31 KB per CU at lx1 = 12 covers a third of the memory latency: measured, the
+    // wait in S3 was 70 % of the kernel): lane (a, m) holds Ur_m and the three gradient entries of its row; the other two Ur come by
+    // lane exchange at the use
+    double bf[2][OB][4];
+    const double *__restrict__ um = m3 == 0 ? u0 : (m3 == 1 ? u1 : u2);
+    // (branch-free: every lane of every wave issues all its loads, out-of-range rows, levels and idle lanes clamped to valid addresses --
+    //  with the loads under wave-uniform branches the compiler's counter bookkeeping merges the paths conservatively and drains BOTH
+    //  levels at the first use)
+    auto request = [&](auto slot, int c) {
+        constexpr int S = decltype(slot)::value;
+        const int64_t qc = e * NPD + (int64_t)(c < ND ? c : ND - 1) * NDD + a3;
 #pragma unroll
-    for (int o = 0; o < OB; ++o) {
-        const int b = wave + NW * o;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) bf[o][q] = 0.0;
-        if (r3 && b < ND) {
-            const int64_t q = e * NPD + a3 + ND * b;
-            bf[o][0] = u0[q], bf[o][1] = u1[q], bf[o][2] = u2[q], bf[o][3] = g0[q], bf[o][4] = g1[q], bf[o][5] = g2[q];
+        for (int o = 0; o < OB; ++o) {
+            const int b = wave + NW * o < ND ? wave + NW * o : ND - 1;
+            const int64_t q = qc + ND * b;
+            bf[S][o][0] = um[q], bf[S][o][1] = g0[q], bf[S][o][2] = g1[q], bf[S][o][3] = g2[q];
         }
-    }
+    };
+    request(std::integral_constant<int, 0>{}, 0);
+    request(std::integral_constant<int, 1>{}, 1);
     // the column must have arrived BEFORE the loop: a use inside it makes the compiler drain the load counter at the top of every
     // level, and with it the base-flow prefetch of the level before
 #pragma unroll
@@ -2253,7 +2262,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const doubl
             }
         }
     };
-    auto S3 = [&](int c) {   // y stage, combination with the base flow of level c, request of level c + 1
+    auto S3 = [&](auto slot, int c) {   // y stage, combination with the base flow of level c (slot c & 1), request of level c + 2
+        constexpr int S = decltype(slot)::value;
         double val[OB], us[OB], ur[OB], ut[OB];
 #pragma unroll
         for (int o = 0; o < OB; ++o) val[o] = us[o] = ur[o] = ut[o] = 0.0;
@@ -2285,23 +2295,14 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const doubl
             const int b = wave + NW * o;
             if (b < ND) {   // wave-uniform: every lane takes part in the exchanges
                 const double v0 = __shfl(val[o], a3, 64), v1 = __shfl(val[o], a3 + ND, 64), v2 = __shfl(val[o], a3 + 2 * ND, 64);
+                const double w0 = __shfl(bf[S][o][0], a3, 64), w1 = __shfl(bf[S][o][0], a3 + ND, 64), w2 = __shfl(bf[S][o][0], a3 + 2 * ND, 64);
                 if (r3)
-                    sAc[m3][a3 + NDQ * b] = sgn * (bf[o][0] * ur[o] + bf[o][1] * us[o] + bf[o][2] * ut[o]) +
-                                            (v0 * bf[o][3] + v1 * bf[o][4] + v2 * bf[o][5]);
+                    sAc[m3][a3 + NDQ * b] = sgn * (w0 * ur[o] + w1 * us[o] + w2 * ut[o]) + (v0 * bf[S][o][1] + v1 * bf[S][o][2] + v2 * bf[S][o][3]);
             }
         }
-        // the base-flow values of the next level, requested only after every value of this one has been used (loads issued
-        // between the uses make the compiler wait for ALL outstanding loads at the next use: vmcnt counts in order)
-        if (r3 && c + 1 < ND) {
-#pragma unroll
-            for (int o = 0; o < OB; ++o) {
-                const int b = wave + NW * o;
-                if (b < ND) {
-                    const int64_t q = e * NPD + (int64_t)(c + 1) * NDD + a3 + ND * b;
-                    bf[o][0] = u0[q], bf[o][1] = u1[q], bf[o][2] = u2[q], bf[o][3] = g0[q], bf[o][4] = g1[q], bf[o][5] = g2[q];
-                }
-            }
-        }
+        // requested only after every value of this level has been used (loads issued between the uses make the compiler wait for ALL
+        // outstanding loads at the next use: vmcnt counts in order)
+        request(slot, c + 2);
     };
     auto S4 = [&]() {        // J_y^T
         if (r3) {
@@ -2352,21 +2353,26 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const doubl
     lds_barrier();
     S2();
     lds_barrier();
-    S3(0);
+    S3(std::integral_constant<int, 0>{}, 0);
     lds_barrier();
-#pragma unroll 1
-    for (int cv = 1; cv < ND; ++cv) {
-        const int c = __builtin_amdgcn_readfirstlane(cv);   // (the counter also feeds per-lane addresses: keep a scalar copy for the matrix rows)
+    auto level = [&](auto slot, int c) {
         S1(c);
         S4();
         lds_barrier();
         S2();
         S5();
         lds_barrier();
-        S3(c);
+        S3(slot, c);
         S6(c - 1);
         lds_barrier();
+    };
+#pragma unroll 1
+    for (int cv = 1; cv + 1 < ND; cv += 2) {
+        const int c = __builtin_amdgcn_readfirstlane(cv);   // (the counter also feeds per-lane addresses: keep a scalar copy for the matrix rows)
+        level(std::integral_constant<int, 1>{}, c);
+        level(std::integral_constant<int, 0>{}, c + 1);
     }
+    if (ND % 2 == 0) level(std::integral_constant<int, 1>{}, ND - 1);
     S4();
     lds_barrier();
     S5();

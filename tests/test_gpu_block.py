@@ -218,7 +218,7 @@ def test_eigs_block_mode_and_warm_start(gpu_ctx):
         assert w.norm() < 1e-6 * Xb[0].norm()
 
 
-@pytest.mark.parametrize("dim,n,s", [(2, 6, 2), (3, 8, 3), (3, 5, 4)])
+@pytest.mark.parametrize("dim,n,s", [(2, 6, 2), (3, 8, 3), (3, 5, 4), (3, 10, 2)])   # (lx1 = 10: lanes as consecutive blocks of k_conv3s)
 @pytest.mark.parametrize("adjoint", [False, True])
 def test_matvec_block_equals_single_matvecs(gpu_ctx, dim, n, s, adjoint):
     """nlg_linop_matvec_block: s vectors advanced together in lockstep PCGs give what s single matvecs give -- with
