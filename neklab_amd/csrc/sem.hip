@@ -877,6 +877,16 @@ __global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const doub
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load (s_waitcnt vmcnt(0)
+// before s_barrier), which turns a prefetch issued ahead of it into a blocking load; with the fences restricted to the LDS address
+// space only the LDS counter is drained.  (An inline-asm barrier with a "memory" clobber does the same to the waits but makes the
+// compiler fetch the wave-uniform matrix rows with VECTOR loads: a clobber between two loads forbids the scalar path.)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Register-column variant for N > 8: one block of ceil(N N / 64) waves per (element, field); thread (i, j) keeps its
 // k-column of u and of w in registers as in k_axhelm3r, the three N x N slabs are shared by the block's waves, so the two
 // hand-overs per slab are block barriers (two or three waves: cheap) instead of the wave-level LDS ordering.  Row k of D
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
     if (done_p && done_p[0] != 0.0) return;
     const int tid = threadIdx.x;
     for (int p = tid; p < NS; p += NTB) sD[p] = Dg[p];
-    __syncthreads();
+    lds_barrier();
     const int64_t e = (int64_t)blockIdx.x / nf;
     const int c = (int)((int64_t)blockIdx.x % nf);
     const bool act = tid < NS;
@@ -957,13 +967,13 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
             gn[0] = G0[q], gn[1] = G1[q], gn[2] = G2[q], gn[3] = G3[q], gn[4] = G4[q], gn[5] = G5[q], gn[6] = bm1[q];
         }
         if (act) mU[i + NQ * j] = uk[k];
-        __syncthreads();
+        lds_barrier();
         double ur = 0.0, us = 0.0, ut = 0.0;
 #pragma unroll
         for (int l = 0; l < N; ++l) {
             ur += di[l] * mU[l + NQ * j];
             us += dj[l] * mU[i + NQ * l];
-            ut += sD[k * N + l] * uk[l];
+            ut += Dg[k * N + l] * uk[l];   // row k of D: compile-time index on a restrict argument = scalar operand (a third of the LDS reads of a slab)
         }
         const double gr = h1 * (g0 * ur + g1 * us + g2 * ut);
         const double gs = h1 * (g1 * ur + g3 * us + g4 * ut);
@@ -972,9 +982,9 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
             mR[i + NQ * j] = gr;
             mS[i + NQ * j] = gs;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
-        for (int l = 0; l < N; ++l) wk[l] += sD[k * N + l] * gt;
+        for (int l = 0; l < N; ++l) wk[l] += Dg[k * N + l] * gt;
         double a = h2 * bm * uk[k];
 #pragma unroll
         for (int l = 0; l < N; ++l) a += dti[l] * mR[l + NQ * j] + dtj[l] * mS[i + NQ * l];
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
         if ((tid & 63) == 0) sred[tid >> 6] = pw;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             double a = 0.0;
             for (int q = 0; q < NWB; ++q) a += sred[q];
@@ -1491,7 +1501,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                 for (int k2 = 0; k2 < N2; ++k2) gq[PF ? j : 0][PF ? k2 : 0] = g.p[j * 3 + 0][e * NP2 + tid + NS2 * k2];
         }
         for (int i = 0; i < 3; ++i) {
-            if (i > 0 || lv > 0) __syncthreads();   // the x stage of the previous pass has read its columns
+            if (i > 0 || lv > 0) lds_barrier();   // the x stage of the previous pass has read its columns
             // z stage: thread = (i2, j2) column, all three arrays
             if (tid < NS2) {
                 const int i2 = tid % N2, j2 = tid / N2;
@@ -1516,7 +1526,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                         for (int k2 = 0; k2 < N2; ++k2) gq[PF ? j : 0][PF ? k2 : 0] = g.p[j * 3 + i + 1][e * NP2 + tid + NS2 * k2];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // y stage in place: B0 = I^T_y A0 ; B1 = D^T_y A1 + I^T_y A2
             if (tid < N2 * N) {
                 double *r = sR + tid * RS;
@@ -1539,7 +1549,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                     r[N + j] = b1;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // x stage: w = D^T_x B0 + I^T_x B1, straight to HBM
             if (tid < N * N) {
                 const int jj = tid % N, kk = tid / N;
@@ -1581,7 +1591,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
         for (int k2 = 0; k2 < N2; ++k2) acc[k2] = 0.0;
         constexpr bool PF = N <= 8;   // lx1 <= 8: the metric columns of a pass are requested at its start, two LDS stages before their use
         for (int i = 0; i < 3; ++i) {
-            if (i > 0 || lv > 0) __syncthreads();   // the z stage of the previous pass has read its columns
+            if (i > 0 || lv > 0) lds_barrier();   // the z stage of the previous pass has read its columns
             double gq[PF ? 3 : 1][PF ? N2 : 1];
             if (PF && tid < NS2) {
 #pragma unroll
@@ -1617,7 +1627,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
                     sR[(i2 + N2 * kk) * RS + N + jj] = b1;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // y stage in place: C0 = I_y B0 ; C1 = D_y B1 ; C2 = I_y B1
             if (tid < N2 * N) {
                 double *r = sR + tid * RS;
@@ -1641,7 +1651,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
                     r[2 * N2 + j2] = c2v;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // z stage: thread = (i2, j2) column; the metric products of the three arrays are summed in registers
             if (tid < NS2) {
                 const int i2 = tid % N2, j2 = tid / N2;
@@ -1689,7 +1699,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
                 red[tid >> 6] = spw;
                 red[NTB / 64 + (tid >> 6)] = sw;
             }
-            __syncthreads();
+            lds_barrier();
             if (tid == 0) {
                 double a = 0.0, b = 0.0;
                 for (int q = 0; q < NTB / 64; ++q) {
@@ -2146,16 +2156,6 @@ __global__ __launch_bounds__(NTC, (DYN && N > 10) ? 1 : 2) void k_conv3(int64_t 
 // so that the LDS image is the planes of ONE level (40 KB at lx1 = 12), the value interpolation of phase A is a by-product
 // of S3, and the base-flow stream is requested a level ahead of its use.  In every stage the matrix entry a wave needs has a
 // wave-uniform address (scalar operand) and a lane reuses the row it read for all the outputs of its wave.
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load (s_waitcnt vmcnt(0)
-// before s_barrier), which turns a prefetch issued ahead of it into a blocking load; with the fences restricted to the LDS address
-// space only the LDS counter is drained.  (An inline-asm barrier with a "memory" clobber does the same to the waits but makes the
-// compiler fetch the wave-uniform matrix rows with VECTOR loads: a clobber between two loads forbids the scalar path.)
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 template <int N, int ND, int NW, int MINB>
 __global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, const double *__restrict__ Jt, CF3 Ur, CF9 GU,
                                                           CF3L ul, F3L outl, int nl, int adjoint) {
