@@ -1490,9 +1490,9 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opgradt3n(int64_t E, const 
                 }
             }
         }
-        // lx1 <= 8 (one wave per element, registers to spare): the metric columns of the NEXT component are requested before
-        // the y and x stages of the current one, so that their latency is hidden behind two LDS stages
-        constexpr bool PF = N <= 8;
+        // lx1 <= 10: the metric columns of the NEXT component are requested before the y and x stages of the current one, so that
+        // their latency is hidden behind two LDS stages
+        constexpr bool PF = N <= 10;   // (measured with LDS-only barriers: lx1 = 10 190 -> 175 us, lx1 = 12 347 -> 414 us)
         double gq[PF ? 3 : 1][PF ? N2 : 1];
         if (PF && tid < NS2) {
 #pragma unroll
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
         double acc[N2];
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) acc[k2] = 0.0;
-        constexpr bool PF = N <= 8;   // lx1 <= 8: the metric columns of a pass are requested at its start, two LDS stages before their use
+        constexpr bool PF = N <= 8;   // lx1 <= 8: the metric columns of a pass are requested at its start, two LDS stages before their use (no gain at lx1 = 10, a loss at 12)
         for (int i = 0; i < 3; ++i) {
             if (i > 0 || lv > 0) lds_barrier();   // the z stage of the previous pass has read its columns
             double gq[PF ? 3 : 1][PF ? N2 : 1];
