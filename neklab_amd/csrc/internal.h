@@ -412,6 +412,7 @@ int sem_opdiv_blocks(const nlg_mesh *m);
 int sem_axhelm_blocks(nlg_mesh *m, int nf);   // 3-D: number of per-block sums of u . w_local written to pw_part
 int sem_helm_diag(nlg_mesh *m, double *out, double h1, double h2);   // local diag (not assembled)
 struct nlg_pupd;
+bool sem_opgradt_has_fg(const nlg_mesh *m);
 int sem_opgradt(nlg_mesh *m, const double *p, double *const *w, bool face_grouped = false, const double *gate = nullptr, const nlg_pupd *upd = nullptr);
 int sem_opdiv(nlg_mesh *m, double *const *u, double *out, double scale, double *const *wts = nullptr, bool face_grouped = false,
               const double *pdot = nullptr, double *pw_part = nullptr, const double *gate = nullptr);

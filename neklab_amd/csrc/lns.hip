@@ -605,15 +605,24 @@ struct Hist {
     int k;
 };
 // `gp` / `w` non-null: the residual form of the tentative-velocity problem in the same pass, rhs_i += gp_i - w_i (D^T p - H u)
-template <int NF>
+// XP: the result is written masked and in the slab-permuted layout of the velocity solve (slot = element-local table), so that its
+// gather-scatter runs on that layout's lists and the solve needs no permutation pass (the Dirichlet mask is the same for every copy
+// of a dof, so masking before the gather-scatter gives the bits masking after it gave)
+template <int NF, bool XP = false>
 __global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1, double rdt, F3 rhs, int64_t ld, CF3 gp = CF3{{nullptr, nullptr, nullptr}},
-                                            CF3 w = CF3{{nullptr, nullptr, nullptr}}) {
+                                            CF3 w = CF3{{nullptr, nullptr, nullptr}}, const int *__restrict__ slot = nullptr, int np = 1,
+                                            CF3 mask = CF3{{nullptr, nullptr, nullptr}}) {
     // (the lane offset is added at the loads: writing it into `h` would move the by-value struct from the kernel-argument segment,
     //  where the runtime index j costs a scalar load, into scratch memory -- measured 123 -> 315 us)
     const int64_t lo = lane_lo(ld);
     rhs = lane_f3(rhs, lo);
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double b = bm1[i] * rdt;
+        int64_t q = i;
+        if (XP) {
+            const int64_t e = i / np;
+            q = e * np + slot[(int)(i - e * np)];
+        }
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             double a = 0.0, u = 0.0;
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(NT) void k_rhs(int64_t n, Hist h, const double *bm1
             }
             double v = a + b * u;
             if (gp.p[c]) v = (v + gp.p[c][lo + i]) - w.p[c][lo + i];
-            rhs.p[c][i] = v;
+            rhs.p[c][q] = XP ? mask.p[c][i] * v : v;
         }
     }
 }
@@ -659,13 +668,19 @@ __global__ __launch_bounds__(NT) void k_add_xp(int64_t n, int np, const int *__r
 }
 
 // y_c += s * wt_c * x_c  (velocity correction: the inverse mass / mask weights of opbinv ride in the update)
-template <int NF>
-__global__ __launch_bounds__(NT) void k_axpy_w(int64_t n, F3 y, CF3 x, CF3 wt, double s, int64_t ld) {
+template <int NF, bool SLOT = false>
+__global__ __launch_bounds__(NT) void k_axpy_w(int64_t n, F3 y, CF3 x, CF3 wt, double s, int64_t ld, const int *__restrict__ slot = nullptr, int np = 1) {
+    // SLOT: x is stored in an element-local permutation (the face-grouped layout of the pressure operator's intermediates)
     const int64_t lo = lane_lo(ld);
     y = lane_f3(y, lo), x = lane_f3(x, lo);
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        int64_t q = i;
+        if (SLOT) {
+            const int64_t e = i / np;
+            q = e * np + slot[(int)(i - e * np)];
+        }
 #pragma unroll
-        for (int c = 0; c < NF; ++c) y.p[c][i] += s * (wt.p[c][i] * x.p[c][i]);
+        for (int c = 0; c < NF; ++c) y.p[c][i] += s * (wt.p[c][i] * x.p[c][q]);
     }
 }
 
@@ -723,6 +738,7 @@ struct nlg_linop {
     double *p = nullptr;
     // work
     double *rhs[3] = {}, *x[3] = {}, *z[3] = {}, *pv[3] = {}, *w[3] = {}, *gp[3] = {};
+    bool rhs_in_xp = false;   // adv_a -> helm_problem: the right-hand side already is masked and in the slab-permuted layout
     double *pr_r = nullptr, *pr_x = nullptr, *pr_z = nullptr, *pr_p = nullptr, *pr_w = nullptr;
     double *pr_b = nullptr;    // the right-hand side the pressure PCG started from (after the projection): A x = b - r afterwards
     double *pcv[4][3] = {};    // mask_i / diag(H) per BDF order
@@ -1046,11 +1062,13 @@ int helm_problem(const Lanes &L, int order, double h2, HelmSolve &H) {
     const bool xp = op->use_xp > 0;
     H.xp = xp;
     H.h2 = h2;
-    if (xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim, L.nl, L.ld(), m->d_mask));   // ... and masked on the way (adv_a leaves the mask to this pass)
+    const bool born_xp = xp && op->rhs_in_xp;   // adv_a wrote the right-hand side masked and slab-permuted already
+    op->rhs_in_xp = false;
+    if (xp && !born_xp) NLG_TRY(sem_to_xp(m, op->rhs, op->gp, dim, L.nl, L.ld(), m->d_mask));   // ... and masked on the way
     P.nf = dim;
     P.n = m->lvn;
     P.x = op->x;
-    P.r = xp ? op->gp : op->rhs;
+    P.r = (xp && !born_xp) ? op->gp : op->rhs;
     P.z = op->z;
     P.p = op->pv;
     P.w = op->w;
@@ -1483,8 +1501,18 @@ int adv_a(const Lanes &L) {
         NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, false, nullptr));
     }
     NLG_TRY(sem_axhelm(m, op->ubuf[0], op->w, dim, nu, h2, nullptr, nullptr, nullptr, nullptr, false, nl, ld));
+    if (op->use_xp > 0) {
+        // slab-permuted velocity solve: the right-hand side is born masked in that layout (no permutation pass in helm_problem, and
+        // its gather-scatter moves the layout's 64-byte runs instead of the natural layout's single points)
+        CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
+        launch_nf(dim, k_rhs<1, true>, k_rhs<2, true>, k_rhs<3, true>, lgrid(grid_for(m->lvn), nl), st, m->lvn, h, (const double *)m->d_bm1, 1.0 / dt,
+                  f3(op->rhs, dim), ld, cf3(op->gp, dim), cf3(op->w, dim), (const int *)m->d_slot_xp, m->np1, mk);
+        NLG_TRY(sem_gs(m, op->rhs, dim, nullptr, LAYOUT_XP, nl, ld, 0));
+        op->rhs_in_xp = true;
+        return 0;
+    }
     launch_nf(dim, k_rhs<1>, k_rhs<2>, k_rhs<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, h, (const double *)m->d_bm1, 1.0 / dt,
-              f3(op->rhs, dim), ld, cf3(op->gp, dim), cf3(op->w, dim));
+              f3(op->rhs, dim), ld, cf3(op->gp, dim), cf3(op->w, dim), (const int *)nullptr, 1, CF3{{nullptr, nullptr, nullptr}});
     NLG_TRY(sem_gs(m, op->rhs, dim, nullptr, LAYOUT_NAT, nl, ld, 0));
     if (op->use_xp <= 0) {   // (slab-permuted velocity solve: the mask is applied by the permutation of the right-hand side, helm_problem)
         CF3 mk = {{m->d_mask[0], m->d_mask[1], m->d_mask[2]}};
@@ -1533,19 +1561,28 @@ int adv_c(const Lanes &L) {
     const double dt = op->dt, b0 = op->adv_b0;
     double **unew = op->ubuf[2];
     NLG_LAUNCH(k_axpy1, lgrid(grid_for(m->lpn), nl), dim3(NT), 0, st, m->lpn, op->p, (const double *)op->pr_x, 1.0, ld);
+    // the gradient of the pressure increment in the face-grouped layout of the pressure operator's intermediates where that exists
+    // (3-D): its gather-scatter then moves whole faces (50 us against 100 us in the natural layout at 10^4 elements), and the update
+    // below reads it through the element-local slot table
+    const bool fg = sem_opgradt_has_fg(m);
     if (nl == 1) {
-        NLG_TRY(sem_opgradt(m, op->pr_x, op->gp));
+        NLG_TRY(sem_opgradt(m, op->pr_x, op->gp, fg));
     } else {
         const double *pp[kMaxLanes];
         double *const *gl[kMaxLanes];
         for (int v = 0; v < nl; ++v) pp[v] = L.ops[v]->pr_x, gl[v] = L.ops[v]->gp;
-        NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, false, nullptr));
+        NLG_TRY(sem_opgradt_lanes(m, nl, pp, gl, fg, nullptr));
     }
     // u = uh + (dt / b0) mask binv QQ^T D^T dp: gather-scatter, then weights and update in one pass
-    NLG_TRY(sem_gs(m, op->gp, dim, nullptr, LAYOUT_NAT, nl, ld, 0));
+    NLG_TRY(sem_gs(m, op->gp, dim, nullptr, fg ? LAYOUT_FG : LAYOUT_NAT, nl, ld, 0));
     {
         CF3 wt = {{m->d_mbinv[0], m->d_mbinv[1], m->d_mbinv[2]}};
-        launch_nf(dim, k_axpy_w<1>, k_axpy_w<2>, k_axpy_w<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(op->gp, dim), wt, dt / b0, ld);
+        if (fg)
+            launch_nf(dim, k_axpy_w<1, true>, k_axpy_w<2, true>, k_axpy_w<3, true>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(op->gp, dim),
+                      wt, dt / b0, ld, (const int *)m->d_slot_fg, m->np1);
+        else
+            launch_nf(dim, k_axpy_w<1>, k_axpy_w<2>, k_axpy_w<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, f3(unew, dim), cf3(op->gp, dim), wt, dt / b0,
+                      ld, (const int *)nullptr, 1);
     }
     NLG_HIP(hipGetLastError());
     // rotate velocity history: new -> current, current -> lag1, lag1 -> lag2

@@ -3141,9 +3141,13 @@ int sem_opbinv(nlg_mesh *m, double *const *w, int nl, int64_t ld) {
 
 // E applied to nl <= 4 pressure fields (block stepper): gradient, gather-scatter, divergence; the two element kernels take
 // all lanes in one launch
+// the intermediates of the pressure operator can be kept in the face-grouped element layout (tables, gather-scatter lists and, on
+// several ranks, halo index lists of that layout exist)
+bool sem_opgradt_has_fg(const nlg_mesh *m) { return m->dim == 3 && m->gs.d_indices_fg && m->d_slot_fg && (!m->halo.active || m->halo.d_send_idx_fg); }
+
 int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate,
                       const nlg_pupd *upd) {
-    const bool fg = m->dim == 3 && m->gs.d_indices_fg && (!m->halo.active || m->halo.d_send_idx_fg);
+    const bool fg = sem_opgradt_has_fg(m);
     // the intermediate velocity-mesh fields of all lanes in ONE allocation at a constant stride, so that their gather-scatter
     // (and its halo exchange) is one launch with gridDim.y = lanes
     const int64_t ldw = 3 * m->lvs;
