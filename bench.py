@@ -245,7 +245,11 @@ def main():
     # the roofline is quoted for a single kernel: classes that bundle several kernels of different sizes (cg_vec,
     # pprec, conv, vec_ops) stay in share_of_step but are not candidates
     single = [k for k in prof if algorithmic_bytes(k, 1, n, dim, m, dim, 1, 1, 1, 1) is not None]
-    dominant = max(single, key=lambda k: prof[k][1])
+    by_share = max(single, key=lambda k: prof[k][1])
+    # continuity: the gather-scatter is the kernel rounds 1 - 3 quote the roofline for (and the review asks about); it stays the quoted
+    # one while its share is within 10 % of the largest single-kernel class (round 3: k_axhelm3r 12.2 %, k_gs 11.6 %); the class with
+    # the largest share is named in `dominant_by_share`, the fraction of every single-kernel class is in `class_frac_warmup`
+    dominant = "gs" if ("gs" in single and prof["gs"][1] >= 0.9 * prof[by_share][1]) else by_share
     host.check(lib.nlg_prof_enable(ctx.h, 1 << names.index(dominant)))
     host.check(lib.nlg_prof_reset(ctx.h))
     # every 8th launch of the dominant class is timed in the timed region: a pair of events costs ~12 us of stream time around
@@ -294,6 +298,15 @@ def main():
     if abytes is not None and avg_ms > 0:
         roofline["achieved"] = abytes / (avg_ms * 1e-3) / 1e9
         roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    roofline["dominant_by_share"] = by_share
+    # algorithmic bytes / event-timed duration / peak of every single-kernel class over the warm-up steps (every launch timed there:
+    # each figure carries ~5 us of event overhead per launch, i.e. is a lower bound)
+    cf = {}
+    for kcls in single:
+        ab = algorithmic_bytes(kcls, E, n, dim, m, dim + nscal, lvs, lps, nshared, (dim + nscal) * lvs + lps, lorder)
+        if ab is not None and prof[kcls][0] > 0 and prof[kcls][1] > 0:
+            cf[kcls] = round(ab * prof[kcls][0] / (prof[kcls][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    roofline["class_frac_warmup"] = cf
     # HBM bytes per launch from the PMC counters: they cannot be sampled from inside this process, so the figure is the
     # one produced by scripts/pmc_traffic.py from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of THIS command on
     # THIS configuration (newest profiles/r*_pmc/traffic_per_launch.json whose config matches); null for any other config.
