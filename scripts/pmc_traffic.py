@@ -10,8 +10,11 @@ Writes  <outdir>/per_class.csv          one row per (kernel, call-site class): d
 
 Per-dispatch classification.  The gather-scatter kernel k_gs<3> runs in three element layouts that move different
 amounts of memory for the same algorithmic bytes; the layout of a dispatch follows from the kernel dispatched before it
-(same stream, in order):  k_axhelm3r<.., true> -> x-planes-first (velocity PCG);  k_opgradt3<.., true> -> face-grouped
-(pressure operator);  anything else -> natural (right-hand sides, set-up).
+(same stream, in order):  k_axhelm3r<.., true> or k_rhs<.., true> -> x-planes-first (velocity PCG and its right-hand side);
+k_opgradt3n<.., true> -> face-grouped (pressure operator, pressure correction);  anything else -> natural (set-up).
+--mix-from <timed-region table of scripts/prof_window.py>: the per-launch figure of k_gs is the mean over its call sites weighted with
+the calls per step of the TIMED REGION (the PMC run also contains the set-up, whose hundreds of natural-layout and face-grouped calls
+would otherwise dominate the mean).
 Launches issued after a PCG has converged return at once (device-side done flag): a dispatch whose counter is below 10 %
 of its class maximum is counted as "gated" and left out of the statistics.
 Corrections (MI355X_MICROARCH.md, section HBM): the counters are in KB; FETCH_SIZE reports half the bytes of wide
@@ -69,7 +72,7 @@ def classify(rows):
     for _, k, v in rows:
         site = ""
         if k.startswith("k_gs<"):
-            if re.match(r"k_axhelm3rb?<\d+, \d+, true", prev):
+            if re.match(r"k_axhelm3rb?<\d+, \d+, true", prev) or re.match(r"k_rhs<\d+, true", prev):
                 site = "slab-permuted (velocity PCG)"
             elif re.match(r"k_opgradt3(<\d+, \d+|n<\d+), true", prev) or re.match(r"k_fdm|k_sch|k_q1", prev):
                 site = "face-grouped (pressure operator / Schwarz exchange)"
@@ -101,6 +104,7 @@ def main():
     ap.add_argument("--E", type=int, required=True)
     ap.add_argument("--lx1", type=int, required=True)
     ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--mix-from", default=None)
     a = ap.parse_args()
     fs, ws = stats(classify(load(a.fetch, "FETCH_SIZE"))), stats(classify(load(a.write, "WRITE_SIZE")))
     os.makedirs(a.outdir, exist_ok=True)
@@ -132,6 +136,19 @@ def main():
                     "traffic_bytes": (2 * fetch + write) * 1024,
                     "by_call_site": {k[1] or "all": {"dispatches": fs[k]["dispatches"] - fs[k]["gated"],
                                                      "traffic_bytes": (2 * fs[k]["median"] + ws[k]["median"]) * 1024} for k in keys}}
+    if a.mix_from and "gs" in out:   # weights of the call sites of k_gs = calls per step in the timed region
+        mix = {}
+        for ln in open(a.mix_from):
+            mm = re.match(r"k_gs<\d> (\S+)\s+([\d.]+) calls/step", ln)
+            if mm:
+                mix[mm.group(1)] = float(mm.group(2))
+        sites = out["gs"]["by_call_site"]
+        num = sum(w * sites[k]["traffic_bytes"] for key, w in mix.items() for k in sites if k.startswith(key))
+        den = sum(w for key, w in mix.items() if any(k.startswith(key) for k in sites))
+        if den > 0:
+            out["gs"]["traffic_bytes_all_dispatches"] = out["gs"]["traffic_bytes"]
+            out["gs"]["traffic_bytes"] = num / den
+            out["gs"]["timed_region_mix_calls_per_step"] = mix
     with open(os.path.join(a.outdir, "traffic_per_launch.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: (v["kernel"], round(v["traffic_bytes"] / 1e6, 1)) for k, v in out.items() if isinstance(v, dict) and "kernel" in v}, indent=1))

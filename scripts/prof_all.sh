@@ -18,7 +18,7 @@ prof _lx12 --lx1 12 --steps 3 --warmup 2 &&
 prof _blk4 --block 4 --steps 3 --warmup 2 &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${T}_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-units --no-cpu > $O/pmc_${T}_fetch.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${T}_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-units --no-cpu > $O/pmc_${T}_write.log 2>&1 &&
-cd $R && python3 scripts/pmc_traffic.py gpurun_out/pmc_${T}_fetch gpurun_out/pmc_${T}_write --outdir gpurun_out/${T}_pmc --E 10000 --lx1 8 --dim 3 > gpurun_out/${T}_pmc.log 2>&1 &&
+cd $R && python3 scripts/pmc_traffic.py gpurun_out/pmc_${T}_fetch gpurun_out/pmc_${T}_write --outdir gpurun_out/${T}_pmc --E 10000 --lx1 8 --dim 3 --mix-from gpurun_out/${T}_timed_region_per_kernel.txt > gpurun_out/${T}_pmc.log 2>&1 &&
 rm -rf gpurun_out/pmc_${T}_fetch gpurun_out/pmc_${T}_write &&
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_driver_cmd.json 2> gpurun_out/${T}_bench_driver_cmd.err
 rc=$?
