@@ -557,11 +557,14 @@ def nek_constant_tol(tol_old: float, target: float, rnorm: float):
 
 
 def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim: int = 30, maxiter: int = 10,
-          shift: float = -1.0, basis: "KrylovBasis | None" = None, replay_history: bool = False, transpose: bool = False):
+          shift: float = -1.0, basis: "KrylovBasis | None" = None, replay_history: bool = False, transpose: bool = False,
+          history: "list | None" = None):
     """Restarted GMRES(kdim) for (A + shift I) x = b, zero initial guess, stop at |residual| <= atol.  The Krylov space of
     A + shift I is that of A, so the Arnoldi relation comes from the device Arnoldi step of A (`nlg_arnoldi_step`:
     matvec + block CGS2) with `shift` added to the diagonal of H.  Returns (residual norm, number of matvecs).
 
+    history (a list): receives the residual norm at the start and after every inner step (what LightKrylov logs as
+    "GMRES(k) init step" / "inner step").
     replay_history = False strips the restart history from every new Krylov vector, so that each matvec starts
     impulsively like the nonlinear map whose Jacobian it stands for.  The reference's jac_exptA_matvec replays the
     history (fixed_point.f90:73); measured on a lid-driven cavity (scripts/newton_cavity_oracle.py, tau = 0.4): Newton
@@ -573,6 +576,8 @@ def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim:
     r = b.copy()
     nmv = 0
     res = r.norm()
+    if history is not None:
+        history.append(res)
     for _ in range(maxiter):
         beta = res
         if beta <= atol:
@@ -605,6 +610,8 @@ def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim:
             g[k] = cs[k] * g[k]
             k += 1
             res = abs(g[k])
+            if history is not None:
+                history.append(res)
             if res <= atol:
                 break
         y = np.linalg.solve(np.triu(R[:k, :k]), g[:k])
@@ -639,6 +646,7 @@ def newton_fixed_point_iteration(sys: nek_system, bf: nek_dvector, tol: float, t
     final = sched(0.0, tol, 0.0)               # the tightest level the scheduler will ever set
     cur, rnorm = 0.0, 1.0
     residuals, nmv_total, converged = [], 0, False
+    gmres_hist = []
     for it in range(maxiter + 1):
         new = sched(cur, tol, rnorm)           # scheduler first, as LightKrylov's newton calls it at the top of an iteration
         if new != cur:
@@ -656,13 +664,15 @@ def newton_fixed_point_iteration(sys: nek_system, bf: nek_dvector, tol: float, t
             break
         sys.set_jacobian_state(bf)
         r.scal(-1.0)
-        res, nmv = gmres(sys.jac, r, dx, atol=sched(cur, tol, rnorm), kdim=kdim, basis=B, replay_history=replay_history)
+        gh = []
+        res, nmv = gmres(sys.jac, r, dx, atol=sched(cur, tol, rnorm), kdim=kdim, basis=B, replay_history=replay_history, history=gh)
+        gmres_hist.append(gh)
         nmv_total += nmv
         bf.axpby(1.0, dx, 1.0)
     if converged and outdir is not None:
         outpost_dnek(bf, "nwt", session, outdir)
     return {"converged": converged, "iterations": len(residuals) - 1, "residuals": residuals, "gmres_matvecs": nmv_total,
-            "evals": sys.n_eval}
+            "evals": sys.n_eval, "gmres_residuals": gmres_hist}
 
 
 def arnoldi_step(exptA: exptA_linop, basis: KrylovBasis, k: int, H: np.ndarray, transpose: bool = False):

@@ -1,0 +1,37 @@
+"""The reference's Newton-Krylov example on the GPU path: examples/cylinder/newton/Re40_fixed_point (1cyl.usr: load BF.fld,
+newton_fixed_point_iteration(sys, bf, tol = 1e-6); 1cyl.par: Re = 40, endTime = 1.0, bdf3), against the convergence history the
+reference publishes for that very run (residual.png next to the case: Newton residuals 9.0e-3, 1.33e-4, 1.3e-6; GMRES inner steps
+20, 18, 2 at a constant tolerance of 1e-6) -- tests/golden/reference_cyl_re40_guess.npz holds the guess and the numbers read off the plot.
+
+    python scripts/cylinder_newton_re40.py > profiles/r03_cylinder_newton_re40.txt
+"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from neklab_amd import host
+from refdata import load_cylinder, load_cylinder_re40_guess
+
+hm, _, _, _, _, lxd, _ = load_cylinder(with_bcs=True)
+g = load_cylinder_re40_guess()
+ctx = host.Context(); gm = host.Mesh(ctx, hm, lxd=lxd)
+X = host.nek_dvector(gm); X.set_field(host.VX, g["ux"]); X.set_field(host.VY, g["uy"]); X.set_field(host.PR, np.zeros(gm.lpn))
+tau, tol = float(g["tau"]), float(g["newton_tol"])
+sysm = host.nek_system(tau, X, re=float(g["re"]), maxit_v=400, maxit_p=4000)
+print("mesh: E = %d, lx1 = %d, lxd = %d; Re = %g, tau = %g, Newton tolerance %.0e (constant solver-tolerance scheduler)" % (hm.x.shape[0], hm.n, lxd, float(g["re"]), tau, tol))
+t0 = time.time()
+replay = len(sys.argv) > 1 and sys.argv[1] == "replay"   # jac_exptA_matvec replays the restart history of its argument (fixed_point.f90:73)
+print("GMRES: Krylov vectors %s their restart history" % ("replay" if replay else "are stripped of"))
+out = host.newton_fixed_point_iteration(sysm, X, tol, tol_mode=1, kdim=30, log=lambda s: print(s, flush=True), replay_history=replay)
+print("converged %s after %d Newton iterations, %d GMRES matvecs, %d evaluations of the nonlinear map, %.1f s; time steps per map: %d (dt = %.5f)"
+      % (out["converged"], out["iterations"], out["gmres_matvecs"], out["evals"], time.time() - t0, sysm.nl.info()["nsteps"], sysm.nl.info()["dt"]))
+ref_n, ref_k = g["plot_newton_residuals"], g["plot_gmres_inner_steps"]
+print("\nNewton residual at the start of each step        this run        reference (read off residual.png)")
+for i, r in enumerate(out["residuals"]):
+    print("  step %d   %.4e    %s" % (i + 1, r, "%.2e" % ref_n[i] if i < len(ref_n) else "-"))
+print("GMRES inner steps per Newton step:  this run %s   reference %s" % ([len(h) - 1 for h in out["gmres_residuals"]], list(ref_k)))
+for s, key in ((0, "plot_gmres_step1"), (1, "plot_gmres_step2")):
+    if s < len(out["gmres_residuals"]):
+        print("\nGMRES residuals of Newton step %d (init, then after every inner step):   this run / reference" % (s + 1))
+        h, ref = out["gmres_residuals"][s], g[key]
+        for k in range(max(len(h), len(ref))):
+            print("  %2d   %s   %s" % (k, "%.3e" % h[k] if k < len(h) else "    -    ", "%.2e" % ref[k] if k < len(ref) else "-"))

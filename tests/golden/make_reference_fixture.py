@@ -13,6 +13,10 @@ Round 3 adds the two other base-flow files the reference ships next to a case th
   examples/rayBen/baseflow/BF_rayBen0.f00001 (+ rayBen.re2) -- fields XUPT on a 10 x 4 box, lx1 = 10.
 -> reference_bfs_baseflow.npz, reference_rayben_baseflow.npz (numbers only: coordinates, fields, element map, boundary records).
 
+  examples/cylinder/newton/Re40_fixed_point/BF.fld -- the initial guess of the reference's Newton-Krylov example (a DNS snapshot at
+      Re = 40, t = 80, fp32, on the mesh of the stability case) together with the numbers read off the convergence plot the reference
+      ships next to it (residual.png: Newton residuals and GMRES residual histories of that very run) -> reference_cyl_re40_guess.npz.
+
 Run from the repo root (needs /root/reference):  python tests/golden/make_reference_fixture.py
 """
 import os
@@ -104,3 +108,28 @@ if __name__ == "__main__":
                         # rayBen.par:5-6 userParam05 = Pr, userParam06 = Ra; rayBen.usr:98 ffy = temp * Ra * Pr
                         prandtl=np.array(1.0), rayleigh=np.array(1900.0))
     print(out4, os.path.getsize(out4), "bytes")
+    # ---- Newton-Krylov example at Re = 40: initial guess + the published convergence history ----------------------------------
+    ndir = "/root/reference/examples/cylinder/newton/Re40_fixed_point/"
+    assert open(ndir + "1cyl.re2", "rb").read() == open(SRC.replace("BF_1cyl0.f00001", "1cyl.re2"), "rb").read()   # same mesh as the stability case
+    fn = rf(ndir + "BF.fld")
+    # the file was written with another element order: bring it to the order of reference_cyl_baseflow.npz (same global elements)
+    pos = {int(g): k for k, g in enumerate(fn["elmap"])}
+    perm = np.array([pos[int(g)] for g in elmap])
+    for k in ("x", "y", "ux", "uy", "p"):
+        fn[k] = fn[k][perm]
+    assert np.max(np.abs(fn["x"] - X[:, 0])) < 1e-5 and np.max(np.abs(fn["y"] - X[:, 1])) < 1e-5    # same points (fp32 coordinates)
+    out5 = OUT.replace("reference_cyl_baseflow", "reference_cyl_re40_guess")
+    np.savez_compressed(out5, ux=fn["ux"].astype(np.float32), uy=fn["uy"].astype(np.float32), p=fn["p"].astype(np.float32),
+                        re=np.array(40.0),                         # 1cyl.par: viscosity = -40
+                        tau=np.array(1.0), dt=np.array(0.009),     # endTime = 1.0, dt = 0.009, bdf3
+                        solver_tol=np.array(1.0e-8),               # [PRESSURE] / [VELOCITY] residualTol
+                        newton_tol=np.array(1.0e-6),               # 1cyl.usr: tol = 1.0e-6_dp
+                        # read off residual.png (log axes, two significant digits): Newton residuals at the start of steps 1 - 3 ...
+                        plot_newton_residuals=np.array([9.0e-3, 1.33e-4, 1.3e-6]),
+                        # ... the GMRES residuals of Newton step 1 (init + 20 inner steps) and the inner-step counts of the three steps
+                        plot_gmres_step1=np.array([9.0e-3, 1.1e-3, 1.65e-4, 9.8e-5, 7.7e-5, 6.1e-5, 4.4e-5, 2.9e-5, 1.9e-5, 1.3e-5, 9.5e-6,
+                                                   7.2e-6, 5.6e-6, 4.4e-6, 3.4e-6, 2.7e-6, 2.2e-6, 1.8e-6, 1.5e-6, 1.2e-6, 9.7e-7]),
+                        plot_gmres_step2=np.array([1.33e-4, 8.1e-5, 3.5e-5, 2.4e-5, 1.8e-5, 1.33e-5, 1.02e-5, 7.9e-6, 6.2e-6, 4.9e-6, 3.9e-6,
+                                                   3.2e-6, 2.65e-6, 2.2e-6, 1.9e-6, 1.6e-6, 1.35e-6, 1.15e-6, 9.8e-7]),
+                        plot_gmres_inner_steps=np.array([20, 18, 2]))
+    print(out5, os.path.getsize(out5), "bytes")

@@ -121,3 +121,10 @@ def load_rayben():
     hm = BoxMesh(dim=2, n=n, nel=(E, 1), x=x, y=y, z=None, glo_num=glo, mask=[m.copy(), m.copy()], tmask=m.copy(), has_outflow=False,
                  elem_gid=np.arange(E, dtype=np.int64))
     return hm, d["ux"].copy(), d["uy"].copy(), d["p"].copy(), d["t"].copy(), int(d["lxd"]), float(d["prandtl"]), float(d["rayleigh"])
+
+
+def load_cylinder_re40_guess():
+    """The initial guess of the reference's Newton-Krylov example (examples/cylinder/newton/Re40_fixed_point/BF.fld, fp32, on the mesh
+    of the stability case) and the numbers read off the convergence plot shipped with it (tests/golden/reference_cyl_re40_guess.npz)."""
+    d = np.load(os.path.join(HERE, "golden", "reference_cyl_re40_guess.npz"))
+    return {k: (d[k].astype(np.float64) if d[k].dtype == np.float32 else d[k]) for k in d.files}

@@ -122,3 +122,29 @@ def test_rayben_field_file_conduction_state_and_hydrostatic_balance():
     # measured: 2.9e-6 (the 1.5e-6 noise of the file's T times Ra Pr dt) / 4.5e-7 / 6e-8; with the buoyancy sign flipped 1.0e-2 / 1.9
     assert out[1.0][0] < 2e-5 and out[1.0][1] < 5e-6 and out[1.0][2] < 1e-6, out
     assert out[-1.0][0] > 100 * out[1.0][0] and out[-1.0][1] > 1.0, out
+
+
+def test_re40_newton_guess_fixture():
+    """examples/cylinder/newton/Re40_fixed_point/BF.fld (the initial guess of the reference's Newton-Krylov example: a DNS snapshot
+    at Re = 40, fp32) on the mesh of the stability case: the fixture carries the fields in the element order of
+    reference_cyl_baseflow.npz and the numbers read off the reference's convergence plot.  With the oracle's operators: boundary
+    values of the case (inflow u = (1, 0), no slip on the cylinder), discretely solenoidal to single precision.  The run itself
+    (Newton residuals 9.0e-3, 1.33e-4, 1.3e-6 reproduced) is the GPU test test_gpu_newton_re40_against_the_reference_convergence_plot."""
+    from refdata import load_cylinder_re40_guess
+    hm, ux50, _, _, _, lxd, _ = load_cylinder(with_bcs=True)
+    g = load_cylinder_re40_guess()
+    assert g["ux"].shape == ux50.shape and float(g["re"]) == 40.0 and float(g["tau"]) == 1.0
+    assert len(g["plot_gmres_step1"]) == 21 and list(g["plot_gmres_inner_steps"]) == [20, 18, 2]
+    sem = SEM(hm, lxd=lxd)
+    u = [g["ux"].reshape(sem.shape1), g["uy"].reshape(sem.shape1)]
+    x, y = hm.x.reshape(sem.shape1), hm.y.reshape(sem.shape1)
+    inflow = np.abs(x + 16.0) < 1e-6
+    wall = np.abs(np.hypot(x, y) - 0.5) < 1e-5
+    assert inflow.sum() > 50 and wall.sum() > 50
+    assert np.abs(u[0][inflow] - 1.0).max() < 1e-6 and np.abs(u[1][inflow]).max() < 1e-6
+    assert np.abs(u[0][wall]).max() < 1e-6 and np.abs(u[1][wall]).max() < 1e-6
+    div = sem.opdiv(u) / sem.bm2
+    l2 = np.sqrt(np.sum(div ** 2 * sem.bm2) / sem.volvm2)
+    gcol = sem.gradm1(u[0])[0] + sem.gradm1(u[1])[1]
+    l2col = np.sqrt(np.sum(gcol ** 2 * sem.bm1) / sem.volvm1)
+    assert l2 < 1e-6 and l2col > 100 * l2, (l2, l2col)     # fp32 field: divergence at single-precision level
