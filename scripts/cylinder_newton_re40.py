@@ -19,7 +19,10 @@ tau, tol = float(g["tau"]), float(g["newton_tol"])
 sysm = host.nek_system(tau, X, re=float(g["re"]), maxit_v=400, maxit_p=4000)
 print("mesh: E = %d, lx1 = %d, lxd = %d; Re = %g, tau = %g, Newton tolerance %.0e (constant solver-tolerance scheduler)" % (hm.x.shape[0], hm.n, lxd, float(g["re"]), tau, tol))
 t0 = time.time()
-replay = len(sys.argv) > 1 and sys.argv[1] == "replay"   # jac_exptA_matvec replays the restart history of its argument (fixed_point.f90:73)
+replay = len(sys.argv) > 1 and sys.argv[1].startswith("replay")
+if len(sys.argv) > 1 and sys.argv[1] == "replay-literal":     # ... with the literal reading of the history update in axpby (include/neklab_gpu.h)
+    host.check(ctx.lib.nlg_set_axpby_rst_consistent(0))
+    print("axpby: literal history update")   # jac_exptA_matvec replays the restart history of its argument (fixed_point.f90:73)
 print("GMRES: Krylov vectors %s their restart history" % ("replay" if replay else "are stripped of"))
 out = host.newton_fixed_point_iteration(sysm, X, tol, tol_mode=1, kdim=30, log=lambda s: print(s, flush=True), replay_history=replay)
 print("converged %s after %d Newton iterations, %d GMRES matvecs, %d evaluations of the nonlinear map, %.1f s; time steps per map: %d (dt = %.5f)"
