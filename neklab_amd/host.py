@@ -759,6 +759,17 @@ def _gl_to_gll_matrix(n: int) -> np.ndarray:
     return M
 
 
+def pressure_from_mesh1(mesh: "Mesh", p1) -> np.ndarray:
+    """A pressure given on the velocity mesh (what a field file holds) on the pressure mesh: tensor interpolation GLL -> GL inside
+    every element, as Nek5000's restart does for a Pn-Pn-2 run (`map_pm1_to_pr`).  Returns the flat array for set_field(PR, .)."""
+    n, dim, E = mesh.host.n, mesh.host.dim, mesh.host.E
+    M = _gll_to_gl_matrix(n)
+    p = np.asarray(p1, dtype=np.float64).reshape((E,) + (n,) * dim)
+    for ax in range(1, dim + 1):
+        p = np.moveaxis(np.tensordot(M, p, axes=([1], [ax])), 0, ax)
+    return np.ascontiguousarray(p.reshape(-1))
+
+
 def pressure_to_mesh1(vec: nek_dvector) -> np.ndarray:
     """Pressure of `vec` on the velocity mesh, as Nek5000's outpost writes it for a Pn-Pn-2 run (`mappr`: tensor
     interpolation GL -> GLL inside every element, then the direct-stiffness average across elements)."""

@@ -14,7 +14,7 @@ from refdata import load_cylinder, load_cylinder_re40_guess
 hm, _, _, _, _, lxd, _ = load_cylinder(with_bcs=True)
 g = load_cylinder_re40_guess()
 ctx = host.Context(); gm = host.Mesh(ctx, hm, lxd=lxd)
-X = host.nek_dvector(gm); X.set_field(host.VX, g["ux"]); X.set_field(host.VY, g["uy"]); X.set_field(host.PR, np.zeros(gm.lpn))
+X = host.nek_dvector(gm); X.set_field(host.VX, g["ux"]); X.set_field(host.VY, g["uy"]); X.set_field(host.PR, host.pressure_from_mesh1(gm, g['p']))   # load_fld reads the pressure too (XUP file)
 tau, tol = float(g["tau"]), float(g["newton_tol"])
 sysm = host.nek_system(tau, X, re=float(g["re"]), maxit_v=400, maxit_p=4000)
 print("mesh: E = %d, lx1 = %d, lxd = %d; Re = %g, tau = %g, Newton tolerance %.0e (constant solver-tolerance scheduler)" % (hm.x.shape[0], hm.n, lxd, float(g["re"]), tau, tol))

@@ -111,11 +111,12 @@ def test_gpu_hydrostatic_balance_on_rayben_field(gpu_ctx):
 def test_gpu_newton_re40_against_the_reference_convergence_plot(gpu_ctx):
     """The reference's Newton-Krylov example (examples/cylinder/newton/Re40_fixed_point: 1cyl.usr loads BF.fld and calls
     newton_fixed_point_iteration(sys, bf, 1e-6); 1cyl.par: Re = 40, endTime = 1, bdf3) run through the HIP path, against the
-    convergence history the reference ships for that very run (residual.png: Newton residuals 9.0e-3, 1.33e-4, 1.3e-6 at a
-    constant solver tolerance, converged after the third step).  A reference-held OUTPUT of the path nonlinear map -> Jacobian
-    (exptA about the current iterate) -> GMRES -> update.  Tolerances: the reading precision of a
-    log-scale plot (3 %) for the first two residuals; the third sits at the level of the linear-solver tolerance (1e-6) and is
-    only bounded.  profiles/r03_cylinder_newton_re40.txt has the full log (this run: 9.014e-3, 1.3326e-4, 1.44e-6)."""
+    convergence history the reference ships for that very run (residual.png): Newton residuals 9.0e-3, 1.33e-4, 1.3e-6 at a
+    constant solver tolerance, and the GMRES residual after every inner step of Newton steps 1 and 2 (20 and 18 inner steps).
+    A reference-held OUTPUT of the path nonlinear map -> Jacobian (exptA about the current iterate) -> GMRES -> update
+    (SURVEY section 8f row 3), 39 Krylov vectors deep.  Tolerances: the reading precision of a log-scale plot -- 3 % for the
+    Newton residuals, 12 % pointwise for the GMRES curves (this build: within 4 % except one point at 8 %); values at the level
+    of the linear-solver tolerance (1e-6) are only bounded.  profiles/r03_cylinder_newton_re40.txt has the full log."""
     from refdata import load_cylinder_re40_guess
     hm, _, _, _, _, lxd, _ = load_cylinder(with_bcs=True)
     g = load_cylinder_re40_guess()
@@ -123,6 +124,7 @@ def test_gpu_newton_re40_against_the_reference_convergence_plot(gpu_ctx):
     X = host.nek_dvector(gm)
     X.set_field(host.VX, g["ux"])
     X.set_field(host.VY, g["uy"])
+    X.set_field(host.PR, host.pressure_from_mesh1(gm, g["p"]))     # load_fld reads the pressure of the XUP file too
     sysm = host.nek_system(float(g["tau"]), X, re=float(g["re"]), maxit_v=400, maxit_p=4000)
     out = host.newton_fixed_point_iteration(sysm, X, float(g["newton_tol"]), tol_mode=1, kdim=30)
     ref = g["plot_newton_residuals"]
@@ -131,7 +133,9 @@ def test_gpu_newton_re40_against_the_reference_convergence_plot(gpu_ctx):
     assert abs(r[0] / ref[0] - 1.0) < 0.03 and abs(r[1] / ref[1] - 1.0) < 0.03, r
     assert 0.5 * ref[2] < r[2] < 2.0 * ref[2], r
     assert r[3] < float(g["newton_tol"])
-    # the GMRES solves reach the reference's tolerance from the reference's starting residuals (the inner-step counts are
-    # LightKrylov's business: 20 / 18 / 2 there, more here)
     h = out["gmres_residuals"]
-    assert abs(h[0][0] / g["plot_gmres_step1"][0] - 1.0) < 0.03 and h[0][-1] <= 1e-6 and h[1][-1] <= 1e-6
+    ref1, ref2 = g["plot_gmres_step1"], g["plot_gmres_step2"]
+    assert len(h[0]) - 1 == 20 and abs((len(h[1]) - 1) - 18) <= 1 and len(h[2]) - 1 <= 2, [len(x) - 1 for x in h]
+    assert np.max(np.abs(np.array(h[0]) / ref1 - 1.0)) < 0.12, np.array(h[0]) / ref1
+    k2 = min(len(h[1]), len(ref2))
+    assert np.max(np.abs(np.array(h[1][:k2]) / ref2[:k2] - 1.0)) < 0.12, np.array(h[1][:k2]) / ref2[:k2]
