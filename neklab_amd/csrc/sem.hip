@@ -892,17 +892,19 @@ __device__ __forceinline__ void lds_barrier() {
 // hand-overs per slab are block barriers (two or three waves: cheap) instead of the wave-level LDS ordering.  Row k of D
 // comes from LDS at a block-uniform address (broadcast).  Replaces the LDS-cube kernel k_axhelm3, which ran at 25 % of
 // the HBM roofline at lx1 = 10 (452 us for 912 MB at 6000 elements) against 58 % for k_axhelm3r at lx1 = 8.
-template <int N, bool XP = false>
-__global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E, int nf, const double *__restrict__ Dg,
+// PPB (element, field) pairs per block (round 3): N N threads fill only 75 - 78 % of the lanes of their waves at N = 10, 12; three pairs
+// side by side (thread -> pair tid / (N N)) fill 94 - 96 %.  Each pair has its own three slabs in LDS; the barriers are the block's.
+template <int N, bool XP = false, int PPB = 1>
+__global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E, int nf, const double *__restrict__ Dg,
                                                                         const double *__restrict__ G0, const double *__restrict__ G1,
                                                                         const double *__restrict__ G2, const double *__restrict__ G3,
                                                                         const double *__restrict__ G4, const double *__restrict__ G5,
                                                                         const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                                         double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
                                                                         const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld) {
-    constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((NS + 63) / 64) * 64, NWB = NTB / 64;
+    constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((PPB * NS + 63) / 64) * 64, NWB = NTB / 64;
     __shared__ double sD[NS];
-    __shared__ double mU[N * NQ], mR[N * NQ], mS[N * NQ];
+    __shared__ double mUa[PPB][N * NQ], mRa[PPB][N * NQ], mSa[PPB][N * NQ];
     __shared__ double sred[NWB];
     {
         const int64_t lo = (int64_t)blockIdx.y * ld;
@@ -920,10 +922,14 @@ __global__ __launch_bounds__(((N * N + 63) / 64) * 64) void k_axhelm3c(int64_t E
     const int tid = threadIdx.x;
     for (int p = tid; p < NS; p += NTB) sD[p] = Dg[p];
     lds_barrier();
-    const int64_t e = (int64_t)blockIdx.x / nf;
-    const int c = (int)((int64_t)blockIdx.x % nf);
-    const bool act = tid < NS;
-    const int ij = act ? tid : 0;
+    const int pb = tid / NS;                                   // pair of this thread within the block
+    const int64_t pair = (int64_t)blockIdx.x * PPB + (pb < PPB ? pb : 0);
+    const bool act = pb < PPB && pair < E * nf;
+    const int64_t pr_ = act ? pair : 0;
+    const int64_t e = pr_ / nf;
+    const int c = (int)(pr_ % nf);
+    const int ij = act ? tid - pb * NS : 0;
+    double *const mU = mUa[pb < PPB ? pb : 0], *const mR = mRa[pb < PPB ? pb : 0], *const mS = mSa[pb < PPB ? pb : 0];
     const int i = ij % N, j = ij / N;
     const int pij = XP ? xptab[ij] : ij;   // slab-permuted layout: the vectors of the PCG; the metric arrays stay natural
     const int64_t eoff = e * NP;
@@ -2794,13 +2800,20 @@ int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate, int nl, int64_t 
     return 0;
 }
 
+// pairs per block of k_axhelm3c (NLG_AXHELM_PPB=1: one pair per block, the round-2 form)
+static int axhelm3c_ppb(int n) {
+    static const int env = getenv("NLG_AXHELM_PPB") ? atoi(getenv("NLG_AXHELM_PPB")) : 0;
+    if (env == 1) return 1;
+    return n == 12 ? 3 : 1;   // measured at 10^4 elements: lx1 = 12 838 -> 778 us (144 of 192 lanes -> 432 of 448), lx1 = 10 397 -> 519 us
+}
+
 int sem_axhelm_blocks(nlg_mesh *m, int nf) {
     if (m->dim == 2) {
         const int epb = NT / (m->n * m->n) > 0 ? NT / (m->n * m->n) : 1;
         return (int)((m->E + epb - 1) / epb);
     }
     static const bool use_cube = getenv("NLG_AXHELM_CUBE") && atoi(getenv("NLG_AXHELM_CUBE")) != 0;
-    if (m->n > 8 && !use_cube) return (int)(m->E * nf);   // k_axhelm3c: one block per (element, field)
+    if (m->n > 8 && !use_cube) return (int)((m->E * nf + axhelm3c_ppb(m->n) - 1) / axhelm3c_ppb(m->n));   // k_axhelm3c: PPB (element, field) pairs per block
     const int nslot = axhelm3_nslot(m->n);
     return (int)((m->E * nf + nslot - 1) / nslot);
 }
@@ -2845,12 +2858,22 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         NLG_LAUNCH((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
                            m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
         else                                                                                                          \
-        { if (xp)                                                                                                     \
-        NLG_LAUNCH((k_axhelm3c<N_, true>), dim3((unsigned)tot, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
-        else                                                                                                          \
-        NLG_LAUNCH((k_axhelm3c<N_, false>), dim3((unsigned)tot, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); } \
+        {                                                                                                             \
+            constexpr int PPB_ = 3;                                                                    \
+            const bool one = axhelm3c_ppb(N_) == 1;                                                                   \
+            const unsigned gb = (unsigned)((tot + (one ? 1 : PPB_) - 1) / (one ? 1 : PPB_));                          \
+            if (one) {                                                                                                \
+                if (xp)                                                                                               \
+                    NLG_LAUNCH((k_axhelm3c<N_, true, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
+                else                                                                                                  \
+                    NLG_LAUNCH((k_axhelm3c<N_, false, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); \
+            } else {                                                                                                  \
+                if (xp)                                                                                               \
+                    NLG_LAUNCH((k_axhelm3c<N_, true, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
+                else                                                                                                  \
+                    NLG_LAUNCH((k_axhelm3c<N_, false, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); \
+            }                                                                                                         \
+        }                                                                                                             \
     }
         NLG_FOR_N(AX3)
 #undef AX3
