@@ -138,3 +138,20 @@ def test_re2_reader_on_the_reference_files_if_present():
     from refdata import load_cylinder_mesh
     xc, yc, curves, vert, pmap = load_cylinder_mesh()
     assert np.array_equal(xc, r["xc"]) and np.array_equal(vert, m["vert"]) and np.array_equal(pmap, m["pmap"])
+
+
+def test_pressure_from_mesh1_is_exact_for_polynomials():
+    """host.pressure_from_mesh1 (what Nek5000's restart does with the mesh-1 pressure of a field file): tensor interpolation
+    GLL -> GL inside every element, exact for polynomials of degree lx1 - 1 in the reference coordinates."""
+    from types import SimpleNamespace
+    from neklab_amd import host
+    from neklab_amd.mesh import gll_points
+    n, dim, E = 6, 2, 3
+    z1 = gll_points(n)
+    z2 = np.polynomial.legendre.leggauss(n - 2)[0]
+    f = lambda r, s, e: (1.0 + e) * (r ** 5 - 0.3 * r ** 2 * s ** 3 + s ** 4 - 0.7)
+    p1 = np.stack([f(z1[None, :], z1[:, None], e) for e in range(E)])          # [e][j][i]
+    ref = np.stack([f(z2[None, :], z2[:, None], e) for e in range(E)])
+    mesh = SimpleNamespace(host=SimpleNamespace(n=n, dim=dim, E=E))
+    out = host.pressure_from_mesh1(mesh, p1).reshape(E, n - 2, n - 2)
+    assert np.max(np.abs(out - ref)) < 1e-13
