@@ -571,7 +571,7 @@ def gmres(exptA: exptA_linop, b: nek_dvector, x: nek_dvector, atol: float, kdim:
     needs 17 iterations with the replay (the Krylov operator is then the start-up-free continuation map, not the
     derivative of the map being solved) and 3 without.  The converged fixed point is the same."""
     mesh = b.mesh
-    B = basis if basis is not None else KrylovBasis(mesh, kdim + 1)
+    B = basis if basis is not None else KrylovBasis(mesh, kdim + 1, b.nscal, b.lorder)
     x.zero()
     r = b.copy()
     nmv = 0
@@ -642,7 +642,7 @@ def newton_fixed_point_iteration(sys: nek_system, bf: nek_dvector, tol: float, t
     mesh = bf.mesh
     r = nek_dvector(mesh, bf.nscal, bf.lorder)
     dx = nek_dvector(mesh, bf.nscal, bf.lorder)
-    B = KrylovBasis(mesh, kdim + 1)
+    B = KrylovBasis(mesh, kdim + 1, bf.nscal, bf.lorder)     # (with the scalar of a temperature-coupled system)
     final = sched(0.0, tol, 0.0)               # the tightest level the scheduler will ever set
     cur, rnorm = 0.0, 1.0
     residuals, nmv_total, converged = [], 0, False

@@ -163,7 +163,7 @@ def read_re2(path):
         r = raw[off: off + 64]
         off += 64
         v = np.frombuffer(r[:56], dtype=np.float64)
-        curves.append((int(v[0]), int(v[1]), v[2:7].copy(), r[56:64].decode().strip()))
+        curves.append((int(v[0]), int(v[1]), v[2:7].copy(), chr(r[56])))   # ccurve is character*1: genbox leaves the other seven bytes unset
     out["curves"] = curves
     nbc = int(np.frombuffer(raw[off: off + 8], dtype=np.float64)[0])
     off += 8
@@ -174,6 +174,18 @@ def read_re2(path):
         v = np.frombuffer(r[:16], dtype=np.float64)
         bcs.append((int(v[0]), int(v[1]), r[56:64].decode().strip()))
     out["bcs"] = bcs
+    # further fields (temperature, passive scalars): same record layout, one section per field
+    out["bcs_fields"] = [bcs]
+    while off + 8 <= len(raw):
+        nbc = int(np.frombuffer(raw[off: off + 8], dtype=np.float64)[0])
+        off += 8
+        sec = []
+        for _ in range(nbc):
+            r = raw[off: off + 64]
+            off += 64
+            v = np.frombuffer(r[:16], dtype=np.float64)
+            sec.append((int(v[0]), int(v[1]), r[56:64].decode(errors="replace").strip()))
+        out["bcs_fields"].append(sec)
     return out
 
 

@@ -17,6 +17,11 @@ Round 3 adds the two other base-flow files the reference ships next to a case th
       Re = 40, t = 80, fp32, on the mesh of the stability case) together with the numbers read off the convergence plot the reference
       ships next to it (residual.png: Newton residuals and GMRES residual histories of that very run) -> reference_cyl_re40_guess.npz.
 
+  examples/thermosyphon/baseflow/tsyphon.re2 -- the annulus 1 <= r <= 2 (8 x 32 elements with circular-arc sides, genbox + curved sides;
+      velocity 'W', temperature 't' on both walls, periodic in the angle) of the reference's temperature-coupled Newton example, the
+      parameters of tsyphon.par / tsyphon.usr, and the Newton residuals read off the convergence plot shipped with the case
+      (residual.png; its initial guess BF_Ra500_tsyphon0.f00001 is NOT shipped) -> reference_tsyphon_mesh.npz.
+
 Run from the repo root (needs /root/reference):  python tests/golden/make_reference_fixture.py
 """
 import os
@@ -133,3 +138,23 @@ if __name__ == "__main__":
                                                    3.2e-6, 2.65e-6, 2.2e-6, 1.9e-6, 1.6e-6, 1.35e-6, 1.15e-6, 9.8e-7]),
                         plot_gmres_inner_steps=np.array([20, 18, 2]))
     print(out5, os.path.getsize(out5), "bytes")
+    # ---- thermosyphon: mesh, parameters, published Newton residuals ---------------------------------------------------------
+    tdir = "/root/reference/examples/thermosyphon/baseflow/"
+    rt = read_re2(tdir + "tsyphon.re2")
+    assert rt["nel"] == 256 and all(c[3] == "C" for c in rt["curves"]) and len(rt["bcs_fields"]) == 2
+    out6 = OUT.replace("reference_cyl_baseflow", "reference_tsyphon_mesh")
+    np.savez_compressed(out6, xc=rt["xc"], yc=rt["yc"], curve_elem=np.array([c[0] for c in rt["curves"]]),
+                        curve_edge=np.array([c[1] for c in rt["curves"]]), curve_par=np.array([c[2] for c in rt["curves"]]),
+                        bc_elem=np.array([b[0] for b in rt["bcs_fields"][0]]), bc_face=np.array([b[1] for b in rt["bcs_fields"][0]]),
+                        bc_tag=np.array([b[2] for b in rt["bcs_fields"][0]]), tbc_tag=np.array([b[2] for b in rt["bcs_fields"][1]]),
+                        n=np.array(8), lxd=np.array(12),                         # SIZE: lx1 = 8, lxd = 12
+                        # tsyphon.par: viscosity = -5 (nu = 1/5), conductivity = 1, rhocp = 1, userparam06 = 510 (Ra), endTime = 1, bdf3,
+                        # tolerances 1e-8; tsyphon.usr: ffy = T * |param(2) * uparam(6)| = T nu Ra, wall temperature 0.5 (1 + tanh(-20 y)),
+                        # newton_fixed_point_iteration(sys, bf, 1e-6, tol_mode = 2) from the Ra = 500 base flow
+                        nu=np.array(0.2), conductivity=np.array(1.0), rhocp=np.array(1.0), rayleigh=np.array(510.0), rayleigh_guess=np.array(500.0),
+                        tau=np.array(1.0), newton_tol=np.array(1.0e-6),
+                        # read off residual.png: Newton residuals at the start of steps 1 - 9
+                        plot_newton_residuals=np.array([4.2e-1, 1.3e-3, 6.6e-5, 4.0e-6, 6.3e-7, 1.7e-7, 6.5e-8, 3.3e-8, 1.8e-8]),
+                        # GMRES of Newton step 1: residual at the start and after inner steps 1 - 3; tolerance lines of steps 1, 3, 4 (dashed)
+                        plot_gmres_step1=np.array([4.2e-1, 6.6e-3, 1.75e-4, 2.45e-5]), plot_gmres_tol=np.array([1.0e-4, 6.6e-6, 4.0e-7]))
+    print(out6, os.path.getsize(out6), "bytes")

@@ -128,3 +128,24 @@ def load_cylinder_re40_guess():
     of the stability case) and the numbers read off the convergence plot shipped with it (tests/golden/reference_cyl_re40_guess.npz)."""
     d = np.load(os.path.join(HERE, "golden", "reference_cyl_re40_guess.npz"))
     return {k: (d[k].astype(np.float64) if d[k].dtype == np.float32 else d[k]) for k in d.files}
+
+
+def load_tsyphon():
+    """The mesh of the reference's temperature-coupled Newton example (examples/thermosyphon/baseflow/tsyphon.re2: the annulus
+    1 <= r <= 2, 8 x 32 elements with circular-arc sides, lx1 = 8; velocity 'W' / temperature 't' on both walls, periodic in the angle --
+    on the closed ring the periodic faces coincide, so the connectivity follows from the coordinates), with the case parameters and the
+    Newton residuals read off the plot shipped with the case.  -> (mesh, dict of parameters)"""
+    from neklab_amd.nekio import re2_gll_coords
+    d = np.load(os.path.join(HERE, "golden", "reference_tsyphon_mesh.npz"))
+    n = int(d["n"])
+    curves = [(int(e), int(s), p, "C") for e, s, p in zip(d["curve_elem"], d["curve_edge"], d["curve_par"])]
+    x, y = re2_gll_coords(d["xc"], d["yc"], curves, n)
+    E = x.shape[0]
+    glo = _glo_from_coords(x, y, tol=1e-9)
+    r = np.hypot(x, y)
+    wall = (np.abs(r - 1.0) < 1e-9) | (np.abs(r - 2.0) < 1e-9)
+    assert int(wall.sum()) == 64 * n                      # the 64 'W' / 't' faces of the file
+    m = np.where(wall, 0.0, 1.0)
+    hm = BoxMesh(dim=2, n=n, nel=(E, 1), x=x, y=y, z=None, glo_num=glo, mask=[m.copy(), m.copy()], tmask=m.copy(), has_outflow=False,
+                 elem_gid=np.arange(E, dtype=np.int64))
+    return hm, {k: d[k] for k in d.files}

@@ -148,3 +148,16 @@ def test_re40_newton_guess_fixture():
     gcol = sem.gradm1(u[0])[0] + sem.gradm1(u[1])[1]
     l2col = np.sqrt(np.sum(gcol ** 2 * sem.bm1) / sem.volvm1)
     assert l2 < 1e-6 and l2col > 100 * l2, (l2, l2col)     # fp32 field: divergence at single-precision level
+
+
+def test_tsyphon_mesh_fixture():
+    """examples/thermosyphon/baseflow/tsyphon.re2 (genbox + circular-arc sides): the annulus 1 <= r <= 2 with 8 x 32 elements, lx1 = 8 --
+    closed ring, walls at r = 1, 2.  57 x 224 distinct points; every element edge on a wall is an arc of that circle."""
+    from refdata import load_tsyphon
+    hm, d = load_tsyphon()
+    assert hm.x.shape == (256, 64) and len(np.unique(hm.glo_num)) == 57 * 224
+    r = np.hypot(hm.x, hm.y)
+    assert abs(r.min() - 1.0) < 1e-12 and abs(r.max() - 2.0) < 1e-12
+    assert int((hm.mask[0] == 0).sum()) == 64 * 8 and np.array_equal(hm.mask[0], hm.tmask)
+    sem = SEM(hm, lxd=int(d["lxd"]))
+    assert abs(np.sum(sem.bm1) - np.pi * 3.0) < 1e-9          # area of the annulus from the curved-element mass matrix
