@@ -72,7 +72,7 @@ def classify(rows):
     for _, k, v in rows:
         site = ""
         if k.startswith("k_gs<"):
-            if re.match(r"k_axhelm3rb?<\d+, \d+, true", prev) or re.match(r"k_rhs<\d+, true", prev):
+            if re.match(r"k_axhelm3rb?<\d+, \d+, true", prev) or re.match(r"k_axhelm3c<\d+, true", prev) or re.match(r"k_rhs<\d+, true", prev):
                 site = "slab-permuted (velocity PCG)"
             elif re.match(r"k_opgradt3(<\d+, \d+|n<\d+), true", prev) or re.match(r"k_fdm|k_sch|k_q1", prev):
                 site = "face-grouped (pressure operator / Schwarz exchange)"
