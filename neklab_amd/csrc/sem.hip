@@ -2391,6 +2391,225 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_conv3s(int64_t E, const doubl
     }
 }
 
+// The scalar (temperature) transport term of the Boussinesq coupling as a plane sweep of the same kind (round 3; it went through seven
+// launches of the generic tensor kernel and a combine pass, 7.7 % of a config-4-shaped step):
+//   out = J^T [ sgn sum_j Ur_j (d theta / d r_j)_fine + gsel sum_m uf_m GT_m ]       direct: sgn = gsel = 1; adjoint: sgn = -1, gsel = 0
+// Four fields are interpolated level by level -- the three velocity components (value only) and theta (three derivatives only); in
+// the y stage lane (a, f), f < 3, forms the value of component f AND the f-th derivative of theta, so that its share
+// sgn Ur_f dtheta_f + gsel uf_f GT_f of the sum is local and the three shares meet by lane exchange.  One field is projected back.
+template <int N, int ND, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_conv3s_scalar(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, const double *__restrict__ Jt,
+                                                              CF3 Ur, CF3 GT, CF3 u, const double *__restrict__ theta, double *__restrict__ out, int adjoint) {
+    constexpr int NN = N * N, NP = NN * N, NDD = ND * ND, NPD = NDD * ND;
+    constexpr int NQ = N | 1, NDQ = ND | 1;
+    constexpr int OB = (ND + NW - 1) / NW, OJ = (N + NW - 1) / NW;
+    static_assert(4 * NN <= NW * 64 && 3 * ND <= 64 && 4 * N <= 64, "one thread per coarse column and field; (a, f) and (j, f) in one wave");
+    __shared__ double sZ0[4][NQ * N], sZ1[NQ * N];
+    __shared__ double sXu[3][NDQ * N], sXt[3][NDQ * N];
+    __shared__ double sAc[NDQ * ND], sY[NDQ * N], sP[NN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t e = blockIdx.x;
+    if (e >= E) return;
+    const bool r1 = tid < 4 * NN;                    // coarse column (i, j) of field f1 (0 .. 2: velocity, 3: theta)
+    const int f1 = r1 ? tid / NN : 0, ij = r1 ? tid % NN : 0;
+    const bool rt = r1 && f1 == 3;                   // ... the theta columns also carry the accumulators of the result
+    const int zidx = (ij % N) + NQ * (ij / N);
+    const bool r2 = lane < 4 * N;                    // (j, f)
+    const int j2 = r2 ? lane % N : 0, f2 = r2 ? lane / N : 0;
+    const bool r3 = lane < 3 * ND;                   // (a, f), f < 3
+    const int a3 = r3 ? lane % ND : 0, f3 = r3 ? lane / ND : 0;
+    const int qf = f3 == 0 ? 1 : (f3 == 1 ? 0 : 2);  // the stage array of theta this lane differentiates: d/dr from DJ_x, d/ds from J_x (then DJ_y), d/dt from J_x DJ_z
+    const bool r4 = lane < ND, r5 = lane < N;
+    const double sgn = adjoint ? -1.0 : 1.0, gsel = adjoint ? 0.0 : 1.0;
+    const double *__restrict__ um = f3 == 0 ? Ur.p[0] : (f3 == 1 ? Ur.p[1] : Ur.p[2]);
+    const double *__restrict__ gm = f3 == 0 ? GT.p[0] : (f3 == 1 ? GT.p[1] : GT.p[2]);
+    double uc[N], oacc[N];
+    {
+        const double *__restrict__ up = (f1 == 0 ? u.p[0] : (f1 == 1 ? u.p[1] : (f1 == 2 ? u.p[2] : theta))) + e * NP + ij;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            uc[k] = up[NN * k];
+            oacc[k] = 0.0;
+        }
+    }
+    double bf[2][OB][2];
+    auto request = [&](auto slot, int c) {   // branch-free, clamped (see k_conv3s)
+        constexpr int S = decltype(slot)::value;
+        const int64_t qc = e * NPD + (int64_t)(c < ND ? c : ND - 1) * NDD + a3;
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const int b = wave + NW * o < ND ? wave + NW * o : ND - 1;
+            const int64_t q = qc + ND * b;
+            bf[S][o][0] = um[q], bf[S][o][1] = gm[q];
+        }
+    };
+    request(std::integral_constant<int, 0>{}, 0);
+    request(std::integral_constant<int, 1>{}, 1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" ::"v"(uc[k]));
+
+    auto S1 = [&](int c) {
+        if (r1) {
+            const double *__restrict__ r0 = Jg + c * N, *__restrict__ rd = DJg + c * N;
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                z0 += r0[k] * uc[k];
+                z1 += rd[k] * uc[k];
+            }
+            sZ0[f1][zidx] = z0;
+            if (rt) sZ1[zidx] = z1;
+        }
+    };
+    auto S2 = [&]() {
+        if (r2) {
+            double z0[N], z1[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                z0[i] = sZ0[f2][i + NQ * j2];
+                z1[i] = sZ1[i + NQ * j2];
+            }
+#pragma unroll
+            for (int o = 0; o < OB; ++o) {
+                const int a = wave + NW * o;
+                if (a < ND) {
+                    const double *__restrict__ r0 = Jg + a * N, *__restrict__ rd = DJg + a * N;
+                    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        x0 += r0[i] * z0[i];
+                        x1 += rd[i] * z0[i];
+                        x2 += r0[i] * z1[i];
+                    }
+                    if (f2 < 3) {
+                        sXu[f2][a + NDQ * j2] = x0;
+                    } else {
+                        sXt[0][a + NDQ * j2] = x0;
+                        sXt[1][a + NDQ * j2] = x1;
+                        sXt[2][a + NDQ * j2] = x2;
+                    }
+                }
+            }
+        }
+    };
+    auto S3 = [&](auto slot, int c) {
+        constexpr int S = decltype(slot)::value;
+        double val[OB], dth[OB];
+#pragma unroll
+        for (int o = 0; o < OB; ++o) val[o] = dth[o] = 0.0;
+        if (r3) {
+            double xu[N], yt[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                xu[j] = sXu[f3][a3 + NDQ * j];
+                yt[j] = sXt[qf][a3 + NDQ * j];
+            }
+#pragma unroll
+            for (int o = 0; o < OB; ++o) {
+                const int b = wave + NW * o;
+                if (b < ND) {
+                    const double *__restrict__ r0 = Jg + b * N, *__restrict__ rd = DJg + b * N;
+                    double tj = 0.0, td = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        val[o] += r0[j] * xu[j];
+                        tj += r0[j] * yt[j];
+                        td += rd[j] * yt[j];
+                    }
+                    dth[o] = f3 == 1 ? td : tj;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const int b = wave + NW * o;
+            if (b < ND) {   // wave-uniform
+                const double sh = sgn * bf[S][o][0] * dth[o] + gsel * (val[o] * bf[S][o][1]);
+                const double t0 = __shfl(sh, a3, 64), t1 = __shfl(sh, a3 + ND, 64), t2 = __shfl(sh, a3 + 2 * ND, 64);
+                if (r3 && f3 == 0) sAc[a3 + NDQ * b] = (t0 + t1) + t2;
+            }
+        }
+        request(slot, c + 2);
+    };
+    auto S4 = [&]() {
+        if (r4) {
+            double col[ND];
+#pragma unroll
+            for (int b = 0; b < ND; ++b) col[b] = sAc[lane + NDQ * b];
+#pragma unroll
+            for (int o = 0; o < OJ; ++o) {
+                const int j = wave + NW * o;
+                if (j < N) {
+                    double y = 0.0;
+#pragma unroll
+                    for (int b = 0; b < ND; ++b) y += Jt[j * ND + b] * col[b];
+                    sY[lane + NDQ * j] = y;
+                }
+            }
+        }
+    };
+    auto S5 = [&]() {
+        if (r5) {
+            double row[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) row[a] = sY[a + NDQ * lane];
+#pragma unroll
+            for (int o = 0; o < OJ; ++o) {
+                const int i = wave + NW * o;
+                if (i < N) {
+                    double p = 0.0;
+#pragma unroll
+                    for (int a = 0; a < ND; ++a) p += Jt[i * ND + a] * row[a];
+                    sP[i + N * lane] = p;
+                }
+            }
+        }
+    };
+    auto S6 = [&](int c) {
+        if (rt) {
+            const double p = sP[ij];
+            const double *__restrict__ r0 = Jg + c * N;
+#pragma unroll
+            for (int k = 0; k < N; ++k) oacc[k] += r0[k] * p;
+        }
+    };
+    S1(0);
+    lds_barrier();
+    S2();
+    lds_barrier();
+    S3(std::integral_constant<int, 0>{}, 0);
+    lds_barrier();
+    auto level = [&](auto slot, int c) {
+        S1(c);
+        S4();
+        lds_barrier();
+        S2();
+        S5();
+        lds_barrier();
+        S3(slot, c);
+        S6(c - 1);
+        lds_barrier();
+    };
+#pragma unroll 1
+    for (int cv = 1; cv + 1 < ND; cv += 2) {
+        const int c = __builtin_amdgcn_readfirstlane(cv);
+        level(std::integral_constant<int, 1>{}, c);
+        level(std::integral_constant<int, 0>{}, c + 1);
+    }
+    if (ND % 2 == 0) level(std::integral_constant<int, 1>{}, ND - 1);
+    S4();
+    lds_barrier();
+    S5();
+    lds_barrier();
+    S6(ND - 1);
+    if (rt) {
+        double *__restrict__ op = out + e * NP + ij;
+#pragma unroll
+        for (int k = 0; k < N; ++k) op[NN * k] = oacc[k];
+    }
+}
+
 // =================================================================================================
 // Dealiasing interpolation on the matrix cores: one velocity-mesh field -> its value and its three reference-space
 // derivatives on the fine (Gauss) mesh,
@@ -3355,6 +3574,17 @@ int sem_scalar_grad_apply(nlg_mesh *m, double *const *GT, const double *theta, d
 int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, double *const *u, const double *theta, double *out, int adjoint) {
     ProfScope ps(m->ctx, P_CONV);
     const int dim = m->dim;
+    static const bool sweep = !(getenv("NLG_CONVS_SWEEP") && atoi(getenv("NLG_CONVS_SWEEP")) == 0);   // A/B: the generic tensor kernels
+    if (sweep && dim == 3 && m->n >= 8 && m->n <= 10 && m->nd == (3 * m->n) / 2) {
+        CF3 cur = {{Ur[0], Ur[1], Ur[2]}}, cgt = {{GT[0], GT[1], GT[2]}}, cu = {{u[0], u[1], u[2]}};
+#define CVS(N_, NW_)                                                                                                                         \
+    NLG_LAUNCH((k_conv3s_scalar<N_, (3 * N_) / 2, NW_>), dim3((unsigned)m->E), dim3(NW_ * 64), 0, m->ctx->stream, m->E, (const double *)m->d_Jd, \
+               (const double *)m->d_DJd, (const double *)m->d_Jdt, cur, cgt, cu, theta, out, adjoint);
+        if (m->n == 8) CVS(8, 4) else if (m->n == 9) CVS(9, 6) else CVS(10, 7)
+#undef CVS
+        NLG_HIP(hipGetLastError());
+        return 0;
+    }
     double *uf[3] = {sem_scratchd(m, 0), sem_scratchd(m, 1), dim == 3 ? sem_scratchd(m, 2) : nullptr};
     double *dt[3] = {sem_scratchd(m, 3), sem_scratchd(m, 4), dim == 3 ? sem_scratchd(m, 5) : nullptr};
     double *acc = sem_scratchd(m, 6);

@@ -13,7 +13,7 @@ from oracle.vectors import NekDVector
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dim,n", [(2, 6), (3, 6), (3, 8)])   # lx1 = 8: the kernel instantiations of the benchmark, with the scalar
+@pytest.mark.parametrize("dim,n", [(2, 6), (3, 6), (3, 8), (3, 9), (3, 10)])   # lx1 = 8 ... 10: the fused scalar-transport kernel k_conv3s_scalar (lx1 = 6, 2-D: generic path)
 def test_boussinesq_matvec_matches_oracle(gpu_ctx, dim, n):
     if dim == 2:
         hm = box_mesh((3, 2), n, lengths=(2.0, 1.0), periodic=(True, False), deform=0.03)
