@@ -2929,9 +2929,11 @@ int sem_gs(nlg_mesh *m, double *const *fields, int nf, const double *gate, int l
         set_error("sem_gs: nf=%d unsupported", nf);
         return 1;
     }
-    if (m->halo.active && m->gs.split) {
-        // several ranks: first the groups that hold a dof another rank shares, so that their sums can be packed and sent,
-        // then all other groups (disjoint dofs) while the exchange is under way, then the received sums (halo.hip)
+    if (m->halo.active && m->gs.split && m->halo.overlap) {
+        // several ranks, NLG_HALO_OVERLAP=1: first the groups that hold a dof another rank shares, so that their sums can be packed and sent,
+        // then all other groups (disjoint dofs) while the exchange is under way on the side stream, then the received sums (halo.hip).
+        // Without the overlap the exchange is in-stream and the split buys nothing: one pass over all groups, then pack / exchange /
+        // unpack (one launch less per gather-scatter; the sums are the same)
         const nlg_gs_tab &th = m->gs.tab_halo[layout], &tr = m->gs.tab_rest[layout];
         NLG_TRY(gs_launch(m, th.d_off, th.d_idx, th.ngroups, th.npairs, th.nquads, fields, nf, gate, nl, ld, ldg));
         NLG_TRY(halo_begin(m, fields, nf, layout, nl, ld));
