@@ -3668,10 +3668,10 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
                 break;
             case 9: CV3D(9, 256, true); break;
             case 10:
-                if (sweep == 2) CV3S(10, 5, 4) else if (sweep) CV3S(10, 5, 2) else CV3D(10, 256, false);   // (u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU)
+                if (sweep) CV3S(10, 5, 2) else CV3D(10, 256, false);   // (u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU)
                 break;
             default:
-                if (sweep == 2) CV3S(12, 7, 4) else if (sweep) CV3S(12, 7, 1) else CV3D(12, 384, false);
+                if (sweep) CV3S(12, 7, 1) else CV3D(12, 384, false);
                 break;
         }
 #undef CV3
