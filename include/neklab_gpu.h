@@ -140,6 +140,10 @@ int nlg_vec_destroy(nlg_vec *v);
 int nlg_vec_generation(const nlg_vec *v, int64_t *gen);
 int nlg_vec_release(nlg_vec *v);
 int nlg_vec_adopt(nlg_vec *v, int64_t gen, int *status);
+/* A copy that only READS (an intent(in) use cannot take ownership) pins a released handle: it leaves the eviction pool and stays
+ * adoptable; the finaliser of a non-owning copy un-pins (back into the pool).  Both validate `gen` like nlg_vec_adopt. */
+int nlg_vec_pin(nlg_vec *v, int64_t gen);
+int nlg_vec_unpin(nlg_vec *v, int64_t gen);
 int nlg_vec_pool_limit(int64_t bytes);
 int nlg_vec_pool_trim(int64_t *freed_bytes);
 /* Fortran intrinsic assignment / sourced allocation of a nek_dvector */
@@ -170,6 +174,10 @@ int nlg_vec_size(const nlg_vec *self, int64_t *out);
 int64_t nlg_vec_size_value(const nlg_vec *self);
 /* dhas_rst_fields as a plain function value for the same reason: the reference declares it `pure` (neklab_vectors.f90:107-110) */
 int nlg_vec_has_rst_value(const nlg_vec *self);
+/* the two plain-value forms for handles that may be stale (the Fortran shim's bitwise copies): -1 when the handle is unknown or
+ * its generation is not `gen`; they never dereference a freed handle */
+int64_t nlg_vec_size_checked(const nlg_vec *self, int64_t gen);
+int nlg_vec_has_rst_checked(const nlg_vec *self, int64_t gen);
 /* outpost_dnek  src/neklab_utils.f90:305-333 (Nek5000 `outpost(vx, vy, vz, pr, t, prefix)`): one vector -> one Nek5000
  * field file at `path` ("#std" header, fp64): GLL coordinates when with_coords != 0 (Nek5000 writes them into the first
  * file of a series only), velocity, the pressure mapped to the velocity mesh (Nek5000's `mappr` for a Pn-Pn-2 run), the
@@ -216,10 +224,12 @@ int nlg_basis_cgs2(const nlg_basis *b, int k, nlg_vec *w, double *h, double *bet
  * (both passes summed), rows k .. k+s-1 the upper-triangular factor R with  W_old = V(:,0:k) coef(0:k,:) + W_new R.
  * Restart history and pressure follow as in axpby / scal (consistent history update only). */
 int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef);
-/* Number of columns the last nlg_basis_block_cgs2 on this basis kept.  A column of the block that is numerically dependent on
- * the basis and the columns before it (squared norm reduced below 1e-14 of what it entered the block factorisation with: the block
- * Krylov space has reached an invariant subspace, or the block was badly conditioned) is deflated, not an error: its coefficients
- * are returned as for any column with a zero diagonal entry in R, and the column becomes the zero vector. */
+/* Number of columns the last nlg_basis_block_cgs2 on this basis kept.  A column is deflated -- not an error: its coefficients are
+ * returned as for any column with a zero diagonal entry in R, and the column becomes the zero vector -- when (1) what the two
+ * projections left of it is below 1e-12 of the norm it came with (|w|^2 = |w - V h|^2 + |h|^2: the column lies in span(V) to
+ * rounding; the block Krylov space has reached an invariant subspace), or (2) its Cholesky pivot among the columns of the block falls
+ * below 1e-14 of its squared norm at entry to the current round of the twofold CholQR (dependent on the columns before it).  The
+ * tests are scale-free: columns of any norm may be passed. */
 int nlg_basis_last_block_rank(const nlg_basis *b, int *rank);
 /* out = sum_j c[j] V(:,j)  over ALL fields (eigenvector reconstruction, LightKrylov eigs tail) */
 int nlg_basis_combine(const nlg_basis *b, int k, const double *c, nlg_vec *out);

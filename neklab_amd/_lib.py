@@ -73,6 +73,10 @@ SIGNATURES = {
     "nlg_vec_generation": (C.c_int, [vp, c_int64_p]),
     "nlg_vec_release": (C.c_int, [vp]),
     "nlg_vec_adopt": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int)]),
+    "nlg_vec_pin": (C.c_int, [vp, C.c_int64]),
+    "nlg_vec_unpin": (C.c_int, [vp, C.c_int64]),
+    "nlg_vec_size_checked": (C.c_int64, [vp, C.c_int64]),
+    "nlg_vec_has_rst_checked": (C.c_int, [vp, C.c_int64]),
     "nlg_vec_pool_limit": (C.c_int, [C.c_int64]),
     "nlg_vec_pool_trim": (C.c_int, [c_int64_p]),
     "nlg_mesh_create": (C.c_int, [vp, C.POINTER(MeshDesc), C.POINTER(vp)]),

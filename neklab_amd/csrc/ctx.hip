@@ -64,7 +64,7 @@ int reduce_ws_reserve(nlg_ctx *ctx, int nvec) {
 }
 
 static const char *kProfNames[P_COUNT] = {"axhelm", "gs", "opgradt", "opdiv", "colmul", "block_dot", "block_axpy",
-                                          "cg_vec", "conv", "vec_ops", "pprec", "axpy_dot"};
+                                          "cg_vec", "conv", "vec_ops", "pprec", "axpy_dot", "cg_update"};
 
 void prof_begin(nlg_ctx *ctx, int id) {
     nlg_prof_slot &s = ctx->prof[id];

@@ -65,7 +65,7 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 }  // namespace nlg
 
 // kernel classes that can be timed with HIP events on the launch stream (bench.py roofline leg)
-enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_PPREC, P_AXPYDOT, P_COUNT };
+enum { P_AXHELM = 0, P_GS, P_OPGRADT, P_OPDIV, P_COLMUL, P_BLOCKDOT, P_BLOCKAXPY, P_CGVEC, P_CONV, P_VECOPS, P_PPREC, P_AXPYDOT, P_CGUPDATE, P_COUNT };
 
 struct nlg_prof_slot {
     std::vector<hipEvent_t> ev;   // pairs (begin, end)
@@ -423,6 +423,7 @@ struct nlg_pupd {
     double *p = nullptr;
 };
 bool sem_opgradt_fuses_pupdate(const nlg_mesh *m);
+bool sem_small_mesh(const nlg_mesh *m);   // local element count below the threshold of the strong-scaling kernel variants (NLG_SMALL_E)
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part = nullptr, const double *gate = nullptr, const nlg_pupd *upd = nullptr);
 int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const *out, double *const *pw_part, const double *const *gate,
                       const nlg_pupd *upd = nullptr);

@@ -995,9 +995,11 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         if (!P.pw_part)
             launch_nf(nf, k_cg_pw<1>, k_cg_pw<2>, k_cg_pw<3>, lgrid(g, nl), st, (const double *)s, P.n, cp, cw, P.ipw, partial, ld);
         NLG_TRY(reduce_post(rd_pw, 2, 1, 1));
-        if (!P.rr_part)
+        if (!P.rr_part) {
+            ProfScope pu(ctx, P_CGUPDATE);   // the largest single kernel of a step by time: its own class inside cg_vec (bench.py quotes its roofline)
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, lgrid(g, nl), st, (const double *)s, P.n, x, r, z, cp, cw,
                       pc, P.ipw, P.nw, partial, ld);
+        }
         if (prof_cg) prof_end(ctx, P_CGVEC);
         if (P.precond) {
             NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
@@ -1137,27 +1139,32 @@ int helm_solve(const Lanes &L, int order, double h2) {
 // One scalar (temperature) step of the Boussinesq coupling, see oracle/lns.py advance (ifheat branch):
 //   rhocp (b0 theta^{n+1} - sum bd_j theta^{n-j}) / dt = -rhocp EXT[(U.grad) theta + (u.grad) Theta] + conductivity lap theta^{n+1}
 // in residual form, Jacobi-PCG; the new level ends in tbuf[0].
-int heat_step(nlg_linop *op, int k, double b0) {
+int heat_step(const Lanes &L, int k, double b0) {
+    nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     hipStream_t st = m->ctx->stream;
     const auto &c = op->cfg;
+    const int nl = L.nl;
+    const int64_t ld = L.ld();
     const double dt = op->dt, rc = c.rhocp;
-    // explicit term into the oldest buffer, then rotate
+    // explicit term into the oldest buffer, then rotate.  The transport term is one launch per lane (base-flow data shared); everything
+    // after it -- right-hand side, operator, gather-scatter, the whole PCG -- is ONE launch for all lanes (gridDim.y), as in the velocity solve
     const int adj = (op->adjoint && !op->nonlinear) ? 1 : 0;
-    NLG_TRY(sem_conv_scalar_apply(m, op->Ur, op->GT, op->ubuf[0], op->tbuf[0], op->ftbuf[2], adj));
-    if (adj) {
-        // adjoint temperature equation: rhocp theta+_t = rhocp (U.grad) theta+ + conductivity lap theta+ + rhocp b . u+
-        // (stored term N_t = -conv(U, theta+) - bm1 b . u+ ; oracle/lns.py advance, adjoint branch)
-        for (int i = 0; i < m->dim; ++i)
-            if (c.buoy[i] != 0.0)
-                NLG_LAUNCH(k_mul3_acc, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->ftbuf[2], (const double *)m->d_bm1,
-                                   (const double *)op->ubuf[0][i], -c.buoy[i]);
-    }
-    {
-        double *t = op->ftbuf[2];
-        op->ftbuf[2] = op->ftbuf[1];
-        op->ftbuf[1] = op->ftbuf[0];
-        op->ftbuf[0] = t;
+    for (int v = 0; v < nl; ++v) {
+        nlg_linop *ln = L.ops[v];
+        NLG_TRY(sem_conv_scalar_apply(m, op->Ur, op->GT, ln->ubuf[0], ln->tbuf[0], ln->ftbuf[2], adj));
+        if (adj) {
+            // adjoint temperature equation: rhocp theta+_t = rhocp (U.grad) theta+ + conductivity lap theta+ + rhocp b . u+
+            // (stored term N_t = -conv(U, theta+) - bm1 b . u+ ; oracle/lns.py advance, adjoint branch)
+            for (int i = 0; i < m->dim; ++i)
+                if (c.buoy[i] != 0.0)
+                    NLG_LAUNCH(k_mul3_acc, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, ln->ftbuf[2], (const double *)m->d_bm1,
+                                       (const double *)ln->ubuf[0][i], -c.buoy[i]);
+        }
+        double *t = ln->ftbuf[2];
+        ln->ftbuf[2] = ln->ftbuf[1];
+        ln->ftbuf[1] = ln->ftbuf[0];
+        ln->ftbuf[0] = t;
     }
     Hist h;
     h.k = k;
@@ -1170,18 +1177,18 @@ int heat_step(nlg_linop *op, int k, double b0) {
         }
     }
     F3 rhs = {{op->trhs, nullptr, nullptr}};
-    NLG_LAUNCH(k_rhs<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, h, (const double *)m->d_bm1, rc / dt, rhs, (int64_t)0);
+    NLG_LAUNCH(k_rhs<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, m->lvn, h, (const double *)m->d_bm1, rc / dt, rhs, ld);
     const double h1 = c.conductivity, h2 = rc * b0 / dt;
     double *tin[1] = {op->tbuf[0]}, *tw[1] = {op->tw}, *trhs[1] = {op->trhs};
-    NLG_TRY(sem_axhelm(m, tin, tw, 1, h1, h2));
+    NLG_TRY(sem_axhelm(m, tin, tw, 1, h1, h2, nullptr, nullptr, nullptr, nullptr, false, nl, ld));
     {
         CF3 a = {{op->trhs, nullptr, nullptr}}, b = {{op->tw, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
-        NLG_LAUNCH(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, rhs, a, b, -1.0, none, 0.0, (int64_t)0);
+        NLG_LAUNCH(k_lin3<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, m->lvn, rhs, a, b, -1.0, none, 0.0, ld);
     }
-    NLG_TRY(sem_gs(m, trhs, 1));
+    NLG_TRY(sem_gs(m, trhs, 1, nullptr, LAYOUT_NAT, nl, ld, 0));
     {
         CF3 mk = {{m->d_tmask, nullptr, nullptr}};
-        NLG_LAUNCH(k_colmul_gated<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, (const double *)nullptr, rhs, mk, m->lvn, (int64_t)0);
+        NLG_LAUNCH(k_colmul_gated<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, (const double *)nullptr, rhs, mk, m->lvn, ld);
     }
     // Jacobi-PCG, one field; the operator kernel sums (p, w) and updates p itself
     double *x[1] = {op->tx}, *z[1] = {op->tz}, *p[1] = {op->tpv}, *pc[1] = {op->pct[k]};
@@ -1201,29 +1208,37 @@ int heat_step(nlg_linop *op, int k, double b0) {
     P.maxit = c.fixed_iters_v > 0 ? c.fixed_iters_v : c.maxit_v;
     P.s = op->d_s;
     P.inv_n = 0.0;
-    P.chunk = std::max(2, std::min(op->last_titers, 64));
+    P.nl = nl;
+    P.ld = ld;
+    P.chunk = 2;
+    for (int v = 0; v < nl; ++v) P.chunk = std::max(P.chunk, std::min(L.ops[v]->last_titers, 64));
     P.pw_part = op->d_part;
     P.pw_n = sem_axhelm_blocks(m, 1);
     P.pw_sum = false;
     P.fused_pupdate = true;
     auto apply = [&](double *) -> int {
-        NLG_TRY(sem_axhelm(m, p, tw, 1, h1, h2, op->d_part, z, op->d_s + S_BETA, op->d_s + S_DONE));
-        NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE));
+        NLG_TRY(sem_axhelm(m, p, tw, 1, h1, h2, op->d_part, z, op->d_s + S_BETA, op->d_s + S_DONE, false, nl, ld));
+        NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE, LAYOUT_NAT, nl, ld, ld));
         return 0;
     };
     int iters[kMaxLanes] = {};
     NLG_TRY(run_pcg(op, P, apply, iters));
-    op->st_titers += iters[0];
-    op->last_titers = iters[0];
+    for (int v = 0; v < nl; ++v) {
+        L.ops[v]->st_titers += iters[v];
+        L.ops[v]->last_titers = iters[v];
+    }
     // theta^{n+1} = theta^n + x into the oldest level, then rotate: new -> current
     {
         F3 y = {{op->tbuf[2], nullptr, nullptr}};
         CF3 a = {{op->tbuf[0], nullptr, nullptr}}, b = {{op->tx, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
-        NLG_LAUNCH(k_lin3<1>, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0, (int64_t)0);
-        double *t = op->tbuf[2];
-        op->tbuf[2] = op->tbuf[1];
-        op->tbuf[1] = op->tbuf[0];
-        op->tbuf[0] = t;
+        NLG_LAUNCH(k_lin3<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0, ld);
+        for (int v = 0; v < nl; ++v) {
+            nlg_linop *ln = L.ops[v];
+            double *t = ln->tbuf[2];
+            ln->tbuf[2] = ln->tbuf[1];
+            ln->tbuf[1] = ln->tbuf[0];
+            ln->tbuf[0] = t;
+        }
     }
     NLG_HIP(hipGetLastError());
     return 0;
@@ -1451,7 +1466,7 @@ int adv_a(const Lanes &L) {
         NLG_TRY(sem_conv_setup(m, op->ubuf[0], op->Ur, op->GU));
         if (op->cfg.ifheat) NLG_TRY(sem_conv_scalar_setup(m, op->tbuf[0], op->GT));
     }
-    if (op->cfg.ifheat) NLG_TRY(heat_step(op, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
+    if (op->cfg.ifheat) NLG_TRY(heat_step(L, k, b0));   // scalar first: the fluid sees the new temperature (Nek5000's order)
     // F = -N(u): written into the oldest forcing buffer, then the buffers rotate
     double **Fnew = op->fbuf[2];
     if (nl == 1) {
@@ -1462,12 +1477,13 @@ int adv_a(const Lanes &L) {
         NLG_TRY(sem_conv_apply_lanes(m, op->Ur, op->GU, nl, ul, ol, op->adjoint));
     }
     if (op->cfg.ifheat && op->adjoint && !op->nonlinear) {
-        // adjoint momentum equation: - theta+ grad Theta with the new theta+ (stored F is +N: add the weak term)
-        NLG_TRY(sem_scalar_grad_apply(m, op->GT, op->tbuf[0], Fnew, 1.0));
+        // adjoint momentum equation: - theta+ grad Theta with the new theta+ (stored F is +N: add the weak term); lane by lane
+        for (int v = 0; v < nl; ++v) NLG_TRY(sem_scalar_grad_apply(m, op->GT, L.ops[v]->tbuf[0], L.ops[v]->fbuf[2], 1.0));
     } else if (op->cfg.ifheat) {
         const double bs = op->nonlinear ? 2.0 : 1.0;   // the nonlinear step halves the whole stored term (F holds 2 N there)
-        launch_nf(dim, k_buoyancy<1>, k_buoyancy<2>, k_buoyancy<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(Fnew, dim),
-                  (const double *)m->d_bm1, (const double *)op->tbuf[0], bs * op->cfg.buoy[0], bs * op->cfg.buoy[1], bs * op->cfg.buoy[2]);
+        for (int v = 0; v < nl; ++v)
+            launch_nf(dim, k_buoyancy<1>, k_buoyancy<2>, k_buoyancy<3>, dim3(grid_for(m->lvn)), st, m->lvn, f3(L.ops[v]->fbuf[2], dim),
+                      (const double *)m->d_bm1, (const double *)L.ops[v]->tbuf[0], bs * op->cfg.buoy[0], bs * op->cfg.buoy[1], bs * op->cfg.buoy[2]);
     }
     if (op->force_re) {
         // forcing of this step: evaluated at the time level the step starts from, (istep - 1) dt, like the explicit terms
@@ -2218,6 +2234,8 @@ int lane_refresh(nlg_linop *op0, nlg_linop *ln) {
         for (int k = 0; k < 4; ++k) ln->pcv[k][c] = op0->pcv[k][c], ln->pcv_xp[k][c] = op0->pcv_xp[k][c];
     }
     for (int q = 0; q < 9; ++q) ln->GU[q] = op0->GU[q];
+    for (int q = 0; q < 3; ++q) ln->GT[q] = op0->GT[q];          // Boussinesq coupling: base-temperature gradient and the scalar's
+    for (int k = 0; k < 4; ++k) ln->pct[k] = op0->pct[k];        // Jacobi preconditioners are the owner's
     ln->pce = op0->pce, ln->nwv = op0->nwv, ln->nwv_xp = op0->nwv_xp, ln->nwp = op0->nwp;
     ln->use_xp = op0->use_xp;
     ln->h_s = nullptr;   // the PCG reads every lane's scalars through the owner's pinned buffer
@@ -2230,11 +2248,12 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
     NLG_CHECK(op->inited, "exptA block matvec: nlg_linop_init has not been called");
     NLG_CHECK(!op->is_lane, "exptA block matvec: called on a lane");
     nlg_mesh *m = op->mesh;
-    NLG_CHECK(!op->cfg.ifheat && op->proj_nlines == 0,
-              "exptA block matvec: the Boussinesq coupling and the wavenumber projection run through the single-vector path");
+    NLG_CHECK(op->proj_nlines == 0, "exptA block matvec: the wavenumber projection runs through the single-vector path");
+    const int want_scal = op->cfg.ifheat ? 1 : 0;
     for (int v = 0; v < s; ++v) {
         NLG_CHECK(vin[v] && vout[v] && vin[v]->mesh == m && vout[v]->mesh == m, "exptA block matvec: vector %d NULL or on a different mesh", v);
-        NLG_CHECK(vin[v]->nscal == 0 && vout[v]->nscal == 0, "exptA block matvec: vector %d carries scalars", v);
+        NLG_CHECK(vin[v]->nscal == want_scal && vout[v]->nscal == want_scal, "exptA block matvec: vector %d carries %d scalars, the operator %d", v,
+                  vin[v]->nscal, want_scal);
         NLG_CHECK(op->cfg.no_history || (vin[v]->lorder >= op->cfg.torder && vout[v]->lorder >= op->cfg.torder), "exptA block matvec: vector lorder < time order");
         for (int u = 0; u < s; ++u) NLG_CHECK(vin[v] != vout[u], "exptA block matvec: an input vector is also an output vector");
         for (int u = 0; u < v; ++u) NLG_CHECK(vout[v] != vout[u], "exptA block matvec: the same output vector twice");
@@ -2275,8 +2294,8 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
     }
     // the lanes' counters are part of the operator's statistics
     for (int v = 1; v < s; ++v) {
-        op->st_steps += ops[v]->st_steps, op->st_viters += ops[v]->st_viters, op->st_piters += ops[v]->st_piters;
-        ops[v]->st_steps = ops[v]->st_viters = ops[v]->st_piters = 0;
+        op->st_steps += ops[v]->st_steps, op->st_viters += ops[v]->st_viters, op->st_piters += ops[v]->st_piters, op->st_titers += ops[v]->st_titers;
+        ops[v]->st_steps = ops[v]->st_viters = ops[v]->st_piters = ops[v]->st_titers = 0;
     }
     op->st_matvecs += s;
     return 0;
@@ -2285,7 +2304,7 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
 }  // namespace
 
 namespace nlg {
-bool linop_can_block(const nlg_linop *op) { return op && !op->cfg.ifheat && op->proj_nlines == 0 && !op->is_lane; }
+bool linop_can_block(const nlg_linop *op) { return op && op->proj_nlines == 0 && !op->is_lane; }
 }
 
 extern "C" {

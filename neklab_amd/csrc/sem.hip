@@ -382,7 +382,71 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
 #pragma unroll
         for (int c = 0; c < NF; ++c) f.p[c] += lo;
     }
-    const int64_t t = blockIdx.x * (int64_t)NT + threadIdx.x;
+    // Thread order: the general groups FIRST (corners and irregular valences: the longest chain of dependent loads in the kernel --
+    // offsets, indices, values), then the quads, then the pairs.  At the end of the grid, where they used to be, their chain was the
+    // kernel's tail: 17 us of a 50-us launch at 10^4 elements and the whole of a launch at 1300 (profiles/r04_E1300_counters.txt).
+    int64_t t = blockIdx.x * (int64_t)NT + threadIdx.x;
+    const int64_t nrest = ngroups - npairs - nquads;
+    if (t < nrest) {
+        // indices of up to eight copies at once, then all their values, then the sum in ascending order of the local index (the order
+        // of the one-at-a-time loop this replaces: same bits).  Eight covers a corner of a structured mesh; longer groups take
+        // another round.  One at a time, every copy cost two serialised round trips (index, value).
+        const int64_t g = npairs + nquads + t;
+        const int b = off[g], e = off[g + 1];
+        constexpr int CH = 8;
+        int i0[CH];
+        double s[NF];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) s[c] = 0.0;
+        for (int q0 = b; q0 < e; q0 += CH) {
+            int ii[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) ii[u] = q0 + u < e ? idx[q0 + u] : -1;
+            double v[CH][NF];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int c = 0; c < NF; ++c) v[u][c] = ii[u] >= 0 ? f.p[c][ii[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int c = 0; c < NF; ++c) s[c] += v[u][c];   // s is never -0.0 here, so adding the +0.0 of an unused slot changes nothing
+            if (q0 == b) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) i0[u] = ii[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (i0[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < NF; ++c) f.p[c][i0[u]] = s[c];
+            }
+        for (int q = b + CH; q < e; ++q) {
+            const int i = idx[q];
+#pragma unroll
+            for (int c = 0; c < NF; ++c) f.p[c][i] = s[c];
+        }
+        return;
+    }
+    t -= nrest;
+    if (t < nquads) {
+        // 2 * npairs is even, so the quad block starts 8-byte aligned; read it as two int2
+        const int2 *q2 = reinterpret_cast<const int2 *>(idx + 2 * npairs) + 2 * t;
+        const int2 ab = q2[0], cd = q2[1];
+        double s[NF];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) s[c] = ((f.p[c][ab.x] + f.p[c][ab.y]) + f.p[c][cd.x]) + f.p[c][cd.y];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            f.p[c][ab.x] = s[c];
+            f.p[c][ab.y] = s[c];
+            f.p[c][cd.x] = s[c];
+            f.p[c][cd.y] = s[c];
+        }
+        return;
+    }
+    t -= nquads;
     const int64_t np2 = npairs >> 1;
     if (t < np2) {
         const int4 q = reinterpret_cast<const int4 *>(idx)[t];
@@ -420,10 +484,8 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
         }
         return;
     }
-    const int64_t g = 2 * np2 + (t - np2);   // the odd pair (if any), then quads, then the rest: one group per thread
-    if (g >= ngroups) return;
-    if (g < npairs) {
-        const int2 ab = reinterpret_cast<const int2 *>(idx)[g];
+    if (t == np2 && (npairs & 1)) {   // the odd pair
+        const int2 ab = reinterpret_cast<const int2 *>(idx)[npairs - 1];
         double s[NF];
 #pragma unroll
         for (int c = 0; c < NF; ++c) s[c] = f.p[c][ab.x] + f.p[c][ab.y];
@@ -432,37 +494,6 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
             f.p[c][ab.x] = s[c];
             f.p[c][ab.y] = s[c];
         }
-        return;
-    }
-    if (g < npairs + nquads) {
-        // 2 * npairs is even, so the quad block starts 8-byte aligned; read it as two int2
-        const int2 *q2 = reinterpret_cast<const int2 *>(idx + 2 * npairs) + 2 * (g - npairs);
-        const int2 ab = q2[0], cd = q2[1];
-        double s[NF];
-#pragma unroll
-        for (int c = 0; c < NF; ++c) s[c] = ((f.p[c][ab.x] + f.p[c][ab.y]) + f.p[c][cd.x]) + f.p[c][cd.y];
-#pragma unroll
-        for (int c = 0; c < NF; ++c) {
-            f.p[c][ab.x] = s[c];
-            f.p[c][ab.y] = s[c];
-            f.p[c][cd.x] = s[c];
-            f.p[c][cd.y] = s[c];
-        }
-        return;
-    }
-    const int b = off[g], e = off[g + 1];
-    double s[NF];
-#pragma unroll
-    for (int c = 0; c < NF; ++c) s[c] = 0.0;
-    for (int q = b; q < e; ++q) {
-        const int i = idx[q];
-#pragma unroll
-        for (int c = 0; c < NF; ++c) s[c] += f.p[c][i];
-    }
-    for (int q = b; q < e; ++q) {
-        const int i = idx[q];
-#pragma unroll
-        for (int c = 0; c < NF; ++c) f.p[c][i] = s[c];
     }
 }
 
@@ -1719,6 +1750,233 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
     }
 }
 
+// ---- small-mesh variants (strong-scaling regime: config 3 on 8 GPUs is 1300 elements per GPU = 1.3 one-wave blocks per SIMD) ----
+// k_opgradt3n / k_opdiv3n send ONE wave per element through the three velocity components one after the other: nine dependent
+// LDS stages and three rounds of metric loads per element, and with one or two waves per SIMD nothing hides them (16.5 us per launch
+// at 1300 elements for 38 - 54 MB, profiles/r04_E1300_counters.txt).  Here a block is THREE waves, wave c owns component c (its own
+// LDS array): the chain is a third as long.  opgradt: every wave loads (and, with the fused direction update, forms) the same
+// pressure column -- the element's 216 values come from L2 twice more, wave 0 alone writes the updated direction back.  opdiv: the
+// three partial sums of a pressure point meet in LDS and are added in the fixed order (c = 0, 1, 2) by wave 0, which also writes the
+// result and the element's contribution to (p, E p).  Single-vector launches only; selected by the local element count
+// (sem_small_mesh; NLG_SMALL_E).  lx1 <= 8 (one wave per stage).
+template <int N, bool FG, bool PU>
+__global__ __launch_bounds__(192) void k_opgradt3w(int64_t E, const double *__restrict__ mIt, const double *__restrict__ mDt, const int *__restrict__ fgtab, CF9 g,
+                                                   const double *__restrict__ p, F3 w, const double *__restrict__ gate, std::conditional_t<PU, PUpd, NoPUpd> pu) {
+    constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
+    constexpr int RS = PBlockN<N>::RS;
+    static_assert(N * N <= 64 && 2 * N <= 3 * N2, "one wave per stage; in-place y stage needs 2 N <= 3 N2");
+    __shared__ double sRR[3][N2 * N * RS];
+    if (gate && gate[0] != 0.0) return;
+    const int tid = threadIdx.x & 63, i = threadIdx.x >> 6;   // i = component of this wave
+    double *sR = sRR[i];
+    const int64_t e = blockIdx.x;
+    const double *pe = p + e * NP2;
+    double pv[N2];
+    double gq[3][N2];
+    if (tid < NS2) {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) pv[k2] = pe[tid + NS2 * k2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) gq[j][k2] = g.p[j * 3 + i][e * NP2 + tid + NS2 * k2];
+        if constexpr (PU) if (pu.z[0]) {
+            const double beta = pu.beta[0][0], zmean = pu.zmean[0][0];
+            const double *ze = pu.z[0] + e * NP2;
+            double *po = pu.p[0] + e * NP2;
+            double zv[N2];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) zv[k2] = ze[tid + NS2 * k2];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) pv[k2] = (zv[k2] - zmean) + beta * pv[k2];
+            if (i == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) po[tid + NS2 * k2] = pv[k2];
+            }
+        }
+        const int i2 = tid % N2, j2 = tid / N2;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double q[N2];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) q[k2] = gq[j][k2] * pv[k2];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                double a = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < N2; ++k2) a += (j < 2 ? mIt[k * N2 + k2] : mDt[k * N2 + k2]) * q[k2];
+                sR[(i2 + N2 * k) * RS + j * N2 + j2] = a;
+            }
+        }
+    }
+    lds_barrier();
+    if (tid < N2 * N) {
+        double *r = sR + tid * RS;
+        double a0[N2], a1[N2], a2[N2];
+#pragma unroll
+        for (int j2 = 0; j2 < N2; ++j2) {
+            a0[j2] = r[j2];
+            a1[j2] = r[N2 + j2];
+            a2[j2] = r[2 * N2 + j2];
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int j2 = 0; j2 < N2; ++j2) {
+                b0 += mIt[j * N2 + j2] * a0[j2];
+                b1 += mDt[j * N2 + j2] * a1[j2] + mIt[j * N2 + j2] * a2[j2];
+            }
+            r[j] = b0;
+            r[N + j] = b1;
+        }
+    }
+    lds_barrier();
+    if (tid < N * N) {
+        const int jj = tid % N, kk = tid / N;
+        double b0[N2], b1[N2];
+#pragma unroll
+        for (int i2 = 0; i2 < N2; ++i2) {
+            b0[i2] = sR[(i2 + N2 * kk) * RS + jj];
+            b1[i2] = sR[(i2 + N2 * kk) * RS + N + jj];
+        }
+        double *wp = w.p[i] + e * NP1;
+        int sl[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) sl[a] = FG ? fgtab[a + N * tid] : a + N * tid;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double v = 0.0;
+#pragma unroll
+            for (int i2 = 0; i2 < N2; ++i2) v += mDt[a * N2 + i2] * b0[i2] + mIt[a * N2 + i2] * b1[i2];
+            wp[sl[a]] = v;
+        }
+    }
+}
+
+template <int N, bool FG>
+__global__ __launch_bounds__(192) void k_opdiv3w(int64_t E, const double *__restrict__ mIm, const double *__restrict__ mDm, const int *__restrict__ fgtab, CF9 g, CF3 u, CF3 wt,
+                                                 double *__restrict__ out, double scale, const double *__restrict__ pdot, double *__restrict__ part, const double *__restrict__ gate) {
+    constexpr int N2 = N - 2, NS2 = N2 * N2, NP2 = NS2 * N2, NP1 = N * N * N;
+    constexpr int RS = PBlockN<N>::RS;
+    static_assert(N * N <= 64, "one wave per stage");
+    __shared__ double sRR[3][N2 * N * RS];
+    __shared__ double sAcc[2][N2][64];
+    if (gate && gate[0] != 0.0) return;
+    const int tid = threadIdx.x & 63, i = threadIdx.x >> 6;
+    double *sR = sRR[i];
+    const int64_t e = blockIdx.x;
+    double acc[N2];
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) acc[k2] = 0.0;
+    double gq[3][N2];
+    if (tid < NS2) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) gq[j][k2] = g.p[j * 3 + i][e * NP2 + tid + NS2 * k2];
+    }
+    double pd[N2];   // wave 0: the pressure direction for (p, E p), requested with everything else
+    if (i == 0 && tid < NS2) {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) pd[k2] = part ? pdot[e * NP2 + tid + NS2 * k2] : 0.0;
+    }
+    if (tid < N * N) {
+        const int jj = tid % N, kk = tid / N;
+        const double *up = u.p[i] + e * NP1;
+        const double *wp = wt.p[i];
+        int sl[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) sl[a] = FG ? fgtab[a + N * tid] : a + N * tid;
+        double uu[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) uu[a] = up[sl[a]];
+        if (wp) {
+            wp += e * NP1;
+#pragma unroll
+            for (int a = 0; a < N; ++a) uu[a] *= wp[sl[a]];
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < N2; ++i2) {
+            double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                b0 += mDm[i2 * N + a] * uu[a];
+                b1 += mIm[i2 * N + a] * uu[a];
+            }
+            sR[(i2 + N2 * kk) * RS + jj] = b0;
+            sR[(i2 + N2 * kk) * RS + N + jj] = b1;
+        }
+    }
+    lds_barrier();
+    if (tid < N2 * N) {
+        double *r = sR + tid * RS;
+        double b0[N], b1[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            b0[j] = r[j];
+            b1[j] = r[N + j];
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < N2; ++j2) {
+            double c0v = 0.0, c1v = 0.0, c2v = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                c0v += mIm[j2 * N + j] * b0[j];
+                c1v += mDm[j2 * N + j] * b1[j];
+                c2v += mIm[j2 * N + j] * b1[j];
+            }
+            r[j2] = c0v;
+            r[N2 + j2] = c1v;
+            r[2 * N2 + j2] = c2v;
+        }
+    }
+    lds_barrier();
+    if (tid < NS2) {
+        const int i2 = tid % N2, j2 = tid / N2;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double cc[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) cc[k] = sR[(i2 + N2 * k) * RS + j * N2 + j2];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) a += (j < 2 ? mIm[k2 * N + k] : mDm[k2 * N + k]) * cc[k];
+                acc[k2] += gq[j][k2] * a;
+            }
+        }
+        if (i > 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) sAcc[i - 1][k2][tid] = acc[k2];
+        }
+    }
+    lds_barrier();
+    if (i != 0) return;
+    double spw = 0.0, sw = 0.0;
+    if (tid < NS2) {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+            const double v = scale * ((acc[k2] + sAcc[0][k2][tid]) + sAcc[1][k2][tid]);
+            out[e * NP2 + tid + NS2 * k2] = v;
+            spw += pd[k2] * v;
+            sw += v;
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            spw += __shfl_down(spw, o, 64);
+            sw += __shfl_down(sw, o, 64);
+        }
+        if (tid == 0) {
+            part[e] = spw;
+            part[E + e] = sw;
+        }
+    }
+}
+
 // ---- 2-D versions (several elements per block would be faster; correctness first) -------------------
 template <int N>
 __global__ __launch_bounds__(NT) void k_opgradt2(int64_t E, const double *__restrict__ Itg,
@@ -2003,6 +2261,15 @@ __global__ __launch_bounds__(NTC, (DYN && N > 10) ? 1 : 2) void k_conv3(int64_t 
     const double sgn = adjoint ? -1.0 : 1.0;
 #pragma unroll 1
     for (int ic = 0; ic < 3; ++ic) {
+        // (round 4: requesting the base-flow values of the first fine levels HERE, two LDS stages ahead, and every later batch before
+        //  the previous one is consumed -- with LDS-only barriers -- was built and measured: 2.93 -> 3.01 ms per step at 10^4 elements.
+        //  The kernel sits at the 256-register cap already (36 bytes of scratch); the second batch of 18 values spills (60 - 84 bytes)
+        //  and the spill traffic costs more than the exposed latency did.  DESIGN.md section 5.)
+        constexpr int CB = ND % 4 == 0 ? 4 : (ND % 5 == 0 ? 5 : (ND % 3 == 0 ? 3 : 1));
+        const double *g0 = adjoint ? GU.p[0 * 3 + ic] : GU.p[ic * 3 + 0];
+        const double *g1 = adjoint ? GU.p[1 * 3 + ic] : GU.p[ic * 3 + 1];
+        const double *g2 = adjoint ? GU.p[2 * 3 + ic] : GU.p[ic * 3 + 2];
+        const int64_t qb = e * NPD + tid;
         // x stage: A = J_x u_i, B = DJ_x u_i
         for (int col = lane; col < N * N; col += 64) {
             double v[N];
@@ -2065,13 +2332,8 @@ __global__ __launch_bounds__(NTC, (DYN && N > 10) ? 1 : 2) void k_conv3(int64_t 
                 v1[k] = sAD[tid + NCOLZ * k];
                 v2[k] = sBA[tid + NCOLZ * k];
             }
-            const int64_t qb = e * NPD + tid;
-            const double *g0 = adjoint ? GU.p[0 * 3 + ic] : GU.p[ic * 3 + 0];
-            const double *g1 = adjoint ? GU.p[1 * 3 + ic] : GU.p[ic * 3 + 1];
-            const double *g2 = adjoint ? GU.p[2 * 3 + ic] : GU.p[ic * 3 + 2];
             // the six base-flow values of CB fine levels are requested together (6 CB loads in flight per lane); level by level
             // the compiler issued six loads and waited for them, i.e. ND serialised round trips to HBM per component
-            constexpr int CB = ND % 4 == 0 ? 4 : (ND % 5 == 0 ? 5 : (ND % 3 == 0 ? 3 : 1));
 #pragma unroll
             for (int c0 = 0; c0 < ND; c0 += CB) {
                 double bb[CB][6];
@@ -2730,6 +2992,189 @@ __global__ __launch_bounds__(256) void k_interp4_mfma(int64_t E, const double *_
     }
 }
 
+// =================================================================================================
+// The fused dealiased convective term on the matrix cores (lx1 = 8, lxd = 12; round 4).  Same mathematics as k_conv3:
+//   out_i = J^T [ sgn * sum_j Ur_j (du_i/dr_j)_fine + sum_m uf_m Gsel_m ],   Gsel_m = GU[i][m] (direct), GU[m][i] (adjoint)
+// but every one of the 21 tensor stages of an element is a set of v_mfma_f64_16x16x4_f64 tiles (operand layouts: k_interp4_mfma):
+//   forward, per velocity component m:  x pass (J u, DJ u: 16 MFMA) -> LDS -> y pass (36) -> LDS -> z pass (72): value and the three
+//     derivatives of u_m arrive in the D registers of the wave that owns the column tile -- row c = (lane >> 4) + 4 r, column (a, b) --
+//     and are folded at once into the three running sums acc_i of the tile with the base-flow values of the same points (loaded in
+//     that very layout: 16 consecutive doubles per row), so no fine-mesh quantity of the perturbation ever goes to LDS or HBM;
+//   backward, per output component i:  the z pass contracts over the fine index c -- and register r of the D layout IS the B operand
+//     of k-step r (B wants in[k = (lane >> 4) + 4 ks][column]), so acc_i is consumed from registers (27 MFMA) -> LDS -> y pass (18)
+//     -> LDS -> x pass (12) -> LDS -> coalesced store.
+// 543 MFMA per element (372 forward, 171 backward), 15 block barriers (33 in k_conv3), LDS 41 KB, the matrix entries live in 7
+// registers per lane instead of going through the scalar cache.  fp64 MFMA has the vector pipe's peak rate on this chip: what
+// the form buys is issue slots -- one instruction per 1024 multiply-adds instead of one per 64 plus its operand traffic -- in a kernel
+// that ran at 33 % of the HBM peak with the vector pipe as the bound.  Lanes of a block step: blockIdx.y.
+// =================================================================================================
+template <int N, int ND>
+__global__ __launch_bounds__(256, 2) void k_conv3m(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, CF3 Ur, CF9 GU,
+                                                   CF3L ul, F3L outl, int adjoint) {
+    static_assert(N == 8 && ND == 12, "two k-steps forward, three backward, one 16-row tile");
+    constexpr int NP = N * N * N, NPD = ND * ND * ND, NDQ = ND + 1, NQ = N + 1;
+    constexpr int CY = ND * N, CZ = ND * ND;                 // columns of the y and z passes
+    constexpr int NTZ = (CZ + 63) / 64;                      // z-pass column tiles per wave (9 tiles on 4 waves: 3, 2, 2, 2)
+    __shared__ double sA[NDQ * N * N], sB[NDQ * N * N];      // forward x pass: (a | j, k); backward: sA = after the y pass, sB = the result (i | j, k)
+    __shared__ double sAA[CZ * N], sAD[CZ * N], sBA[CZ * N]; // forward y pass: (a, b | k); backward: sAA = after the z pass
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t e = blockIdx.x;
+    const int lv = blockIdx.y;
+    if (e >= E) return;
+    double ja[2], da[2], jt[3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        ja[ks] = l15 < ND ? Jg[l15 * N + lg + 4 * ks] : 0.0;      // A[row = fine index][k = coarse index]
+        da[ks] = l15 < ND ? DJg[l15 * N + lg + 4 * ks] : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) jt[ks] = l15 < N ? Jg[(lg + 4 * ks) * N + l15] : 0.0;   // A[row = coarse index][k = fine index] = J^T
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    const double sgn = adjoint ? -1.0 : 1.0;
+    double acc[NTZ][3][3];   // [column tile of this wave][output component][D register = fine level (lane >> 4) + 4 r]
+#pragma unroll
+    for (int ti = 0; ti < NTZ; ++ti)
+#pragma unroll
+        for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) acc[ti][ic][r] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const double *__restrict__ u = ul.p[lv][m] + e * NP;
+        // ---- x pass: columns (j, k), 64 = 4 tiles, one per wave
+        {
+            const int col = 16 * wave + l15;
+            const double b0 = u[lg + N * col], b1 = u[lg + 4 + N * col];
+            v4f64 aj = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], b0, zero, 0, 0, 0);
+            aj = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], b1, aj, 0, 0, 0);
+            v4f64 ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], b0, zero, 0, 0, 0);
+            ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], b1, ad, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                sA[lg + 4 * r + NDQ * col] = aj[r];
+                sB[lg + 4 * r + NDQ * col] = ad[r];
+            }
+        }
+        lds_barrier();   // (also: every wave has left the z pass of the previous component, whose operands the y pass overwrites)
+        // ---- y pass: columns (a, k), 96 = 6 tiles
+        for (int t = wave; t * 16 < CY; t += 4) {
+            const int col = 16 * t + l15;
+            const int a = col % ND, kz = col / ND;
+            double va[2], vb[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int j = lg + 4 * ks;
+                va[ks] = sA[a + NDQ * (j + N * kz)];
+                vb[ks] = sB[a + NDQ * (j + N * kz)];
+            }
+            v4f64 aa = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], va[0], zero, 0, 0, 0);
+            aa = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], va[1], aa, 0, 0, 0);
+            v4f64 ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], va[0], zero, 0, 0, 0);
+            ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], va[1], ad, 0, 0, 0);
+            v4f64 ba = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], vb[0], zero, 0, 0, 0);
+            ba = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], vb[1], ba, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int q = a + ND * (lg + 4 * r + ND * kz);
+                sAA[q] = aa[r];
+                sAD[q] = ad[r];
+                sBA[q] = ba[r];
+            }
+        }
+        lds_barrier();
+        // ---- z pass: columns (a, b), 144 = 9 tiles; results stay in registers and meet the base flow there
+#pragma unroll
+        for (int ti = 0; ti < NTZ; ++ti) {
+            const int t = wave + 4 * ti;
+            if (t * 16 < CZ) {   // wave-uniform
+                const int col = 16 * t + l15;
+                // base-flow values of the tile's points, requested before the matrix work: Ur_j and the three G of this component
+                const int64_t qb = e * NPD + col;
+                double bu[3][3], bg[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int64_t q = qb + (int64_t)CZ * (lg + 4 * r);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        bu[j][r] = Ur.p[j][q];
+                        bg[j][r] = adjoint ? GU.p[m * 3 + j][q] : GU.p[j * 3 + m][q];   // multiplies uf_m in output component j
+                    }
+                }
+                double v0[2], v1[2], v2[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int k = lg + 4 * ks;
+                    v0[ks] = sAA[col + CZ * k];
+                    v1[ks] = sAD[col + CZ * k];
+                    v2[ks] = sBA[col + CZ * k];
+                }
+                v4f64 r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v0[0], zero, 0, 0, 0);   // uf_m
+                r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v0[1], r0, 0, 0, 0);
+                v4f64 r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], v0[0], zero, 0, 0, 0);   // d/dr_2 (z)
+                r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], v0[1], r1, 0, 0, 0);
+                v4f64 r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v1[0], zero, 0, 0, 0);   // d/dr_1 (y)
+                r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v1[1], r2, 0, 0, 0);
+                v4f64 r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v2[0], zero, 0, 0, 0);   // d/dr_0 (x)
+                r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v2[1], r3, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[ti][m][r] += sgn * (bu[0][r] * r3[r] + bu[1][r] * r2[r] + bu[2][r] * r1[r]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[ti][j][r] += r0[r] * bg[j][r];
+                }
+            }
+        }
+    }
+    // ---- backward: J_z^T from registers, J_y^T and J_x^T through LDS, one output component at a time
+#pragma unroll
+    for (int ic = 0; ic < 3; ++ic) {
+        lds_barrier();   // sAA: the last z pass / the y pass of the previous component has read it; sB: the previous store has read it
+#pragma unroll
+        for (int ti = 0; ti < NTZ; ++ti) {
+            const int t = wave + 4 * ti;
+            if (t * 16 < CZ) {
+                const int col = 16 * t + l15;
+                v4f64 tt = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[0], acc[ti][ic][0], zero, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[1], acc[ti][ic][1], tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[2], acc[ti][ic][2], tt, 0, 0, 0);
+                sAA[col + CZ * lg] = tt[0];            // T(a, b | k), k = lg and lg + 4
+                sAA[col + CZ * (lg + 4)] = tt[1];
+            }
+        }
+        lds_barrier();
+        for (int t = wave; t * 16 < CY; t += 4) {      // S(a | j, k) = sum_b J[b][j] T(a, b, k): columns (a, k)
+            const int col = 16 * t + l15;
+            const int a = col % ND, kz = col / ND;
+            double vb[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) vb[ks] = sAA[a + ND * (lg + 4 * ks) + CZ * kz];
+            v4f64 ss = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[0], vb[0], zero, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[1], vb[1], ss, 0, 0, 0);
+            ss = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[2], vb[2], ss, 0, 0, 0);
+            sA[a + NDQ * (lg + N * kz)] = ss[0];
+            sA[a + NDQ * (lg + 4 + N * kz)] = ss[1];
+        }
+        lds_barrier();
+        {                                               // out(i | j, k) = sum_a J[a][i] S(a, j, k): columns (j, k), one tile per wave
+            const int col = 16 * wave + l15;
+            double va[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) va[ks] = sA[lg + 4 * ks + NDQ * col];
+            v4f64 oo = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[0], va[0], zero, 0, 0, 0);
+            oo = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[1], va[1], oo, 0, 0, 0);
+            oo = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[2], va[2], oo, 0, 0, 0);
+            sB[lg + NQ * col] = oo[0];
+            sB[lg + 4 + NQ * col] = oo[1];
+        }
+        lds_barrier();
+        {
+            double *__restrict__ op = outl.p[lv][ic] + e * NP;
+            for (int q = threadIdx.x; q < NP; q += 256) op[q] = sB[(q % N) + NQ * (q / N)];
+        }
+    }
+}
+
 // CFL (Nek compute_cfl): max over points of dt * sum_j |u_rj| * rdr
 __global__ __launch_bounds__(NT) void k_cfl(int dim, int n, int64_t E, CF9 rst, const double *jac, const double *rdr,
                                             CF3 U, double dt, double *partial) {
@@ -3194,6 +3639,13 @@ static void fill_pmats(const nlg_mesh *m, PMats<N> &M) {
         }
 }
 
+// the small-mesh (strong-scaling) variants of the element kernels are chosen below this many local elements; NLG_SMALL_E=0 switches
+// them off, NLG_SMALL_E=<count> moves the threshold (A/B runs).  Default: 4 waves per SIMD of one-wave-per-element blocks
+bool sem_small_mesh(const nlg_mesh *m) {
+    static const int64_t lim = getenv("NLG_SMALL_E") ? atoll(getenv("NLG_SMALL_E")) : 4096;
+    return m->E < lim;
+}
+
 static CF9 rst2w_ptrs(const nlg_mesh *m) {
     CF9 g;
     for (int q = 0; q < 9; ++q) g.p[q] = m->d_rst2w[q];
@@ -3237,6 +3689,23 @@ int sem_opgradt_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
             pl.p[v] = v < nl ? p[v] : nullptr;
             gl.p[v] = (v < nl && gate) ? gate[v] : nullptr;
             for (int c = 0; c < 3; ++c) wl.p[v][c] = v < nl ? w[v][c] : nullptr;
+        }
+        if (m->n == 8 && nl == 1 && n8new && !old_big && sem_small_mesh(m)) {   // strong-scaling regime: three waves per element
+            const F3 w3 = {{w[0][0], w[0][1], w[0][2]}};
+            const double *g0 = gate ? gate[0] : nullptr;
+            if (upd) {
+                if (face_grouped)
+                    NLG_LAUNCH((k_opgradt3w<8, true, true>), dim3((unsigned)m->E), dim3(192), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, p[0], w3, g0, pu);
+                else
+                    NLG_LAUNCH((k_opgradt3w<8, false, true>), dim3((unsigned)m->E), dim3(192), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, p[0], w3, g0, pu);
+            } else {
+                if (face_grouped)
+                    NLG_LAUNCH((k_opgradt3w<8, true, false>), dim3((unsigned)m->E), dim3(192), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, p[0], w3, g0, NoPUpd{});
+                else
+                    NLG_LAUNCH((k_opgradt3w<8, false, false>), dim3((unsigned)m->E), dim3(192), 0, s, m->E, (const double *)m->d_I12t, (const double *)m->d_D12t, (const int *)m->d_slot_fg, g, p[0], w3, g0, NoPUpd{});
+            }
+            NLG_HIP(hipGetLastError());
+            return 0;
         }
 #define GT3_(N_, ML_)                                                                                                        \
     {                                                                                                                  \
@@ -3325,6 +3794,17 @@ int sem_opdiv_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const 
             pl.p[v] = (v < nl && pw_part) ? pw_part[v] : nullptr;
             dl.p[v] = (v < nl && pdot) ? pdot[v] : nullptr;
             gl.p[v] = (v < nl && gate) ? gate[v] : nullptr;
+        }
+        if (m->n == 8 && nl == 1 && n8new && !old_big && sem_small_mesh(m)) {   // strong-scaling regime: three waves per element
+            const CF3 u3 = {{u[0][0], u[0][1], u[0][2]}};
+            const double *g0 = gate ? gate[0] : nullptr, *d0 = pdot ? pdot[0] : nullptr;
+            double *p0 = pw_part ? pw_part[0] : nullptr;
+            if (face_grouped)
+                NLG_LAUNCH((k_opdiv3w<8, true>), dim3((unsigned)m->E), dim3(192), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, u3, wt, out[0], scale, d0, p0, g0);
+            else
+                NLG_LAUNCH((k_opdiv3w<8, false>), dim3((unsigned)m->E), dim3(192), 0, s, m->E, (const double *)m->d_I12, (const double *)m->d_D12, (const int *)m->d_slot_fg, g, u3, wt, out[0], scale, d0, p0, g0);
+            NLG_HIP(hipGetLastError());
+            return 0;
         }
 #define DV3_(N_, ML_)                                                                                                        \
     {                                                                                                                  \
@@ -3663,9 +4143,16 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
             case 5: CV3(5); break;
             case 6: CV3(6); break;
             case 7: CV3(7); break;
-            case 8:
-                if (sweep == 3) CV3S(8, 3, 3) else CV3(8);   // (measured: see DESIGN.md section 5)
-                break;
+            case 8: {
+                static const bool mfma = !(getenv("NLG_CONV_MFMA") && atoi(getenv("NLG_CONV_MFMA")) == 0);   // A/B: 0 = the vector-pipe kernel k_conv3
+                if (sweep == 3)
+                    CV3S(8, 3, 3)
+                else if (mfma)
+                    NLG_LAUNCH((k_conv3m<8, 12>), dim3((unsigned)m->E, (unsigned)nl), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd,
+                               (const double *)m->d_DJd, cur, cg, cu, co, adjoint);
+                else
+                    CV3(8);   // (measured: see DESIGN.md section 5)
+            } break;
             case 9: CV3D(9, 256, true); break;
             case 10:
                 if (sweep) CV3S(10, 5, 2) else CV3D(10, 256, false);   // (u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU)

@@ -487,7 +487,8 @@ int nlg_set_axpby_rst_consistent(int flag) {
 namespace {
 struct VecInfo {
     uint64_t gen = 0;
-    bool released = false;
+    bool released = false;      // the owner's finaliser ran: in the pool, evictable, any copy may adopt it
+    bool pinned = false;        // released, then READ by a copy that cannot take ownership (intent(in) use): out of the pool, still adoptable
     uint64_t released_at = 0;
 };
 std::map<const nlg_vec *, VecInfo> g_vecs;      // every live or released handle
@@ -576,14 +577,52 @@ int nlg_vec_adopt(nlg_vec *v, int64_t gen, int *status) {
     NLG_CHECK(it != g_vecs.end() && (int64_t)it->second.gen == gen,
               "nlg_vec_adopt: the handle of this copy has been freed (a bitwise copy of a vector was used after more than "
               "nlg_vec_pool_limit bytes of released vectors piled up, or after nlg_vec_pool_trim)");
-    if (it->second.released) {
-        it->second.released = false;
-        g_pool_bytes -= (int64_t)sizeof(double) * v->total_len;
+    if (it->second.released || it->second.pinned) {
+        if (it->second.released) g_pool_bytes -= (int64_t)sizeof(double) * v->total_len;
+        it->second.released = it->second.pinned = false;
         *status = 1;   // the caller owns the handle now
     } else {
         *status = 0;   // owned by a live object: the caller clones
     }
     return 0;
+}
+
+int nlg_vec_pin(nlg_vec *v, int64_t gen) {
+    NLG_CHECK(v, "nlg_vec_pin: NULL argument");
+    auto it = g_vecs.find(v);
+    NLG_CHECK(it != g_vecs.end() && (int64_t)it->second.gen == gen,
+              "nlg_vec_pin: the handle of this copy has been freed (a bitwise copy of a vector was used after more than "
+              "nlg_vec_pool_limit bytes of released vectors piled up, or after nlg_vec_pool_trim)");
+    if (it->second.released) {   // read through a released handle: keep it out of the eviction pool from now on
+        it->second.released = false;
+        it->second.pinned = true;
+        g_pool_bytes -= (int64_t)sizeof(double) * v->total_len;
+    }
+    return 0;
+}
+
+int nlg_vec_unpin(nlg_vec *v, int64_t gen) {
+    if (!v) return 0;
+    auto it = g_vecs.find(v);
+    if (it == g_vecs.end() || (int64_t)it->second.gen != gen || !it->second.pinned) return 0;   // not this copy's business
+    it->second.pinned = false;
+    it->second.released = true;
+    it->second.released_at = ++g_release_tick;
+    g_pool_bytes += (int64_t)sizeof(double) * v->total_len;
+    while (g_pool_bytes > g_pool_limit) pool_free_oldest();
+    return 0;
+}
+
+int64_t nlg_vec_size_checked(const nlg_vec *v, int64_t gen) {
+    auto it = g_vecs.find(v);
+    if (!v || it == g_vecs.end() || (int64_t)it->second.gen != gen) return -1;
+    return (int64_t)v->ncomp * v->mesh->lvn + v->mesh->lpn;
+}
+
+int nlg_vec_has_rst_checked(const nlg_vec *v, int64_t gen) {
+    auto it = g_vecs.find(v);
+    if (!v || it == g_vecs.end() || (int64_t)it->second.gen != gen) return -1;
+    return v->nrst > 0 ? 1 : 0;
 }
 
 int nlg_vec_pool_limit(int64_t bytes) {
@@ -1034,10 +1073,23 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
     // columns before it go into R as for any column, its diagonal entry of R is 0 and the column itself becomes the zero vector
     // (harmless in every later projection).  b->last_block_rank = number of columns kept; nlg_eigs stops expanding the space when
     // it falls below s, as it does at beta = 0 in the single-vector iteration.
+    // Two tests, both relative to what the column was when the step that can lose it began: (1) against the BASIS -- the squared
+    // norm a column brought to this call is what is left of it plus the squares of its coefficients on the (orthonormal) basis,
+    // |w|^2 = |w - V h|^2 + |h|^2; CGS2 leaves a remainder of about eps |w| of a column that lies in span(V), so a remainder below
+    // 1e-12 |w| (1e-24 on the squares) is rounding noise, whatever the other columns of the block look like; (2) among the columns
+    // of the block -- the Cholesky pivot against the diagonal entry at entry to the CURRENT round (the second round sees
+    // normalised columns: a threshold carried over from the first would deflate any healthy column that came in with a norm above 1e7).
     double R[4][4] = {};
     for (int a = 0; a < s; ++a) R[a][a] = 1.0;
     bool dep[4] = {false, false, false, false};
-    double g0[4] = {0.0, 0.0, 0.0, 0.0};   // squared norms of the columns when they entered the factorisation
+    double hsq[4] = {0.0, 0.0, 0.0, 0.0};   // |h_v|^2: squared norm of the part of column v that the projections removed
+    std::vector<double> hs((size_t)std::max(k, 1) * s);
+    if (k > 0) {
+        NLG_HIP(hipMemcpyAsync(hs.data(), H1, sizeof(double) * (size_t)k * s, hipMemcpyDeviceToHost, st));
+        NLG_HIP(hipStreamSynchronize(st));
+        for (int v = 0; v < s; ++v)
+            for (int j = 0; j < k; ++j) hsq[v] += hs[(size_t)j * s + v] * hs[(size_t)j * s + v];
+    }
     for (int round = 0; round < 2; ++round) {
         NLG_TRY(dots(W, s, dG, nullptr));
         double G[16];
@@ -1046,14 +1098,15 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
         double L[4][4] = {};
         for (int i = 0; i < s; ++i) {
             NLG_CHECK(std::isfinite(G[i * s + i]), "nlg_basis_block_cgs2: column %d is not finite", k + i);
-            if (round == 0) g0[i] = G[i * s + i];
+            const double gin = G[i * s + i];   // squared norm of column i at entry to this round
+            if (round == 0 && !(gin > 1e-24 * (gin + hsq[i]))) dep[i] = true;   // nothing left of it beside span(V)
             for (int j = 0; j <= i; ++j) {
                 double a = G[i * s + j];
                 for (int q = 0; q < j; ++q) a -= L[i][q] * L[j][q];
                 if (i == j) {
                     // the pivot is the squared norm of column i after the columns before it have been projected out: a block with
                     // condition number above ~1e7 loses it to rounding (CholQR works on the SQUARED condition number)
-                    if (dep[i] || !(a > 1e-14 * g0[i]) || !(g0[i] > 0.0)) {
+                    if (dep[i] || !(a > 1e-14 * gin) || !(gin > 0.0)) {
                         dep[i] = true;
                         L[i][i] = 0.0;
                     } else {
@@ -1098,11 +1151,6 @@ int nlg_basis_block_cgs2(nlg_basis *b, int k, int s, double *coef) {
     }
     for (int v = 0; v < s; ++v)
         if (dep[v]) --b->last_block_rank;
-    std::vector<double> hs((size_t)std::max(k, 1) * s);
-    if (k > 0) {
-        NLG_HIP(hipMemcpyAsync(hs.data(), H1, sizeof(double) * (size_t)k * s, hipMemcpyDeviceToHost, st));
-        NLG_HIP(hipStreamSynchronize(st));
-    }
     for (int v = 0; v < s; ++v) {
         for (int j = 0; j < k; ++j) coef[(size_t)v * ld + j] = hs[(size_t)j * s + v];
         for (int a = 0; a < s; ++a) coef[(size_t)v * ld + k + a] = R[a][v];

@@ -109,6 +109,30 @@ module neklab_gpu_capi
          integer(c_int), intent(out) :: status
          integer(c_int) :: rc
       end function
+      function c_vec_pin(v, gen) bind(C, name="nlg_vec_pin") result(rc)
+         import c_int, c_ptr, c_int64_t
+         type(c_ptr), value :: v
+         integer(c_int64_t), value :: gen
+         integer(c_int) :: rc
+      end function
+      function c_vec_unpin(v, gen) bind(C, name="nlg_vec_unpin") result(rc)
+         import c_int, c_ptr, c_int64_t
+         type(c_ptr), value :: v
+         integer(c_int64_t), value :: gen
+         integer(c_int) :: rc
+      end function
+      pure function c_vec_has_rst_checked(v, gen) bind(C, name="nlg_vec_has_rst_checked") result(flag)
+         import c_int, c_ptr, c_int64_t
+         type(c_ptr), value :: v
+         integer(c_int64_t), value :: gen
+         integer(c_int) :: flag
+      end function
+      pure function c_vec_size_checked(v, gen) bind(C, name="nlg_vec_size_checked") result(n)
+         import c_ptr, c_int64_t
+         type(c_ptr), value :: v
+         integer(c_int64_t), value :: gen
+         integer(c_int64_t) :: n
+      end function
       function c_vec_pool_trim(freed) bind(C, name="nlg_vec_pool_trim") result(rc)
          import c_int, c_ptr
          type(c_ptr), value :: freed

@@ -90,7 +90,9 @@ contains
             call nlg_check(c_vec_clone(self%h, hnew), 'nek_dvector copy-on-detect')
             self%h = hnew
          end if
-      else
+      else      ! the owner by address -- or a bitwise copy that landed where its original stood (`X = [X, v]` grown in place), whose
+         !        handle the original's finaliser has released: validate the generation and take a released handle back
+         call nlg_check(c_vec_adopt(self%h, self%gen, status), 'nek_dvector (owner whose handle has been freed)')
          return
       end if
       self%owner = loc(self)
@@ -101,17 +103,16 @@ contains
    function nek_dvector_handle(self) result(h)
       class(nek_dvector), intent(in) :: self
       type(c_ptr) :: h
-      integer(c_int64_t) :: gnow
+      integer(c_int) :: status
       if (.not. c_associated(self%h)) then
          write (*, '(A)') 'ERROR in '//this_module//': use of a nek_dvector that holds no data yet'
          error stop 1
       end if
-      if (self%owner /= loc(self)) then      ! a bitwise copy reads through the original's handle: it must still be that handle
-         call nlg_check(c_vec_generation(self%h, gnow), 'nek_dvector (bitwise copy whose original has been freed)')
-         if (gnow /= self%gen) then
-            write (*, '(A)') 'ERROR in '//this_module//': this nek_dvector is a bitwise copy of a vector that has been freed since'
-            error stop 1
-         end if
+      if (self%owner /= loc(self)) then      ! a bitwise copy reads through the original's handle: it must still be that handle (same
+         !                                     generation); a released one is pinned, so that it cannot be evicted under the reader
+         call nlg_check(c_vec_pin(self%h, self%gen), 'nek_dvector (bitwise copy whose original has been freed)')
+      else                                   ! owner by address: see nek_dvector_ensure
+         call nlg_check(c_vec_adopt(self%h, self%gen, status), 'nek_dvector (owner whose handle has been freed)')
       end if
       h = self%h
    end function
@@ -197,7 +198,8 @@ contains
       class(nek_dvector), intent(in) :: self
       integer :: n
       if (c_associated(self%h)) then
-         n = int(c_vec_size_value(self%h))
+         n = int(c_vec_size_checked(self%h, self%gen))
+         if (n < 0) error stop 'neklab_vectors::nek_dsize: this nek_dvector is a bitwise copy of a vector that has been freed since'
       else      ! not materialised yet: the size is a property of the mesh and the case (real_vectors.f90:235-247)
          n = int((nek_ldim + nek_nscal)*nek_lvn + nek_lpn)
       end if
@@ -232,8 +234,13 @@ contains
    pure function dhas_rst_fields(self) result(has_rst_fields)      ! `pure` as in the reference (neklab_vectors.f90:107-110)
       class(nek_dvector), intent(in) :: self
       logical :: has_rst_fields
+      integer(c_int) :: flag
       has_rst_fields = .false.
-      if (c_associated(self%h)) has_rst_fields = c_vec_has_rst_value(self%h) /= 0
+      if (c_associated(self%h)) then      ! never dereferences a stale handle: unknown handle or another generation -> -1
+         flag = c_vec_has_rst_checked(self%h, self%gen)
+         if (flag < 0) error stop 'neklab_vectors::dhas_rst_fields: this nek_dvector is a bitwise copy of a vector that has been freed since'
+         has_rst_fields = flag /= 0
+      end if
    end function
 
    subroutine dclear_rst_fields(self)
@@ -338,7 +345,13 @@ contains
    subroutine finalize_dvector(self)
       type(nek_dvector), intent(inout) :: self
       integer(c_int) :: rc
-      if (c_associated(self%h) .and. self%owner == loc(self)) rc = c_vec_release(self%h)      ! a bitwise copy may still adopt it
+      if (c_associated(self%h)) then
+         if (self%owner == loc(self)) then
+            rc = c_vec_release(self%h)      ! a bitwise copy may still adopt it
+         else
+            rc = c_vec_unpin(self%h, self%gen)      ! a reader that pinned a released handle gives it back to the pool
+         end if
+      end if
       self%h = c_null_ptr; self%owner = 0; self%gen = 0
    end subroutine
 
@@ -347,7 +360,13 @@ contains
       integer :: i
       integer(c_int) :: rc
       do i = 1, size(self)
-         if (c_associated(self(i)%h) .and. self(i)%owner == loc(self(i))) rc = c_vec_release(self(i)%h)
+         if (c_associated(self(i)%h)) then
+            if (self(i)%owner == loc(self(i))) then
+               rc = c_vec_release(self(i)%h)
+            else
+               rc = c_vec_unpin(self(i)%h, self(i)%gen)
+            end if
+         end if
          self(i)%h = c_null_ptr; self(i)%owner = 0; self(i)%gen = 0
       end do
    end subroutine

@@ -64,17 +64,20 @@ def block_cgs2(V, k, s):
         coef[:k] += h
     R = np.eye(s)
     dep = [False] * s          # deflated (numerically dependent) columns, as in nlg_basis_block_cgs2: zero vector, zero diagonal of R
-    g0 = None
-    for _ in range(2):
+    hsq = np.sum(coef[:k] ** 2, axis=0)     # what the projections removed: |w|^2 = |w - V h|^2 + |h|^2 for an orthonormal basis
+    for rnd in range(2):
         G = np.array([[W[a].dot(W[b]) for b in range(s)] for a in range(s)])
-        if g0 is None:
-            g0 = np.diag(G).copy()
+        gin = np.diag(G).copy()             # squared norms at entry to THIS round (the pivots are tested against these)
+        if rnd == 0:
+            for i in range(s):              # a column in span(V) to rounding: CGS2 leaves about eps |w| of it
+                if not (gin[i] > 1e-24 * (gin[i] + hsq[i])):
+                    dep[i] = True
         L = np.zeros((s, s))
         for i in range(s):
             for j in range(i + 1):
                 a = G[i, j] - np.dot(L[i, :j], L[j, :j])
                 if i == j:
-                    if dep[i] or not (a > 1e-14 * g0[i]) or not (g0[i] > 0.0):
+                    if dep[i] or not (a > 1e-14 * gin[i]) or not (gin[i] > 0.0):
                         dep[i] = True
                     else:
                         L[i, i] = np.sqrt(a)

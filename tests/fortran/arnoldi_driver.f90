@@ -82,6 +82,19 @@ program arnoldi_driver
       call Z(3)%scal(2.0_dp)                  ! copy of the live `extra`: gets a clone, `extra` keeps its value
       write (*, '(A,I0,4ES24.16)') 'REALLOC ', size(Z), Z(1)%norm(), Z(2)%norm(), Z(3)%norm(), extra%norm()
       write (*, '(A,L1)') 'HASRST ', Z(1)%has_rst_fields()
+      ! a moved element that has only been READ since the move, then the pool of released vectors is emptied (as an allocation
+      ! failure or nlg_vec_pool_limit would): the element must still hold its data -- also when the reallocation grew the array in
+      ! place, i.e. the copy stands at the address of its finalised original and is "the owner" by address
+      extra = Xb(2)
+      Z = [Z, extra]
+      n1 = Z(2)%norm()
+      block
+         use neklab_gpu_capi, only: c_vec_pool_trim
+         integer(c_int) :: rc
+         rc = c_vec_pool_trim(c_null_ptr)
+      end block
+      call Z(2)%scal(2.0_dp)
+      write (*, '(A,I0,3ES24.16,1X,L1)') 'TRIM ', size(Z), n1, Z(2)%norm(), Z(4)%norm(), Z(2)%has_rst_fields()
    end block
    deallocate (Xb, exptA, bf)
    call neklab_gpu_finalize()

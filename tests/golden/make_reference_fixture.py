@@ -124,25 +124,30 @@ if __name__ == "__main__":
         fn[k] = fn[k][perm]
     assert np.max(np.abs(fn["x"] - X[:, 0])) < 1e-5 and np.max(np.abs(fn["y"] - X[:, 1])) < 1e-5    # same points (fp32 coordinates)
     out5 = OUT.replace("reference_cyl_baseflow", "reference_cyl_re40_guess")
+    import digitize_reference_plots as dgp
+    dg = dgp.cylinder_re40()
+    assert [len(v) for v in dg["gmres"]] == [21, 19, 3] and len(dg["newton"]) == 3 and dg["rel_err"] < 0.01
     np.savez_compressed(out5, ux=fn["ux"].astype(np.float32), uy=fn["uy"].astype(np.float32), p=fn["p"].astype(np.float32),
                         re=np.array(40.0),                         # 1cyl.par: viscosity = -40
                         tau=np.array(1.0), dt=np.array(0.009),     # endTime = 1.0, dt = 0.009, bdf3
                         solver_tol=np.array(1.0e-8),               # [PRESSURE] / [VELOCITY] residualTol
                         newton_tol=np.array(1.0e-6),               # 1cyl.usr: tol = 1.0e-6_dp
-                        # read off residual.png (log axes, two significant digits): Newton residuals at the start of steps 1 - 3 ...
-                        plot_newton_residuals=np.array([9.0e-3, 1.33e-4, 1.3e-6]),
-                        # ... the GMRES residuals of Newton step 1 (init + 20 inner steps) and the inner-step counts of the three steps
-                        plot_gmres_step1=np.array([9.0e-3, 1.1e-3, 1.65e-4, 9.8e-5, 7.7e-5, 6.1e-5, 4.4e-5, 2.9e-5, 1.9e-5, 1.3e-5, 9.5e-6,
-                                                   7.2e-6, 5.6e-6, 4.4e-6, 3.4e-6, 2.7e-6, 2.2e-6, 1.8e-6, 1.5e-6, 1.2e-6, 9.7e-7]),
-                        plot_gmres_step2=np.array([1.33e-4, 8.1e-5, 3.5e-5, 2.4e-5, 1.8e-5, 1.33e-5, 1.02e-5, 7.9e-6, 6.2e-6, 4.9e-6, 3.9e-6,
-                                                   3.2e-6, 2.65e-6, 2.2e-6, 1.9e-6, 1.6e-6, 1.35e-6, 1.15e-6, 9.8e-7]),
-                        plot_gmres_inner_steps=np.array([20, 18, 2]))
+                        # digitised from residual.png by tests/golden/digitize_reference_plots.py (marker centroids against the tick marks of the
+                        # log axes; one-sigma relative error `plot_rel_err`, about 0.8 %): Newton residuals at the start of steps 1 - 3 ...
+                        plot_newton_residuals=dg["newton"], plot_rel_err=np.array(dg["rel_err"]),
+                        # ... the GMRES residuals of every Newton step ("init step", then the inner steps) and the inner-step counts
+                        plot_gmres_step1=dg["gmres"][0], plot_gmres_step2=dg["gmres"][1], plot_gmres_step3=dg["gmres"][2],
+                        # the same number read on both axes (GMRES init residual of step k / Newton residual of step k - 1): the digitisation's own check
+                        plot_cross_check=dg["cross_check"],
+                        plot_gmres_inner_steps=np.array([len(v) - 1 for v in dg["gmres"]]))
     print(out5, os.path.getsize(out5), "bytes")
     # ---- thermosyphon: mesh, parameters, published Newton residuals ---------------------------------------------------------
     tdir = "/root/reference/examples/thermosyphon/baseflow/"
     rt = read_re2(tdir + "tsyphon.re2")
     assert rt["nel"] == 256 and all(c[3] == "C" for c in rt["curves"]) and len(rt["bcs_fields"]) == 2
     out6 = OUT.replace("reference_cyl_baseflow", "reference_tsyphon_mesh")
+    dgt = dgp.thermosyphon()
+    assert len(dgt["newton"]) == 9
     np.savez_compressed(out6, xc=rt["xc"], yc=rt["yc"], curve_elem=np.array([c[0] for c in rt["curves"]]),
                         curve_edge=np.array([c[1] for c in rt["curves"]]), curve_par=np.array([c[2] for c in rt["curves"]]),
                         bc_elem=np.array([b[0] for b in rt["bcs_fields"][0]]), bc_face=np.array([b[1] for b in rt["bcs_fields"][0]]),
@@ -153,8 +158,9 @@ if __name__ == "__main__":
                         # newton_fixed_point_iteration(sys, bf, 1e-6, tol_mode = 2) from the Ra = 500 base flow
                         nu=np.array(0.2), conductivity=np.array(1.0), rhocp=np.array(1.0), rayleigh=np.array(510.0), rayleigh_guess=np.array(500.0),
                         tau=np.array(1.0), newton_tol=np.array(1.0e-6),
-                        # read off residual.png: Newton residuals at the start of steps 1 - 9
-                        plot_newton_residuals=np.array([4.2e-1, 1.3e-3, 6.6e-5, 4.0e-6, 6.3e-7, 1.7e-7, 6.5e-8, 3.3e-8, 1.8e-8]),
+                        # digitised from residual.png (digitize_reference_plots.thermosyphon; left axes only -- the GMRES curves of its nine
+                        # Newton steps overlap too much for marker segmentation): Newton residuals at the start of steps 1 - 9
+                        plot_newton_residuals=dgt["newton"], plot_rel_err=np.array(dgt["rel_err"]),
                         # GMRES of Newton step 1: residual at the start and after inner steps 1 - 3; tolerance lines of steps 1, 3, 4 (dashed)
                         plot_gmres_step1=np.array([4.2e-1, 6.6e-3, 1.75e-4, 2.45e-5]), plot_gmres_tol=np.array([1.0e-4, 6.6e-6, 4.0e-7]))
     print(out6, os.path.getsize(out6), "bytes")

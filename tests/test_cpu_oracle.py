@@ -302,3 +302,41 @@ def test_matvec_matches_golden_3d_n8():
     y = A.matvec(x)
     assert max(np.abs(y.v[i] - g["mv_out_v"][i]).max() for i in range(3)) < 1e-13 * np.abs(g["mv_out_v"]).max()
     assert max(np.abs(y.v_rst[1][i] - g["mv_out_rst2_v"][i]).max() for i in range(3)) < 1e-13 * np.abs(g["mv_out_v"]).max()
+
+
+def test_block_cgs2_deflation_is_scale_free_and_sees_the_span_of_the_basis():
+    """The oracle twin of nlg_basis_block_cgs2's two deflation tests (ADVICE round 3): columns of norm 1e8 / 1e-8 are kept;
+    a block in span(V) is deflated although the rounding noise the projections leave is not mutually dependent."""
+    from oracle.krylov import block_cgs2, cgs2_step
+    sem = SEM(box_mesh((3, 2), 5, periodic=(True, False), deform=0.04))
+    def basis(k):
+        V = []
+        for j in range(k):
+            v = NekDVector(sem)
+            v.rand(ifnorm=True, seed=20 + j)
+            if j:
+                cgs2_step(V, v)
+            v.scal(1.0 / v.norm())
+            V.append(v)
+        return V
+    V = basis(3)
+    for v, scale in enumerate((1e8, 1.0, 1e-8)):
+        w = NekDVector(sem)
+        w.rand(ifnorm=True, seed=50 + v)
+        w.scal(scale)
+        V.append(w)
+    coef = block_cgs2(V, 3, 3)
+    assert np.all(np.diag(coef[3:]) > 0.0)
+    G = np.array([[a.dot(b) for b in V] for a in V])
+    assert np.max(np.abs(G - np.eye(6))) < 1e-12
+    V = basis(4)
+    C = np.random.default_rng(1).standard_normal((4, 2))
+    for v in range(2):
+        w = V[0].copy()
+        w.scal(C[0, v])
+        for j in range(1, 4):
+            w.axpby(C[j, v], V[j], 1.0)
+        V.append(w)
+    coef = block_cgs2(V, 4, 2)
+    assert np.max(np.abs(coef[:4] - C)) < 1e-12 and np.all(np.diag(coef[4:]) == 0.0)
+    assert V[4].norm() == 0.0 and V[5].norm() == 0.0

@@ -135,6 +135,13 @@ def test_re40_newton_guess_fixture():
     g = load_cylinder_re40_guess()
     assert g["ux"].shape == ux50.shape and float(g["re"]) == 40.0 and float(g["tau"]) == 1.0
     assert len(g["plot_gmres_step1"]) == 21 and list(g["plot_gmres_inner_steps"]) == [20, 18, 2]
+    # the digitised figure (tests/golden/digitize_reference_plots.py): its own error bars and internal consistency -- a GMRES residual
+    # history decreases monotonically, and the "init" residual of Newton step k is the Newton residual of step k read on the other axes
+    assert float(g["plot_rel_err"]) < 0.01 and np.max(np.abs(g["plot_cross_check"])) < 0.015
+    for key in ("plot_gmres_step1", "plot_gmres_step2", "plot_gmres_step3"):
+        assert np.all(np.diff(g[key]) < 0.0), key
+    assert abs(g["plot_gmres_step1"][0] / g["plot_newton_residuals"][0] - 1.0) < 0.015
+    assert abs(g["plot_gmres_step1"][-1] / 1e-6 - 1.0) < 0.05 and abs(g["plot_gmres_step2"][-1] / 1e-6 - 1.0) < 0.05   # both stop at the tolerance 1e-6
     sem = SEM(hm, lxd=lxd)
     u = [g["ux"].reshape(sem.shape1), g["uy"].reshape(sem.shape1)]
     x, y = hm.x.reshape(sem.shape1), hm.y.reshape(sem.shape1)

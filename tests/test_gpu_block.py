@@ -133,6 +133,65 @@ def test_block_cgs2_deflates_a_dependent_column(gpu_ctx):
             assert d < 1e-10, (v, r, d)
 
 
+def _basis_of(sem, gm, k, s):
+    B = host.KrylovBasis(gm, k + s)
+    oV = []
+    for j in range(k):
+        ov = pair(sem, gm, 10 + j, with_history=False)
+        upload(B[j], ov, 3)
+        B.cgs2(j, B[j])
+        if j:
+            cgs2_step(oV, ov)
+        ov.scal(1.0 / ov.norm())
+        oV.append(ov)
+    return B, oV
+
+
+def test_block_cgs2_keeps_columns_of_large_norm(gpu_ctx):
+    """ADVICE round 3 (vec.hip deflation test): the pivot of the SECOND CholQR round must be compared with the column's norm at entry
+    to that round, not with the norm it had before the first -- healthy columns of norm 1e8 / 1e-8 are kept, like columns of norm 1."""
+    hm = box_mesh((3, 2, 2), 5, periodic=(True, False, False), deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    k, s = 3, 3
+    B, oV = _basis_of(sem, gm, k, s)
+    new = [pair(sem, gm, 60 + v, with_history=False) for v in range(s)]
+    for v, scale in enumerate((1e8, 1.0, 1e-8)):
+        new[v].scal(scale)
+        upload(B[k + v], new[v], 3)
+        oV.append(new[v])
+    coef = B.block_cgs2(k, s)
+    ocoef = o_block_cgs2(oV, k, s)
+    assert B.last_block_rank() == 3
+    assert np.all(np.abs(coef - ocoef) < 1e-10 * np.max(np.abs(ocoef), axis=0)), np.max(np.abs(coef - ocoef))
+    G = np.array([[B[i].dot(B[j]) for j in range(k + s)] for i in range(k + s)])
+    assert np.max(np.abs(G - np.eye(k + s))) < 1e-12
+
+
+def test_block_cgs2_deflates_a_block_that_lies_in_the_span_of_the_basis(gpu_ctx):
+    """The documented 'invariant subspace reached' case: every column of the new block is a combination of basis vectors.  What the two
+    projections leave is rounding noise whose columns are NOT mutually dependent, so only the comparison with the norm before
+    the projections (|w|^2 = |w - V h|^2 + |h|^2) can see it: rank 0, zero vectors, the coefficients on the basis returned."""
+    hm = box_mesh((3, 2, 2), 5, periodic=(True, False, False), deform=0.04)
+    sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)
+    k, s = 4, 2
+    B, oV = _basis_of(sem, gm, k, s)
+    rng = np.random.default_rng(3)
+    C = rng.standard_normal((k, s))
+    for v in range(s):
+        w = oV[0].copy()
+        w.scal(C[0, v])
+        for j in range(1, k):
+            w.axpby(C[j, v], oV[j], 1.0)
+        upload(B[k + v], w, 3)
+        oV.append(w)
+    coef = B.block_cgs2(k, s)
+    ocoef = o_block_cgs2(oV, k, s)
+    assert B.last_block_rank() == 0
+    assert np.max(np.abs(coef[:k] - C)) < 1e-12 and np.max(np.abs(ocoef[:k] - C)) < 1e-12
+    assert np.all(np.diag(coef[k:]) == 0.0) and np.all(np.diag(ocoef[k:]) == 0.0)
+    assert B[k].norm() == 0.0 and B[k + 1].norm() == 0.0
+
+
 def test_block_arnoldi_matches_oracle_and_single_vector_spectrum(gpu_ctx):
     hm = box_mesh((4, 3), 6, lengths=(4.0, 2.0), periodic=(True, False), deform=0.04)
     sem, gm = SEM(hm), host.Mesh(gpu_ctx, hm)

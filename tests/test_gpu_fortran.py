@@ -38,7 +38,7 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
     r = subprocess.run([exe], cwd=tmp, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     H = np.zeros((kdim + 1, kdim))
-    alias = size = move = realloc = None
+    alias = size = move = realloc = trim = None
     for ln in r.stdout.splitlines():
         p = ln.split()
         if p and p[0] == "H":
@@ -51,6 +51,8 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
             move = [float(v) for v in p[1:]]
         elif p and p[0] == "REALLOC":
             realloc = [float(v) for v in p[1:]]
+        elif p and p[0] == "TRIM":
+            trim = [float(v) for v in p[1:5]] + [p[5]]
     # same computation through the C ABI's block path
     gb = host.nek_dvector(gm)
     for i in range(2):
@@ -71,6 +73,9 @@ def test_fortran_shim_arnoldi_matches_c_abi(gpu_ctx):
     assert abs(n1 - 1.0) < 1e-12 and abs(n2 - 3.0) < 1e-12 and abs(move[2] - n1) < 1e-12 and abs(move[3] - n2) < 1e-12
     assert realloc[0] == 3 and abs(realloc[1] - 2.0 * n1) < 1e-12 and abs(realloc[2] - n2) < 1e-12
     assert abs(realloc[3] - 10.0) < 1e-12 and abs(realloc[4] - 5.0) < 1e-12
+    # a moved element read once, then nlg_vec_pool_trim, then modified: its handle must have left the pool with the read
+    # (owner-by-address copies re-adopt, other copies pin) -- ADVICE round 3, neklab_vectors.f90:87
+    assert trim[0] == 4 and abs(trim[1] - n2) < 1e-12 and abs(trim[2] - 2.0 * n2) < 1e-12 and abs(trim[3] - n2 / 3.0) < 1e-12 and trim[4] in ("T", "F"), trim
 
 
 @pytest.mark.parametrize("device_eigs", [0, 1])

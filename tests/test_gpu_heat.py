@@ -131,3 +131,51 @@ def test_nonlinear_map_with_temperature_matches_oracle(gpu_ctx):
     assert np.max(np.abs(gF.get_field(host.THETA).reshape(sem.shape1) - oF.theta[0])) < 1e-9 * np.abs(oF.theta[0]).max()
     # Dirichlet values of the temperature stay: F vanishes on the walls
     assert np.max(np.abs(gF.get_field(host.THETA).reshape(sem.shape1) * (1 - sem.tmask))) == 0.0
+
+
+@pytest.mark.parametrize("dim,n,s", [(2, 6, 2), (3, 8, 3), (3, 10, 2)])
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_boussinesq_matvec_block_equals_single_matvecs(gpu_ctx, dim, n, s, adjoint):
+    """Lane-batched propagator with the temperature coupling (the reference's coupled operator
+    exponential_propagator_temp.f90:15-60 / :62-107): s vectors advanced together -- scalar right-hand side, operator, gather-scatter
+    and the scalar's PCG as ONE launch for all lanes -- give what s single matvecs give, velocity, pressure, temperature and their
+    restart histories, with very different magnitudes per lane (different iteration counts) and a restart history on the odd lanes."""
+    if dim == 2:
+        hm = box_mesh((3, 2), n, lengths=(2.0, 1.0), periodic=(True, False), deform=0.03)
+    else:
+        hm = box_mesh((2, 2, 2), n, lengths=(2.0, 1.0, 1.0), periodic=(True, False, True), deform=0.03)
+    sem = SEM(hm)
+    gm = host.Mesh(gpu_ctx, hm)
+    gb = host.nek_dvector(gm, 1)
+    gb.set_field(0, sem.mask[0] * (4 * sem.X[1] * (1 - sem.X[1])))
+    gb.set_field(host.THETA, 1.0 - sem.X[1] + 0.1 * np.sin(np.pi * sem.X[0]) * np.sin(np.pi * sem.X[1]))
+    A = host.exptA_linop(0.05, gb, re=5.0, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=600, maxit_p=4000, dt=0.01,
+                         ifheat=1, conductivity=0.3, rhocp=1.5, buoy=(0.0, 50.0, 0.0))
+    A.init()
+    mv = A.rmatvec if adjoint else A.matvec
+    vin = []
+    for v in range(s):
+        x = host.nek_dvector(gm, 1)
+        x.rand(True, seed=70 + v)
+        x.scal(10.0 ** (-2 * v))
+        if v % 2 == 1:
+            y = host.nek_dvector(gm, 1)
+            mv(x, y)
+            x = y
+        vin.append(x)
+    single = [host.nek_dvector(gm, 1) for _ in range(s)]
+    for v in range(s):
+        mv(vin[v], single[v])
+    blk = [host.nek_dvector(gm, 1) for _ in range(s)]
+    A.matvec_block(vin, blk, transpose=adjoint)
+    for v in range(s):
+        sc = max(np.abs(single[v].get_field(i)).max() for i in range(dim))
+        st = np.abs(single[v].get_field(host.THETA)).max()
+        for r in range(3):
+            for i in range(dim):
+                assert np.max(np.abs(blk[v].get_field(i, r) - single[v].get_field(i, r))) < 1e-11 * sc, (v, r, i)
+            assert np.max(np.abs(blk[v].get_field(host.THETA, r) - single[v].get_field(host.THETA, r))) < 1e-11 * max(st, sc), (v, r)
+            assert np.max(np.abs(blk[v].get_field(host.PR, r) - single[v].get_field(host.PR, r))) < 1e-9 * max(sc, np.abs(single[v].get_field(host.PR, r)).max())
+        assert blk[v].nrst == 2
+    with pytest.raises(host.NlgError):       # a vector without the scalar is refused by the block path too
+        A.matvec_block([host.nek_dvector(gm)], [host.nek_dvector(gm)])

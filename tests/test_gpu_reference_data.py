@@ -114,9 +114,13 @@ def test_gpu_newton_re40_against_the_reference_convergence_plot(gpu_ctx):
     convergence history the reference ships for that very run (residual.png): Newton residuals 9.0e-3, 1.33e-4, 1.3e-6 at a
     constant solver tolerance, and the GMRES residual after every inner step of Newton steps 1 and 2 (20 and 18 inner steps).
     A reference-held OUTPUT of the path nonlinear map -> Jacobian (exptA about the current iterate) -> GMRES -> update
-    (SURVEY section 8f row 3), 39 Krylov vectors deep.  Tolerances: the reading precision of a log-scale plot -- 3 % for the
-    Newton residuals, 12 % pointwise for the GMRES curves (this build: within 4 % except one point at 8 %); values at the level
-    of the linear-solver tolerance (1e-6) are only bounded.  profiles/r03_cylinder_newton_re40.txt has the full log."""
+    (SURVEY section 8f row 3), 39 Krylov vectors deep.  The reference numbers are DIGITISED from the figure
+    (tests/golden/digitize_reference_plots.py: marker centroids against the axis ticks, one-sigma 0.8 %, the same residual read on both
+    axes agrees to 0.2 - 1.0 %), so the tolerances are those of the digitisation, not of a reading by eye: Newton residuals 1 and 2
+    within 1.5 % (this build: 0.07 % and 0.05 %); every GMRES residual within 4 % (this build: 0.3 - 3.2 %) EXCEPT the residual after
+    the SECOND inner step of either Newton step, where this build sits 8.0 % / 5.9 % above the reference (asserted < 9 %; variants of
+    the Jacobian tolerance and time step do not move it, profiles/r04_re40_variants.txt -- an open difference, DESIGN.md section 2a'').
+    Values at the level of the linear-solver tolerance (1e-6: Newton residual 3, the last GMRES points) are only bounded."""
     from refdata import load_cylinder_re40_guess
     hm, _, _, _, _, lxd, _ = load_cylinder(with_bcs=True)
     g = load_cylinder_re40_guess()
@@ -130,12 +134,17 @@ def test_gpu_newton_re40_against_the_reference_convergence_plot(gpu_ctx):
     ref = g["plot_newton_residuals"]
     assert out["converged"] and out["iterations"] == 3, out
     r = out["residuals"]
-    assert abs(r[0] / ref[0] - 1.0) < 0.03 and abs(r[1] / ref[1] - 1.0) < 0.03, r
+    assert float(g["plot_rel_err"]) < 0.01 and np.max(np.abs(g["plot_cross_check"])) < 0.015      # the digitisation's own error bars
+    assert abs(r[0] / ref[0] - 1.0) < 0.015 and abs(r[1] / ref[1] - 1.0) < 0.015, r
     assert 0.5 * ref[2] < r[2] < 2.0 * ref[2], r
     assert r[3] < float(g["newton_tol"])
     h = out["gmres_residuals"]
     ref1, ref2 = g["plot_gmres_step1"], g["plot_gmres_step2"]
     assert len(h[0]) - 1 == 20 and abs((len(h[1]) - 1) - 18) <= 1 and len(h[2]) - 1 <= 2, [len(x) - 1 for x in h]
-    assert np.max(np.abs(np.array(h[0]) / ref1 - 1.0)) < 0.12, np.array(h[0]) / ref1
+    d1 = np.abs(np.array(h[0]) / ref1 - 1.0)
     k2 = min(len(h[1]), len(ref2))
-    assert np.max(np.abs(np.array(h[1][:k2]) / ref2[:k2] - 1.0)) < 0.12, np.array(h[1][:k2]) / ref2[:k2]
+    d2 = np.abs(np.array(h[1][:k2]) / ref2[:k2] - 1.0)
+    rest = np.arange(len(d1)) != 2
+    assert np.max(d1[rest]) < 0.04 and d1[2] < 0.09, d1
+    rest = np.arange(k2) != 2
+    assert np.max(d2[rest]) < 0.04 and d2[2] < 0.09, d2
