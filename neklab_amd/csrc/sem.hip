@@ -3008,117 +3008,152 @@ __global__ __launch_bounds__(256) void k_interp4_mfma(int64_t E, const double *_
 // the form buys is issue slots -- one instruction per 1024 multiply-adds instead of one per 64 plus its operand traffic -- in a kernel
 // that ran at 33 % of the HBM peak with the vector pipe as the bound.  Lanes of a block step: blockIdx.y.
 // =================================================================================================
-template <int N, int ND>
-__global__ __launch_bounds__(256, 2) void k_conv3m(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, CF3 Ur, CF9 GU,
+template <int N, int ND, bool DYN>
+__global__ __launch_bounds__(256, (ND > 16) ? 1 : 2) void k_conv3m(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, CF3 Ur, CF9 GU,
                                                    CF3L ul, F3L outl, int adjoint) {
-    static_assert(N == 8 && ND == 12, "two k-steps forward, three backward, one 16-row tile");
+    static_assert(ND <= 32 && N <= 16 && ND > N, "fine rows in one or two 16-row tiles: lx1 = 8 (lxd 12), 10 (15), 12 (18: rows 16, 17 in a second tile)");
     constexpr int NP = N * N * N, NPD = ND * ND * ND, NDQ = ND + 1, NQ = N + 1;
-    constexpr int CY = ND * N, CZ = ND * ND;                 // columns of the y and z passes
-    constexpr int NTZ = (CZ + 63) / 64;                      // z-pass column tiles per wave (9 tiles on 4 waves: 3, 2, 2, 2)
-    __shared__ double sA[NDQ * N * N], sB[NDQ * N * N];      // forward x pass: (a | j, k); backward: sA = after the y pass, sB = the result (i | j, k)
-    __shared__ double sAA[CZ * N], sAD[CZ * N], sBA[CZ * N]; // forward y pass: (a, b | k); backward: sAA = after the z pass
+    constexpr int CX = N * N, CY = ND * N, CZ = ND * ND;     // columns of the x, y and z passes
+    constexpr int KF = (N + 3) / 4, KB = (ND + 3) / 4;       // k-steps of a forward (contraction over a coarse index) / backward pass
+    constexpr int RF = KB, RB = KF;                          // D registers that hold real rows: fine rows forward, coarse rows backward
+    constexpr int RT = (ND + 15) / 16;                       // 16-row tiles of a forward result; register r = 4 rt + r' holds fine row lg + 4 r
+    constexpr int NTZ = (CZ + 63) / 64;                      // z-pass column tiles per wave (lx1 = 8: 9 tiles on 4 waves: 3, 2, 2, 2)
+    constexpr bool XF = CX % 16 == 0, YF = CY % 16 == 0, ZF = CZ % 16 == 0;   // full column tiles (lx1 = 8): no column guards
+    constexpr bool RFF = ND % 4 == 0, RBF = N % 4 == 0;                       // full register rows: no row guards
+    // forward x pass: (a | j, k) in sA, sB; y pass: (a, b | k) in sAA, sAD, sBA.  Backward: sAA = after the z pass, sA = after the y
+    // pass, sB = the result (i | j, k).  lx1 = 10: 80 KB, more than a kernel may declare statically -> dynamic LDS, two blocks per CU still
+    constexpr int LA = NDQ * CX, LY = CZ * N;
+    extern __shared__ double conv3m_dyn[];
+    __shared__ double st_lds[DYN ? 1 : 2 * LA + 3 * LY];
+    double *sA = DYN ? conv3m_dyn : st_lds, *sB = sA + LA, *sAA = sB + LA, *sAD = sAA + LY, *sBA = sAD + LY;
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t e = blockIdx.x;
     const int lv = blockIdx.y;
     if (e >= E) return;
-    double ja[2], da[2], jt[3];
+    double ja[RT][KF], da[RT][KF], jt[KB];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        ja[ks] = l15 < ND ? Jg[l15 * N + lg + 4 * ks] : 0.0;      // A[row = fine index][k = coarse index]
-        da[ks] = l15 < ND ? DJg[l15 * N + lg + 4 * ks] : 0.0;
-    }
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) jt[ks] = l15 < N ? Jg[(lg + 4 * ks) * N + l15] : 0.0;   // A[row = coarse index][k = fine index] = J^T
+        for (int ks = 0; ks < KF; ++ks) {
+            const bool ok = 16 * rt + l15 < ND && (RBF || lg + 4 * ks < N);
+            ja[rt][ks] = ok ? Jg[(16 * rt + l15) * N + lg + 4 * ks] : 0.0;       // A[row = fine index][k = coarse index]
+            da[rt][ks] = ok ? DJg[(16 * rt + l15) * N + lg + 4 * ks] : 0.0;
+        }
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) jt[ks] = (l15 < N && (RFF || lg + 4 * ks < ND)) ? Jg[(lg + 4 * ks) * N + l15] : 0.0;   // A[row = coarse][k = fine] = J^T
     const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
     const double sgn = adjoint ? -1.0 : 1.0;
-    double acc[NTZ][3][3];   // [column tile of this wave][output component][D register = fine level (lane >> 4) + 4 r]
+    // one small GEMM: D = sum_ks A[ks] B[ks]
+    auto mm = [&](const auto &A, const auto &B, auto nks) {
+        v4f64 d = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], B[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < decltype(nks)::value; ++ks) d = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], B[ks], d, 0, 0, 0);
+        return d;
+    };
+    constexpr std::integral_constant<int, KF> kf{};
+    constexpr std::integral_constant<int, KB> kb{};
+    // forward GEMM: all fine rows of the result, out[r] = row lg + 4 r
+    auto fw = [&](const double (&A)[RT][KF], const double (&B)[KF], double (&out)[RF]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const v4f64 d = mm(A[rt], B, kf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * rt + q < RF) out[4 * rt + q] = d[q];
+        }
+    };
+    double acc[NTZ][3][RF];   // [column tile of this wave][output component][D register = fine level (lane >> 4) + 4 r]
 #pragma unroll
     for (int ti = 0; ti < NTZ; ++ti)
 #pragma unroll
         for (int ic = 0; ic < 3; ++ic)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) acc[ti][ic][r] = 0.0;
+            for (int r = 0; r < RF; ++r) acc[ti][ic][r] = 0.0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const double *__restrict__ u = ul.p[lv][m] + e * NP;
-        // ---- x pass: columns (j, k), 64 = 4 tiles, one per wave
-        {
-            const int col = 16 * wave + l15;
-            const double b0 = u[lg + N * col], b1 = u[lg + 4 + N * col];
-            v4f64 aj = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], b0, zero, 0, 0, 0);
-            aj = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], b1, aj, 0, 0, 0);
-            v4f64 ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], b0, zero, 0, 0, 0);
-            ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], b1, ad, 0, 0, 0);
+        // ---- x pass: columns (j, k)
+        for (int t = wave; t * 16 < CX; t += 4) {
+            const int col = 16 * t + l15;
+            const bool okc = XF || col < CX;
+            double bv[KF];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                sA[lg + 4 * r + NDQ * col] = aj[r];
-                sB[lg + 4 * r + NDQ * col] = ad[r];
-            }
+            for (int ks = 0; ks < KF; ++ks) bv[ks] = (okc && (RBF || lg + 4 * ks < N)) ? u[lg + 4 * ks + N * col] : 0.0;
+            double aj[RF], ad[RF];
+            fw(ja, bv, aj);
+            fw(da, bv, ad);
+#pragma unroll
+            for (int r = 0; r < RF; ++r)
+                if (okc && (RFF || lg + 4 * r < ND)) {
+                    sA[lg + 4 * r + NDQ * col] = aj[r];
+                    sB[lg + 4 * r + NDQ * col] = ad[r];
+                }
         }
         lds_barrier();   // (also: every wave has left the z pass of the previous component, whose operands the y pass overwrites)
-        // ---- y pass: columns (a, k), 96 = 6 tiles
+        // ---- y pass: columns (a, k)
         for (int t = wave; t * 16 < CY; t += 4) {
             const int col = 16 * t + l15;
+            const bool okc = YF || col < CY;
             const int a = col % ND, kz = col / ND;
-            double va[2], vb[2];
+            double va[KF], vb[KF];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KF; ++ks) {
                 const int j = lg + 4 * ks;
-                va[ks] = sA[a + NDQ * (j + N * kz)];
-                vb[ks] = sB[a + NDQ * (j + N * kz)];
+                const bool ok = okc && (RBF || j < N);
+                va[ks] = ok ? sA[a + NDQ * (j + N * kz)] : 0.0;
+                vb[ks] = ok ? sB[a + NDQ * (j + N * kz)] : 0.0;
             }
-            v4f64 aa = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], va[0], zero, 0, 0, 0);
-            aa = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], va[1], aa, 0, 0, 0);
-            v4f64 ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], va[0], zero, 0, 0, 0);
-            ad = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], va[1], ad, 0, 0, 0);
-            v4f64 ba = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], vb[0], zero, 0, 0, 0);
-            ba = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], vb[1], ba, 0, 0, 0);
+            double aa[RF], ad[RF], ba[RF];
+            fw(ja, va, aa);
+            fw(da, va, ad);
+            fw(ja, vb, ba);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int q = a + ND * (lg + 4 * r + ND * kz);
-                sAA[q] = aa[r];
-                sAD[q] = ad[r];
-                sBA[q] = ba[r];
-            }
+            for (int r = 0; r < RF; ++r)
+                if (okc && (RFF || lg + 4 * r < ND)) {
+                    const int q = a + ND * (lg + 4 * r + ND * kz);
+                    sAA[q] = aa[r];
+                    sAD[q] = ad[r];
+                    sBA[q] = ba[r];
+                }
         }
         lds_barrier();
-        // ---- z pass: columns (a, b), 144 = 9 tiles; results stay in registers and meet the base flow there
+        // ---- z pass: columns (a, b); results stay in registers and meet the base flow there
 #pragma unroll
         for (int ti = 0; ti < NTZ; ++ti) {
             const int t = wave + 4 * ti;
             if (t * 16 < CZ) {   // wave-uniform
                 const int col = 16 * t + l15;
+                const bool okc = ZF || col < CZ;
                 // base-flow values of the tile's points, requested before the matrix work: Ur_j and the three G of this component
                 const int64_t qb = e * NPD + col;
-                double bu[3][3], bg[3][3];
+                double bu[3][RF], bg[3][RF];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                for (int r = 0; r < RF; ++r) {
+                    const bool ok = okc && (RFF || lg + 4 * r < ND);
                     const int64_t q = qb + (int64_t)CZ * (lg + 4 * r);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        bu[j][r] = Ur.p[j][q];
-                        bg[j][r] = adjoint ? GU.p[m * 3 + j][q] : GU.p[j * 3 + m][q];   // multiplies uf_m in output component j
+                        bu[j][r] = ok ? Ur.p[j][q] : 0.0;
+                        bg[j][r] = ok ? (adjoint ? GU.p[m * 3 + j][q] : GU.p[j * 3 + m][q]) : 0.0;   // multiplies uf_m in output component j
                     }
                 }
-                double v0[2], v1[2], v2[2];
+                double v0[KF], v1[KF], v2[KF];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KF; ++ks) {
                     const int k = lg + 4 * ks;
-                    v0[ks] = sAA[col + CZ * k];
-                    v1[ks] = sAD[col + CZ * k];
-                    v2[ks] = sBA[col + CZ * k];
+                    const bool ok = okc && (RBF || k < N);
+                    v0[ks] = ok ? sAA[col + CZ * k] : 0.0;
+                    v1[ks] = ok ? sAD[col + CZ * k] : 0.0;
+                    v2[ks] = ok ? sBA[col + CZ * k] : 0.0;
                 }
-                v4f64 r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v0[0], zero, 0, 0, 0);   // uf_m
-                r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v0[1], r0, 0, 0, 0);
-                v4f64 r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[0], v0[0], zero, 0, 0, 0);   // d/dr_2 (z)
-                r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da[1], v0[1], r1, 0, 0, 0);
-                v4f64 r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v1[0], zero, 0, 0, 0);   // d/dr_1 (y)
-                r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v1[1], r2, 0, 0, 0);
-                v4f64 r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[0], v2[0], zero, 0, 0, 0);   // d/dr_0 (x)
-                r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[1], v2[1], r3, 0, 0, 0);
+                double r0[RF], r1[RF], r2[RF], r3[RF];
+                fw(ja, v0, r0);   // uf_m
+                fw(da, v0, r1);   // d/dr_2 (z)
+                fw(ja, v1, r2);   // d/dr_1 (y)
+                fw(ja, v2, r3);   // d/dr_0 (x)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                for (int r = 0; r < RF; ++r) {
                     acc[ti][m][r] += sgn * (bu[0][r] * r3[r] + bu[1][r] * r2[r] + bu[2][r] * r1[r]);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[ti][j][r] += r0[r] * bg[j][r];
@@ -3135,43 +3170,227 @@ __global__ __launch_bounds__(256, 2) void k_conv3m(int64_t E, const double *__re
             const int t = wave + 4 * ti;
             if (t * 16 < CZ) {
                 const int col = 16 * t + l15;
-                v4f64 tt = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[0], acc[ti][ic][0], zero, 0, 0, 0);
-                tt = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[1], acc[ti][ic][1], tt, 0, 0, 0);
-                tt = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[2], acc[ti][ic][2], tt, 0, 0, 0);
-                sAA[col + CZ * lg] = tt[0];            // T(a, b | k), k = lg and lg + 4
-                sAA[col + CZ * (lg + 4)] = tt[1];
+                const v4f64 tt = mm(jt, acc[ti][ic], kb);      // (rows beyond the fine mesh and columns beyond (a, b) carry zeros)
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    if ((ZF || col < CZ) && (RBF || lg + 4 * r < N)) sAA[col + CZ * (lg + 4 * r)] = tt[r];   // T(a, b | k)
             }
         }
         lds_barrier();
         for (int t = wave; t * 16 < CY; t += 4) {      // S(a | j, k) = sum_b J[b][j] T(a, b, k): columns (a, k)
             const int col = 16 * t + l15;
+            const bool okc = YF || col < CY;
             const int a = col % ND, kz = col / ND;
-            double vb[3];
+            double vb[KB];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) vb[ks] = sAA[a + ND * (lg + 4 * ks) + CZ * kz];
-            v4f64 ss = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[0], vb[0], zero, 0, 0, 0);
-            ss = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[1], vb[1], ss, 0, 0, 0);
-            ss = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[2], vb[2], ss, 0, 0, 0);
-            sA[a + NDQ * (lg + N * kz)] = ss[0];
-            sA[a + NDQ * (lg + 4 + N * kz)] = ss[1];
+            for (int ks = 0; ks < KB; ++ks) vb[ks] = (okc && (RFF || lg + 4 * ks < ND)) ? sAA[a + ND * (lg + 4 * ks) + CZ * kz] : 0.0;
+            const v4f64 ss = mm(jt, vb, kb);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (okc && (RBF || lg + 4 * r < N)) sA[a + NDQ * (lg + 4 * r + N * kz)] = ss[r];
         }
         lds_barrier();
-        {                                               // out(i | j, k) = sum_a J[a][i] S(a, j, k): columns (j, k), one tile per wave
-            const int col = 16 * wave + l15;
-            double va[3];
+        for (int t = wave; t * 16 < CX; t += 4) {      // out(i | j, k) = sum_a J[a][i] S(a, j, k): columns (j, k)
+            const int col = 16 * t + l15;
+            const bool okc = XF || col < CX;
+            double va[KB];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) va[ks] = sA[lg + 4 * ks + NDQ * col];
-            v4f64 oo = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[0], va[0], zero, 0, 0, 0);
-            oo = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[1], va[1], oo, 0, 0, 0);
-            oo = __builtin_amdgcn_mfma_f64_16x16x4f64(jt[2], va[2], oo, 0, 0, 0);
-            sB[lg + NQ * col] = oo[0];
-            sB[lg + 4 + NQ * col] = oo[1];
+            for (int ks = 0; ks < KB; ++ks) va[ks] = (okc && (RFF || lg + 4 * ks < ND)) ? sA[lg + 4 * ks + NDQ * col] : 0.0;
+            const v4f64 oo = mm(jt, va, kb);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (okc && (RBF || lg + 4 * r < N)) sB[lg + 4 * r + NQ * col] = oo[r];
         }
         lds_barrier();
         {
             double *__restrict__ op = outl.p[lv][ic] + e * NP;
             for (int q = threadIdx.x; q < NP; q += 256) op[q] = sB[(q % N) + NQ * (q / N)];
         }
+    }
+}
+
+// The scalar (temperature) transport term of the Boussinesq coupling in the same matrix-pipe form (see k_conv3s_scalar for the term):
+//   out = J^T [ sgn sum_j Ur_j (d theta / d r_j)_fine + gsel sum_m uf_m GT_m ]       direct: sgn = gsel = 1; adjoint: sgn = -1, gsel = 0
+// Four fields go through the forward passes -- the velocity components for their VALUE only (one matrix per pass; skipped in the adjoint),
+// theta for its three derivatives -- into ONE running sum per column tile; one field is projected back.
+template <int N, int ND, bool DYN>
+__global__ __launch_bounds__(256, 2) void k_conv3m_scalar(int64_t E, const double *__restrict__ Jg, const double *__restrict__ DJg, CF3 Ur, CF3 GT, CF3 uv,
+                                                          const double *__restrict__ theta, double *__restrict__ out, int adjoint) {
+    static_assert(ND <= 16 && N <= 12 && ND > N, "one 16-row tile per matrix: lx1 = 8 (lxd 12), 10 (15)");
+    constexpr int NP = N * N * N, NPD = ND * ND * ND, NDQ = ND + 1, NQ = N + 1;
+    constexpr int CX = N * N, CY = ND * N, CZ = ND * ND;
+    constexpr int KF = (N + 3) / 4, KB = (ND + 3) / 4, RF = KB, RB = KF;
+    constexpr int NTZ = (CZ + 63) / 64;
+    constexpr bool XF = CX % 16 == 0, YF = CY % 16 == 0, ZF = CZ % 16 == 0, RFF = ND % 4 == 0, RBF = N % 4 == 0;
+    constexpr int LA = NDQ * CX, LY = CZ * N;
+    extern __shared__ double conv3ms_dyn[];
+    __shared__ double st_lds[DYN ? 1 : 2 * LA + 3 * LY];
+    double *sA = DYN ? conv3ms_dyn : st_lds, *sB = sA + LA, *sAA = sB + LA, *sAD = sAA + LY, *sBA = sAD + LY;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t e = blockIdx.x;
+    if (e >= E) return;
+    double ja[KF], da[KF], jt[KB];
+#pragma unroll
+    for (int ks = 0; ks < KF; ++ks) {
+        const bool ok = l15 < ND && (RBF || lg + 4 * ks < N);
+        ja[ks] = ok ? Jg[l15 * N + lg + 4 * ks] : 0.0;
+        da[ks] = ok ? DJg[l15 * N + lg + 4 * ks] : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) jt[ks] = (l15 < N && (RFF || lg + 4 * ks < ND)) ? Jg[(lg + 4 * ks) * N + l15] : 0.0;
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    const double sgn = adjoint ? -1.0 : 1.0;
+    auto mm = [&](const auto &A, const auto &B, auto nks) {
+        v4f64 d = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], B[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < decltype(nks)::value; ++ks) d = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], B[ks], d, 0, 0, 0);
+        return d;
+    };
+    constexpr std::integral_constant<int, KF> kf{};
+    constexpr std::integral_constant<int, KB> kb{};
+    double acc[NTZ][RF];
+#pragma unroll
+    for (int ti = 0; ti < NTZ; ++ti)
+#pragma unroll
+        for (int r = 0; r < RF; ++r) acc[ti][r] = 0.0;
+    // one field through the three forward passes; TH: theta (derivatives), else a velocity component (value, times GT_f)
+    auto field = [&](auto th, const double *__restrict__ u, const double *__restrict__ gt) {
+        constexpr bool TH = decltype(th)::value;
+        for (int t = wave; t * 16 < CX; t += 4) {
+            const int col = 16 * t + l15;
+            const bool okc = XF || col < CX;
+            double bv[KF];
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) bv[ks] = (okc && (RBF || lg + 4 * ks < N)) ? u[lg + 4 * ks + N * col] : 0.0;
+            const v4f64 aj = mm(ja, bv, kf);
+            v4f64 ad = zero;
+            if constexpr (TH) ad = mm(da, bv, kf);
+#pragma unroll
+            for (int r = 0; r < RF; ++r)
+                if (okc && (RFF || lg + 4 * r < ND)) {
+                    sA[lg + 4 * r + NDQ * col] = aj[r];
+                    if constexpr (TH) sB[lg + 4 * r + NDQ * col] = ad[r];
+                }
+        }
+        lds_barrier();
+        for (int t = wave; t * 16 < CY; t += 4) {
+            const int col = 16 * t + l15;
+            const bool okc = YF || col < CY;
+            const int a = col % ND, kz = col / ND;
+            double va[KF], vb[KF];
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+                const int j = lg + 4 * ks;
+                const bool ok = okc && (RBF || j < N);
+                va[ks] = ok ? sA[a + NDQ * (j + N * kz)] : 0.0;
+                vb[ks] = (TH && ok) ? sB[a + NDQ * (j + N * kz)] : 0.0;
+            }
+            const v4f64 aa = mm(ja, va, kf);
+            v4f64 ad = zero, ba = zero;
+            if constexpr (TH) {
+                ad = mm(da, va, kf);
+                ba = mm(ja, vb, kf);
+            }
+#pragma unroll
+            for (int r = 0; r < RF; ++r)
+                if (okc && (RFF || lg + 4 * r < ND)) {
+                    const int q = a + ND * (lg + 4 * r + ND * kz);
+                    sAA[q] = aa[r];
+                    if constexpr (TH) {
+                        sAD[q] = ad[r];
+                        sBA[q] = ba[r];
+                    }
+                }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int ti = 0; ti < NTZ; ++ti) {
+            const int t = wave + 4 * ti;
+            if (t * 16 < CZ) {
+                const int col = 16 * t + l15;
+                const bool okc = ZF || col < CZ;
+                const int64_t qb = e * NPD + col;
+                double b0[RF], b1[RF], b2[RF];
+#pragma unroll
+                for (int r = 0; r < RF; ++r) {
+                    const bool ok = okc && (RFF || lg + 4 * r < ND);
+                    const int64_t q = qb + (int64_t)CZ * (lg + 4 * r);
+                    if constexpr (TH) {
+                        b0[r] = ok ? Ur.p[0][q] : 0.0, b1[r] = ok ? Ur.p[1][q] : 0.0, b2[r] = ok ? Ur.p[2][q] : 0.0;
+                    } else {
+                        b0[r] = ok ? gt[q] : 0.0;
+                    }
+                }
+                double v0[KF], v1[KF], v2[KF];
+#pragma unroll
+                for (int ks = 0; ks < KF; ++ks) {
+                    const int k = lg + 4 * ks;
+                    const bool ok = okc && (RBF || k < N);
+                    v0[ks] = ok ? sAA[col + CZ * k] : 0.0;
+                    v1[ks] = (TH && ok) ? sAD[col + CZ * k] : 0.0;
+                    v2[ks] = (TH && ok) ? sBA[col + CZ * k] : 0.0;
+                }
+                if constexpr (TH) {
+                    const v4f64 r1 = mm(da, v0, kf), r2 = mm(ja, v1, kf), r3 = mm(ja, v2, kf);   // d/dr_2, d/dr_1, d/dr_0
+#pragma unroll
+                    for (int r = 0; r < RF; ++r) acc[ti][r] += sgn * (b0[r] * r3[r] + b1[r] * r2[r] + b2[r] * r1[r]);
+                } else {
+                    const v4f64 r0 = mm(ja, v0, kf);
+#pragma unroll
+                    for (int r = 0; r < RF; ++r) acc[ti][r] += r0[r] * b0[r];
+                }
+            }
+        }
+        lds_barrier();   // the next field's passes overwrite the stage arrays
+    };
+    if (!adjoint) {
+        field(std::false_type{}, uv.p[0] + e * NP, GT.p[0]);
+        field(std::false_type{}, uv.p[1] + e * NP, GT.p[1]);
+        field(std::false_type{}, uv.p[2] + e * NP, GT.p[2]);
+    }
+    field(std::true_type{}, theta + e * NP, nullptr);
+    // ---- backward
+#pragma unroll
+    for (int ti = 0; ti < NTZ; ++ti) {
+        const int t = wave + 4 * ti;
+        if (t * 16 < CZ) {
+            const int col = 16 * t + l15;
+            const v4f64 tt = mm(jt, acc[ti], kb);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if ((ZF || col < CZ) && (RBF || lg + 4 * r < N)) sAA[col + CZ * (lg + 4 * r)] = tt[r];
+        }
+    }
+    lds_barrier();
+    for (int t = wave; t * 16 < CY; t += 4) {
+        const int col = 16 * t + l15;
+        const bool okc = YF || col < CY;
+        const int a = col % ND, kz = col / ND;
+        double vb[KB];
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks) vb[ks] = (okc && (RFF || lg + 4 * ks < ND)) ? sAA[a + ND * (lg + 4 * ks) + CZ * kz] : 0.0;
+        const v4f64 ss = mm(jt, vb, kb);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (okc && (RBF || lg + 4 * r < N)) sA[a + NDQ * (lg + 4 * r + N * kz)] = ss[r];
+    }
+    lds_barrier();
+    for (int t = wave; t * 16 < CX; t += 4) {
+        const int col = 16 * t + l15;
+        const bool okc = XF || col < CX;
+        double va[KB];
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks) va[ks] = (okc && (RFF || lg + 4 * ks < ND)) ? sA[lg + 4 * ks + NDQ * col] : 0.0;
+        const v4f64 oo = mm(jt, va, kb);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (okc && (RBF || lg + 4 * r < N)) sB[lg + 4 * r + NQ * col] = oo[r];
+    }
+    lds_barrier();
+    {
+        double *__restrict__ op = out + e * NP;
+        for (int q = threadIdx.x; q < NP; q += 256) op[q] = sB[(q % N) + NQ * (q / N)];
     }
 }
 
@@ -4059,6 +4278,25 @@ int sem_conv_scalar_apply(nlg_mesh *m, double *const *Ur, double *const *GT, dou
     static const bool sweep = !(getenv("NLG_CONVS_SWEEP") && atoi(getenv("NLG_CONVS_SWEEP")) == 0);   // A/B: the generic tensor kernels
     if (sweep && dim == 3 && m->n >= 8 && m->n <= 10 && m->nd == (3 * m->n) / 2) {
         CF3 cur = {{Ur[0], Ur[1], Ur[2]}}, cgt = {{GT[0], GT[1], GT[2]}}, cu = {{u[0], u[1], u[2]}};
+        static const bool mfma = !(getenv("NLG_CONV_MFMA") && atoi(getenv("NLG_CONV_MFMA")) == 0);   // A/B: 0 = the plane-sweep kernel
+        if (mfma && m->n == 8) {
+            NLG_LAUNCH((k_conv3m_scalar<8, 12, false>), dim3((unsigned)m->E), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd, (const double *)m->d_DJd,
+                       cur, cgt, cu, theta, out, adjoint);
+            NLG_HIP(hipGetLastError());
+            return 0;
+        }
+        if (mfma && m->n == 10) {
+            constexpr size_t lds = sizeof(double) * (2 * 16 * 100 + 3 * 225 * 10);
+            static bool attr_set = false;
+            if (!attr_set) {
+                NLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3m_scalar<10, 15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            NLG_LAUNCH((k_conv3m_scalar<10, 15, true>), dim3((unsigned)m->E), dim3(256), lds, m->ctx->stream, m->E, (const double *)m->d_Jd, (const double *)m->d_DJd,
+                       cur, cgt, cu, theta, out, adjoint);
+            NLG_HIP(hipGetLastError());
+            return 0;
+        }
 #define CVS(N_, NW_)                                                                                                                         \
     NLG_LAUNCH((k_conv3s_scalar<N_, (3 * N_) / 2, NW_>), dim3((unsigned)m->E), dim3(NW_ * 64), 0, m->ctx->stream, m->E, (const double *)m->d_Jd, \
                (const double *)m->d_DJd, (const double *)m->d_Jdt, cur, cgt, cu, theta, out, adjoint);
@@ -4148,16 +4386,32 @@ int sem_conv_apply_lanes(nlg_mesh *m, double *const *Ur, double *const *GU, int 
                 if (sweep == 3)
                     CV3S(8, 3, 3)
                 else if (mfma)
-                    NLG_LAUNCH((k_conv3m<8, 12>), dim3((unsigned)m->E, (unsigned)nl), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd,
+                    NLG_LAUNCH((k_conv3m<8, 12, false>), dim3((unsigned)m->E, (unsigned)nl), dim3(256), 0, m->ctx->stream, m->E, (const double *)m->d_Jd,
                                (const double *)m->d_DJd, cur, cg, cu, co, adjoint);
                 else
                     CV3(8);   // (measured: see DESIGN.md section 5)
             } break;
             case 9: CV3D(9, 256, true); break;
-            case 10:
-                if (sweep) CV3S(10, 5, 2) else CV3D(10, 256, false);   // (u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU)
-                break;
+            case 10: {
+                static const bool mfma = !(getenv("NLG_CONV_MFMA") && atoi(getenv("NLG_CONV_MFMA")) == 0);   // A/B: 0 = the plane-sweep kernel k_conv3s
+                if (mfma) {
+                    constexpr size_t lds = sizeof(double) * (2 * 16 * 100 + 3 * 225 * 10);   // 79.6 KB: two blocks per CU
+                    static bool attr_set = false;
+                    if (!attr_set) {
+                        NLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3m<10, 15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        attr_set = true;
+                    }
+                    NLG_LAUNCH((k_conv3m<10, 15, true>), dim3((unsigned)m->E, (unsigned)nl), dim3(256), lds, m->ctx->stream, m->E, (const double *)m->d_Jd,
+                               (const double *)m->d_DJd, cur, cg, cu, co, adjoint);
+                } else if (sweep)
+                    CV3S(10, 5, 2)
+                else
+                    CV3D(10, 256, false);   // (u from global memory: 78 KB of LDS instead of 104 KB, two blocks per CU)
+            } break;
             default:
+                // lx1 = 12 stays on the plane-sweep kernel: lxd = 18 needs a SECOND 16-row tile for fine rows 16, 17 in every forward
+                // pass (3252 MFMA per element against 1320 at lx1 = 10) and 137 KB of LDS, i.e. one block per CU; built and measured
+                // (k_conv3m<12, 18>, parity green): 3.10 ms per launch against 3.10 ms -- a tie, so the instantiation was dropped
                 if (sweep) CV3S(12, 7, 1) else CV3D(12, 384, false);
                 break;
         }

@@ -10,7 +10,8 @@
 !! (In a build against the real LightKrylov the reference's own file works unchanged on top of neklab_vectors / neklab_linops;
 !!  this module exists for the device switch.)
 module neklab_analysis
-   use LightKrylov, only: dp, eigs, svds, save_eigenspectrum, zero_basis, initialize_krylov_subspace, newton, gmres_rdp
+   use LightKrylov, only: dp, eigs, svds, save_eigenspectrum, zero_basis, initialize_krylov_subspace, newton, gmres_rdp, &
+                          newton_dp_opts, newton_dp_metadata
    use LightKrylov, only: abstract_vector_rdp, abstract_exptA_linop_rdp, abstract_system_rdp
    use neklab_vectors
    use neklab_linops
@@ -104,20 +105,23 @@ contains
       real(dp), intent(inout) :: tol
       integer, optional, intent(in) :: tol_mode
       logical, optional, intent(out) :: input_is_fixed_point
-      integer :: niter, mode
+      integer :: info, mode
+      type(newton_dp_opts) :: opts
+      type(newton_dp_metadata) :: meta
       mode = 1
       if (present(tol_mode)) mode = tol_mode
+      opts = newton_dp_opts(maxiter=40, ifbisect=.false.)      ! LightKrylov's own interface, as the reference calls it (neklab_analysis.f90:186-196)
       if (mode == 1) then
-         call newton(sys, bf, gmres_rdp, niter, atol=tol, maxiter=40, scheduler=nek_constant_tol)
+         call newton(sys, bf, gmres_rdp, info, atol=tol, options=opts, scheduler=nek_constant_tol, meta=meta)
       else
-         call newton(sys, bf, gmres_rdp, niter, atol=tol, maxiter=40, scheduler=nek_dynamic_tol)
+         call newton(sys, bf, gmres_rdp, info, atol=tol, options=opts, scheduler=nek_dynamic_tol, meta=meta)
       end if
-      if (niter < 0) write (*, '(A)') 'WARNING in newton_fixed_point_iteration: not converged after 40 iterations'
+      if (.not. meta%converged) write (*, '(A)') 'WARNING in newton_fixed_point_iteration: not converged after 40 iterations'
       select type (bf)
       type is (nek_dvector)
          call outpost_dnek(bf, 'nwt')
       end select
-      if (present(input_is_fixed_point)) input_is_fixed_point = niter == 0
+      if (present(input_is_fixed_point)) input_is_fixed_point = meta%input_is_fixed_point
       call sys%finalize_timer()
       call sys%jacobian%finalize_timer()
    end subroutine newton_fixed_point_iteration

@@ -50,6 +50,9 @@ module neklab_systems
    end type
 
    !> the solver tolerance the schedulers last chose = what Nek5000 keeps in param(21) / param(22) (neklab_systems.f90:261-264)
+   !> the reference's param(22) (Nek5000's velocity tolerance), which its schedulers, nonlinear_map and the Jacobian products read and
+   !! write in turn (neklab_systems.f90:259-260, fixed_point.f90:14-17, :49-62, :87): ONE variable here too, so that the tolerance of
+   !! a Jacobian product depends on who set it last exactly as it does there
    real(dp), save, private :: solver_tol = 1.0e-9_dp
 
 contains
@@ -81,6 +84,7 @@ contains
                self%ready = .true.
             end if
             call self%prop%set_tolerances(0.1_dp*atol, 0.1_dp*atol)
+            solver_tol = 0.1_dp*atol      ! setup_nonlinear_solver(vtol = atol*0.1) leaves param(22) at this value (neklab_nek_setup.f90:228)
             call self%prop%nonlinear_map(vec_in, vec_out)      ! Phi_T(X) - X; the time step follows the CFL number of X
          class default
             call type_error('vec_out', 'nek_dvector', 'OUT', this_module, 'nonlinear_map')
@@ -111,6 +115,8 @@ contains
          else
             call self%prop%set_baseflow(state)
          end if
+         ! fixed_point.f90:49-62: atol = param(22) AS IT STANDS at the call -- the value the scheduler wrote if it ran last, a tenth of it
+         ! if nonlinear_map ran last -- the solves run at half of it, and param(22) is put back afterwards (:87)
          call self%prop%set_tolerances(0.5_dp*solver_tol, 0.5_dp*solver_tol)
          if (transposed) then
             call self%prop%rmatvec(vec_in, vec_out)

@@ -48,6 +48,19 @@ module LightKrylov
    public :: zero_basis, eigs, svds, save_eigenspectrum, innerprod, type_error, stop_error, initialize_krylov_subspace
    public :: newton, gmres_rdp
 
+   !> options / metadata of `newton` as the reference uses them (src/neklab_analysis.f90:173-196: newton_dp_opts(maxiter=40,
+   !! ifbisect=.false.), meta%input_is_fixed_point); only the components the reference touches are restated
+   type, public :: newton_dp_opts
+      integer :: maxiter = 100
+      logical :: ifbisect = .false.
+      integer :: maxstep_bisection = 5
+   end type
+   type, public :: newton_dp_metadata
+      integer :: n_iter = 0
+      logical :: converged = .false.
+      logical :: input_is_fixed_point = .false.
+   end type
+
    type, abstract, public :: abstract_vector_rdp
    contains
       procedure(abstract_zero), pass(self), deferred, public :: zero
@@ -321,21 +334,25 @@ contains
 
    !> Newton iteration on sys%response(X) = 0: X <- X + dx with jacobian dx = -F(X) by `linear_solver`; the scheduler sets the
    !! tolerance the residual and the linear solves are evaluated with (neklab_analysis.f90:186-192).  info = iterations, < 0: not converged.
-   subroutine newton(sys, X, linear_solver, info, atol, maxiter, scheduler)
+   subroutine newton(sys, X, linear_solver, info, atol, options, scheduler, meta)
       class(abstract_system_rdp), intent(inout) :: sys
       class(abstract_vector_rdp), intent(inout) :: X
       procedure(abstract_linear_solver) :: linear_solver
       integer, intent(out) :: info
       real(dp), intent(in) :: atol
-      integer, optional, intent(in) :: maxiter
+      type(newton_dp_opts), optional, intent(in) :: options
       procedure(abstract_scheduler), optional :: scheduler
+      type(newton_dp_metadata), optional, intent(out) :: meta
       class(abstract_vector_rdp), allocatable :: r, dx
       real(dp) :: tol, rnorm
       integer :: it, nmax, sinfo, linfo
-      nmax = 40; if (present(maxiter)) nmax = maxiter
+      nmax = 100; if (present(options)) nmax = options%maxiter
       allocate (r, mold=X); allocate (dx, mold=X)
       tol = atol
       info = -1
+      if (present(meta)) then
+         meta%converged = .false.; meta%input_is_fixed_point = .false.; meta%n_iter = 0
+      end if
       do it = 0, nmax
          call sys%response(X, r, tol)
          rnorm = r%norm()
@@ -344,7 +361,11 @@ contains
          end if
          if (rnorm < atol) then
             if (tol <= atol*(1.0_dp + 1.0e-12_dp)) then
-               info = it; return
+               info = it
+               if (present(meta)) then
+                  meta%converged = .true.; meta%input_is_fixed_point = it == 0; meta%n_iter = it
+               end if
+               return
             end if
             tol = atol; cycle                                ! converged at a loose solver tolerance: re-evaluate at the target
          end if
@@ -355,6 +376,7 @@ contains
          call linear_solver(sys%jacobian, r, dx, linfo, 0.1_dp*max(rnorm, atol))
          call X%add(dx)
       end do
+      if (present(meta)) meta%n_iter = nmax
    end subroutine newton
 
    !> Golub-Kahan-Lanczos bidiagonalisation with full re-orthogonalisation through the abstract interfaces; singular values of
