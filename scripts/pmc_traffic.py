@@ -35,8 +35,8 @@ import sys
 
 CLASSES = {      # bench.py kernel class -> regex on the demangled kernel name
     "gs": r"^k_gs<3>", "axhelm": r"^k_axhelm3[rc]?<", "opgradt": r"^k_opgradt3(<\d+, \d+|n<\d+), true", "opdiv": r"^k_opdiv3(<\d+, \d+|n<\d+), true",
-    "block_dot": r"^k_block_dot<", "axpy_dot": r"^k_block_axpy_dot<", "block_axpy": r"^k_block_axpy$", "cg_vec": r"^k_cg_update<3>",
-    "conv": r"^k_conv3<", "fdm": r"^k_fdm_ext(<|_mfma8)",
+    "block_dot": r"^k_block_dot<", "axpy_dot": r"^k_block_axpy_dot<", "block_axpy": r"^k_block_axpy$", "cg_vec": r"^k_cg_update<3>", "cg_update": r"^k_cg_update<3>",
+    "conv": r"^k_conv3m?<", "fdm": r"^k_fdm_ext(<|_mfma8)",
 }
 
 
