@@ -531,6 +531,10 @@ __global__ __launch_bounds__(64, 4) void k_fdm_ext_mfma8(const double *__restric
 }
 
 // z += (own + neighbours' ghost values at this point, from W after QQ^T) + prolonged coarse correction; r.z and z sums
+// relative weight of the coarse-level correction in the additive sum (1 = plain additive; NLG_COARSE_SCALE for experiments: PCG does not
+// care about the overall scale of a preconditioner, but it does about the balance of its two terms)
+__device__ __constant__ double c_coarse_scale = 1.0;
+
 template <int N>
 __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ flag, int64_t E, const double *__restrict__ W,
                                                    const double *__restrict__ r, const double *__restrict__ wq,
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(NT) void k_sch_finish(const double *__restrict__ fl
 #pragma unroll
                 for (int c = 0; c < 8; ++c) av[c] = agg[vv[c]];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) cv[c] = xc[vv[c]] + xa[av[c]];
+                for (int c = 0; c < 8; ++c) cv[c] = c_coarse_scale * (xc[vv[c]] + xa[av[c]]);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
@@ -1352,6 +1356,10 @@ int up(const std::vector<T> &v, T **d) {
 namespace nlg {
 
 int pprec_setup(nlg_mesh *m, const nlg_mesh_desc *d) {
+    if (getenv("NLG_COARSE_SCALE")) {
+        const double cs = atof(getenv("NLG_COARSE_SCALE"));
+        NLG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_coarse_scale), &cs, sizeof(double)));
+    }
     nlg_pprec &P = m->pprec;
     nlg_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
