@@ -1783,17 +1783,26 @@ __global__ __launch_bounds__(192) void k_opgradt3w(int64_t E, const double *__re
         if constexpr (PU) if (pu.z[0]) {
             const double beta = pu.beta[0][0], zmean = pu.zmean[0][0];
             const double *ze = pu.z[0] + e * NP2;
-            double *po = pu.p[0] + e * NP2;
             double zv[N2];
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) zv[k2] = ze[tid + NS2 * k2];
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) pv[k2] = (zv[k2] - zmean) + beta * pv[k2];
-            if (i == 0) {
-#pragma unroll
-                for (int k2 = 0; k2 < N2; ++k2) po[tid + NS2 * k2] = pv[k2];
-            }
         }
+    }
+    if constexpr (PU) {
+        // the updated direction is written IN PLACE over the array the other two waves are still reading: every wave's loads of p must have
+        // RETURNED before wave 0 stores (a full barrier with the vector-memory counter drained, not an LDS-only one).  Without it the race
+        // is silent -- a wave that reads the updated p applies the update twice, the PCG still converges, only more slowly: 12.75 -> 26.75
+        // pressure iterations per time step in the 4-rank rehearsal, which is how it was found
+        __syncthreads();
+        if (pu.z[0] && i == 0 && tid < NS2) {
+            double *po = pu.p[0] + e * NP2;
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) po[tid + NS2 * k2] = pv[k2];
+        }
+    }
+    if (tid < NS2) {
         const int i2 = tid % N2, j2 = tid / N2;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {

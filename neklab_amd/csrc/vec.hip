@@ -222,6 +222,63 @@ __global__ __launch_bounds__(NT) void k_block_axpy_dot(const double *__restrict_
     }
 }
 
+// The same sweep for 64 < k <= 128 (round 4; BASELINE configs 4 and 5 name m = 128 and 256): k values and k running sums no longer fit
+// one lane's registers, so the SECOND half of the basis values of a point is parked in LDS (one column of 64 doubles per thread: 128 KB of
+// dynamic LDS, one block per CU as before) between the subtraction, which needs all k of them, and the projection, which needs them again
+// together with the finished w: the basis is still read ONCE per pass.  Before, the 64 vectors in front of the fused tile cost a separate
+// subtraction and a separate projection (k = 128: 448 vector reads per CGS2 instead of 384).
+template <int KH>
+__global__ __launch_bounds__(NT) void k_block_axpy_dot2(const double *__restrict__ V, int64_t vstride, int k,
+                                                        const double *__restrict__ h, double *__restrict__ w,
+                                                        const double *__restrict__ bm1, int64_t lvs, int64_t nv,
+                                                        double *__restrict__ partial) {
+    extern __shared__ double dyn2[];
+    double *sh = dyn2;                    // 2 KH coefficients (zero beyond k)
+    double *stash = dyn2 + 2 * KH;        // [KH][NT]: the second half of a point's basis values, column of this thread
+    __shared__ double sm[4][2 * KH];
+    for (int j = threadIdx.x; j < 2 * KH; j += NT) sh[j] = j < k ? h[j] : 0.0;
+    __syncthreads();
+    double acc0[KH], acc1[KH];
+#pragma unroll
+    for (int j = 0; j < KH; ++j) acc0[j] = 0.0, acc1[j] = 0.0;
+    double *mine = stash + threadIdx.x;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < nv; i += (int64_t)gridDim.x * NT) {
+        double v[KH];
+#pragma unroll
+        for (int j = 0; j < KH; ++j) v[j] = KH + j < k ? V[(int64_t)(KH + j) * vstride + i] : 0.0;
+        double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            s1 += sh[KH + j] * v[j];
+            mine[j * NT] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < KH; ++j) v[j] = V[(int64_t)j * vstride + i];
+        double s0 = 0.0;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) s0 += sh[j] * v[j];
+        const double wn = w[i] - (s0 + s1);
+        w[i] = wn;
+        const double x = wn * bm1[i % lvs];
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            acc0[j] += v[j] * x;
+            acc1[j] += mine[j * NT] * x;
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+        const double t0 = wave_sum(acc0[j]), t1 = wave_sum(acc1[j]);
+        if (lane == 0) sm[wid][j] = t0, sm[wid][KH + j] = t1;
+    }
+    __syncthreads();
+    if (threadIdx.x < k) {
+        const int j = threadIdx.x;
+        partial[(int64_t)j * gridDim.x + blockIdx.x] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+    }
+}
+
 // w -= sum_j h_j V_j on the main block; history slots of w receive the same correction
 // (reference axpby quirk) or the combination of the basis history (consistent mode).
 // `hh` (may be null): a second coefficient set used for the entries at or beyond blk2 (the history blocks of a sweep
@@ -898,12 +955,14 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
             // rounding, at two thirds of the traffic
             // (measured, CGS2 + norm + scale at 10^4 elements: k = 64: 6.29 -> 4.94 ms, 32: 3.28 -> 2.79, 16: 1.78 -> 1.88,
             // 8: 1.04 -> 1.46 — the fully unrolled KMAX = 64 kernel does all 128 FMAs whatever k — hence the lower bound)
-            static const int fuse_max = getenv("NLG_CGS2_FUSE_MAX") ? atoi(getenv("NLG_CGS2_FUSE_MAX")) : 64;
+            static const int fuse_max = getenv("NLG_CGS2_FUSE_MAX") ? atoi(getenv("NLG_CGS2_FUSE_MAX")) : 128;
             if (k >= 24 && fuse_max >= 24) {
                 // first subtraction and second projection in one sweep over the LAST kf <= 64 basis vectors
                 // (k_block_axpy_dot); the k0 = k - kf vectors before them are subtracted first and projected after
                 const nlg_vec *v0 = b->views[0];
-                const int kf = std::min(std::min(k, fuse_max), 64), k0 = k - kf;
+                // k <= 64: one register tile (k_block_axpy_dot<64>); up to 128: two tiles, the second parked in LDS (k_block_axpy_dot2<64>)
+                const int kf = std::min(std::min(k, fuse_max), 128) > 64 ? std::min(std::min(k, fuse_max), 128) : std::min(std::min(k, fuse_max), 64);
+                const int k0 = k - kf;
                 const int64_t nv = (int64_t)v0->ncomp * b->mesh->lvs;   // velocity (+ scalar) part; the pressure follows
                 const int G = 256;                                     // one block per CU (one wave per SIMD)
                 NLG_TRY(reduce_ws_reserve(ctx, k));
@@ -911,8 +970,19 @@ int basis_cgs2_dev(nlg_basis *b, int k, nlg_vec *w) {
                 const double *Vf = b->d + (int64_t)k0 * b->stride;
                 {
                     ProfScope ps(ctx, P_AXPYDOT);
-                    NLG_LAUNCH(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, Vf, b->stride, kf,
-                                       (const double *)(h + k0), w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
+                    if (kf > 64) {
+                        constexpr size_t lds2 = sizeof(double) * (2 * 64 + 64 * NT);
+                        static bool attr_set = false;
+                        if (!attr_set) {
+                            NLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_axpy_dot2<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                            attr_set = true;
+                        }
+                        NLG_LAUNCH(k_block_axpy_dot2<64>, dim3(G), dim3(NT), lds2, ctx->stream, Vf, b->stride, kf,
+                                           (const double *)(h + k0), w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
+                    } else {
+                        NLG_LAUNCH(k_block_axpy_dot<64>, dim3(G), dim3(NT), 0, ctx->stream, Vf, b->stride, kf,
+                                           (const double *)(h + k0), w->d, (const double *)b->mesh->d_bm1, b->mesh->lvs, nv, ctx->d_partial);
+                    }
                 }
                 {
                     ProfScope ps(ctx, P_BLOCKAXPY);

@@ -147,13 +147,13 @@ def test_scalar_fields_in_the_basis(gpu_ctx):
     assert np.max(np.abs(B.block_dot(k, w))) < 1e-13
 
 
-@pytest.mark.parametrize("k", [23, 24, 40, 64, 65, 100])
+@pytest.mark.parametrize("k", [23, 24, 40, 64, 65, 100, 128, 131])
 def test_cgs2_fused_sweep_matches_separate_kernels(gpu_ctx, k):
     """CGS2 (LightKrylov's double Gram-Schmidt) through `nlg_basis_cgs2` -- which for 24 <= k <= 64 fuses the
     first subtraction with the second projection (k_block_axpy_dot) -- against the same four passes made with the
     separate block_dot / block_axpy entry points: coefficients, the orthogonalised vector (velocity, pressure and the
-    restart-history blocks) and the norm.  k = 23 takes the unfused path and pins the comparison itself; above 64 the sweep
-    is fused over the last 64 vectors only."""
+    restart-history blocks) and the norm.  k = 23 takes the unfused path and pins the comparison itself; 64 < k <= 128 (round 4) takes
+    the two-tile sweep k_block_axpy_dot2 (second half of a point's basis values parked in LDS), above 128 the last 128 vectors are fused."""
     hm = box_mesh((3, 3, 2), 6, deform=0.03)
     gm = host.Mesh(gpu_ctx, hm)
     B = host.KrylovBasis(gm, k + 1)
@@ -221,3 +221,44 @@ def test_sampled_kernel_timing(gpu_ctx):
     assert n1 == 8 and n4 == 2 and t1 > 0 and t4 > 0
     assert host.check(lib.nlg_prof_sample(gpu_ctx.h, 1)) is None
     assert lib.nlg_prof_sample(gpu_ctx.h, 0) != 0          # stride < 1 is an error
+
+
+def test_small_mesh_pressure_kernels_agree_with_the_one_wave_kernels():
+    """Below NLG_SMALL_E local elements the pressure operator runs three waves per element (k_opgradt3w / k_opdiv3w, the strong-scaling
+    variants).  The same propagator application in two fresh processes -- variants on (default) and off (NLG_SMALL_E=0) -- must give the
+    same fields and, within a couple of iterations, the same pressure iteration count: the first build of k_opgradt3w let wave 0 write the
+    updated PCG direction in place while the other two waves were still reading it, which no parity test saw (the solve still converged,
+    to the same answer) and which doubled the iteration count of a 4-rank rehearsal."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+hm = box_mesh((9, 8, 8), 8, deform=0.05)
+ctx = host.Context(0); gm = host.Mesh(ctx, hm)
+X = [hm.x, hm.y, hm.z]
+gb = host.nek_dvector(gm)
+gb.set_field(0, hm.mask[0] * np.sin(X[1]) * np.cos(X[2])); gb.set_field(1, hm.mask[1] * 0.5 * np.sin(X[2]) * np.cos(X[0]))
+A = host.exptA_linop(0.05, gb, re=100.0, dt=0.01, torder=3, vtol=1e-10, ptol=1e-9, maxit_v=200, maxit_p=2000); A.init()
+v = host.nek_dvector(gm); v.rand(True, seed=5); w = host.nek_dvector(gm)
+A.matvec(v, w)
+st = A.stats()
+print("RESULT", st["p_iters"], st["v_iters"], " ".join("%%.15e" %% float(np.sum(np.abs(w.get_field(i)) * (1.0 + 0.001 * (np.arange(w.get_field(i).size) %% 977)))) for i in range(3)))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, val in (("on", None), ("off", "0")):
+        env = dict(os.environ)
+        env.pop("NLG_SMALL_E", None)
+        if val is not None:
+            env["NLG_SMALL_E"] = val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        ln = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1].split()
+        out[tag] = (int(ln[1]), int(ln[2]), [float(x) for x in ln[3:]])
+    (pa, va, ca), (pb, vb, cb) = out["on"], out["off"]
+    assert va == vb and abs(pa - pb) <= max(2, pb // 50), out
+    for a, b in zip(ca, cb):
+        assert abs(a - b) < 1e-7 * max(abs(b), 1e-30), out      # (solver tolerances 1e-10 / 1e-9: the two builds round differently)
