@@ -385,6 +385,10 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
     // Thread order: the general groups FIRST (corners and irregular valences: the longest chain of dependent loads in the kernel --
     // offsets, indices, values), then the quads, then the pairs.  At the end of the grid, where they used to be, their chain was the
     // kernel's tail: 17 us of a 50-us launch at 10^4 elements and the whole of a launch at 1300 (profiles/r04_E1300_counters.txt).
+    // (round 4: an XCD-contiguous block order -- cdna_hip_programming.md T1, every XCD walking one eighth of the list so that blocks which
+    //  share the lines at the seams of their runs share an L2 -- was measured: 54.5 -> 83 us per launch.  The dispatcher's round-robin
+    //  order spreads the eight XCDs over all memory channels at every moment; an eighth of the list per XCD is an eighth of the address
+    //  range per XCD, and the channels behind it saturate.  Not kept.)
     int64_t t = blockIdx.x * (int64_t)NT + threadIdx.x;
     const int64_t nrest = ngroups - npairs - nquads;
     if (t < nrest) {
