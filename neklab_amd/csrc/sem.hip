@@ -397,7 +397,8 @@ __global__ __launch_bounds__(NT) void k_gs(const int *__restrict__ off, const in
         // another round.  One at a time, every copy cost two serialised round trips (index, value).
         const int64_t g = npairs + nquads + t;
         const int b = off[g], e = off[g + 1];
-        constexpr int CH = 8;
+        constexpr int CH = 8;   // (90 registers = five waves per SIMD for every thread of the kernel; CH = 4 gives 54 registers and eight waves -- and a SLOWER
+                                // kernel, 4.91 -> 5.16 ms of gather-scatter per step: more waves in flight evict each other's lines)
         int i0[CH];
         double s[NF];
 #pragma unroll
@@ -4718,6 +4719,10 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
                     }
                     return a[0] < b[0];
                 });
+                // (round 4: the faces in CHAIN order -- face of e towards p, then the face of p opposite to it, ... -- so that the two users of
+                //  a slab line, which holds the rows of two opposite faces, are lanes of one block: built from the pair list for any conforming
+                //  mesh, parity green, 4.91 -> 4.84 ms of gather-scatter per step: the second fetch of such a line was coming from the Infinity
+                //  Cache, not from HBM.  Not kept.)
                 std::vector<int> off2{0}, idx2;
                 for (auto &v : gl) {
                     idx2.insert(idx2.end(), v.begin(), v.end());
