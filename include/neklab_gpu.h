@@ -290,7 +290,9 @@ int nlg_linop_rmatvec(nlg_linop *op, const nlg_vec *vec_in, nlg_vec *vec_out);
  * convergence flag per vector: every vector gets exactly the iteration of nlg_linop_matvec), with the operator
  * applications of an iteration issued together, so that metric factors, base-flow fields of the convective term and
  * preconditioner data are read once per iteration for all vectors.  Each vector keeps its restart-history protocol
- * (replay of vec_in's history, history of vec_out).  Not with cfg.ifheat or a wavenumber projection. */
+ * (replay of vec_in's history, history of vec_out).  Round 4: also with cfg.ifheat (the scalar's solve is lane-batched like the
+ * velocity's: exponential_propagator_temp.f90:15-60, :62-107) and with a wavenumber projection (exptA_proj_linop: every projection
+ * of the single-vector path applied lane by lane against the operator's tables, exponential_propagator_proj.f90:30-75). */
 int nlg_linop_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vec_in, nlg_vec *const *vec_out, int transpose);
 /* Newton-Krylov base-flow solver.
  * nonlinear_map  src/systems/fixed_point.f90:4-38 : vec_out = Phi_tau(vec_in) - vec_in with the nonlinear integrator,

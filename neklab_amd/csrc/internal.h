@@ -386,7 +386,7 @@ int pprec_reserve_lanes(nlg_mesh *m, int nl);
 void pprec_free(nlg_mesh *m);
 
 // ---- lns.hip
-bool linop_can_block(const nlg_linop *op);   // the multi-vector stepper covers this operator (no Boussinesq coupling / projection)
+bool linop_can_block(const nlg_linop *op);   // the multi-vector stepper covers this operator (round 4: also with the Boussinesq coupling and the wavenumber projection)
 
 // ---- halo.hip ----
 int halo_setup(nlg_mesh *m, const int64_t *glo_num);

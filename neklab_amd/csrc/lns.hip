@@ -1654,13 +1654,14 @@ int store_state(nlg_linop *op, nlg_vec *v, int irst) {
     return 0;
 }
 
-// no-op unless nlg_linop_set_projection has been called
-int project_alpha(nlg_linop *op, int slot = 0) {
-    if (op->proj_nlines == 0) return 0;
-    nlg_mesh *m = op->mesh;
-    const unsigned grid = (unsigned)((op->proj_nlines + NT / 64 - 1) / (NT / 64));
-    F3 u = f3(op->ubuf[slot], m->dim);
-    if (op->proj_gslot) {
+// no-op unless nlg_linop_set_projection has been called.  `tab` holds the projection tables (the operator itself), `dat` the state that is
+// projected: the operator again, or one of its lanes in a block step
+int project_alpha(const nlg_linop *tab, nlg_linop *dat, int slot) {
+    if (tab->proj_nlines == 0) return 0;
+    nlg_mesh *m = tab->mesh;
+    const unsigned grid = (unsigned)((tab->proj_nlines + NT / 64 - 1) / (NT / 64));
+    F3 u = f3(dat->ubuf[slot], m->dim);
+    if (tab->proj_gslot) {
         // several ranks: partial sums -> global slots -> all-reduce -> apply (the reference's planar_avg is a global
         // operation, exponential_propagator_proj.f90:146-169)
         hipStream_t st = m->ctx->stream;
@@ -1668,58 +1669,60 @@ int project_alpha(nlg_linop *op, int slot = 0) {
                         const double *cv, const double *sv, const double *iden, F3 f) -> int {
             const unsigned g = (unsigned)((nl + NT / 64 - 1) / (NT / 64));
             const int64_t cnt = nglob * 2 * nf;
-            NLG_HIP(hipMemsetAsync(op->proj_glob, 0, sizeof(double) * (size_t)cnt, st));
+            NLG_HIP(hipMemsetAsync(tab->proj_glob, 0, sizeof(double) * (size_t)cnt, st));
             CF3 cf = {{f.p[0], f.p[1], f.p[2]}};
             if (nl > 0) {
                 if (nf == 3)
-                    NLG_LAUNCH(k_proj_sums<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                    NLG_LAUNCH(k_proj_sums<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, tab->proj_glob);
                 else if (nf == 2)
-                    NLG_LAUNCH(k_proj_sums<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                    NLG_LAUNCH(k_proj_sums<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, tab->proj_glob);
                 else
-                    NLG_LAUNCH(k_proj_sums<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, op->proj_glob);
+                    NLG_LAUNCH(k_proj_sums<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, wt, cv, sv, cf, tab->proj_glob);
             }
-            NLG_TRY(allreduce_sum(m->ctx, op->proj_glob, (int)cnt));
+            NLG_TRY(allreduce_sum(m->ctx, tab->proj_glob, (int)cnt));
             if (nl > 0) {
                 if (nf == 3)
-                    NLG_LAUNCH(k_proj_apply<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                    NLG_LAUNCH(k_proj_apply<3>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)tab->proj_glob, f);
                 else if (nf == 2)
-                    NLG_LAUNCH(k_proj_apply<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                    NLG_LAUNCH(k_proj_apply<2>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)tab->proj_glob, f);
                 else
-                    NLG_LAUNCH(k_proj_apply<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)op->proj_glob, f);
+                    NLG_LAUNCH(k_proj_apply<1>, dim3(g), dim3(NT), 0, st, nl, off, idx, gs, cv, sv, iden, (const double *)tab->proj_glob, f);
             }
             return 0;
         };
-        NLG_TRY(pass(m->dim, op->proj_nlines, op->proj_off, op->proj_idx, op->proj_gslot, op->proj_nglob, m->d_bm1, op->proj_cv, op->proj_sv,
-                     op->proj_iden, u));
-        if (op->proj_gslot2 && slot == 0) {
-            F3 pp = {{op->p, nullptr, nullptr}};
-            NLG_TRY(pass(1, op->proj_nlines2, op->proj_off2, op->proj_idx2, op->proj_gslot2, op->proj_nglob2, m->d_bm2, op->proj_cv2,
-                         op->proj_sv2, op->proj_iden2, pp));
+        NLG_TRY(pass(m->dim, tab->proj_nlines, tab->proj_off, tab->proj_idx, tab->proj_gslot, tab->proj_nglob, m->d_bm1, tab->proj_cv, tab->proj_sv,
+                     tab->proj_iden, u));
+        if (tab->proj_gslot2 && slot == 0) {
+            F3 pp = {{dat->p, nullptr, nullptr}};
+            NLG_TRY(pass(1, tab->proj_nlines2, tab->proj_off2, tab->proj_idx2, tab->proj_gslot2, tab->proj_nglob2, m->d_bm2, tab->proj_cv2,
+                         tab->proj_sv2, tab->proj_iden2, pp));
         }
         NLG_HIP(hipGetLastError());
         return 0;
     }
     if (m->dim == 3)
-        NLG_LAUNCH(k_proj_alpha<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
-                           (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
-                           (const double *)op->proj_iden, u);
+        NLG_LAUNCH(k_proj_alpha<3>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)tab->proj_nlines, (const int *)tab->proj_off,
+                           (const int *)tab->proj_idx, (const double *)m->d_bm1, (const double *)tab->proj_cv, (const double *)tab->proj_sv,
+                           (const double *)tab->proj_iden, u);
     else
-        NLG_LAUNCH(k_proj_alpha<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines, (const int *)op->proj_off,
-                           (const int *)op->proj_idx, (const double *)m->d_bm1, (const double *)op->proj_cv, (const double *)op->proj_sv,
-                           (const double *)op->proj_iden, u);
-    if (op->proj_nlines2 > 0 && slot == 0) {
+        NLG_LAUNCH(k_proj_alpha<2>, dim3(grid), dim3(NT), 0, m->ctx->stream, (int64_t)tab->proj_nlines, (const int *)tab->proj_off,
+                           (const int *)tab->proj_idx, (const double *)m->d_bm1, (const double *)tab->proj_cv, (const double *)tab->proj_sv,
+                           (const double *)tab->proj_iden, u);
+    if (tab->proj_nlines2 > 0 && slot == 0) {
         // the pressure is part of the state the integrator starts from (lagged pressure of the correction scheme) but not
         // of the inner product: left unprojected it is a subspace the Arnoldi norm cannot see (observed: a spurious
         // |mu| = 1.41 for plane Poiseuille flow at alpha = 2 instead of 0.945)
-        const unsigned grid2 = (unsigned)((op->proj_nlines2 + NT / 64 - 1) / (NT / 64));
-        F3 pp = {{op->p, nullptr, nullptr}};
-        NLG_LAUNCH(k_proj_alpha<1>, dim3(grid2), dim3(NT), 0, m->ctx->stream, (int64_t)op->proj_nlines2, (const int *)op->proj_off2,
-                           (const int *)op->proj_idx2, (const double *)m->d_bm2, (const double *)op->proj_cv2, (const double *)op->proj_sv2,
-                           (const double *)op->proj_iden2, pp);
+        const unsigned grid2 = (unsigned)((tab->proj_nlines2 + NT / 64 - 1) / (NT / 64));
+        F3 pp = {{dat->p, nullptr, nullptr}};
+        NLG_LAUNCH(k_proj_alpha<1>, dim3(grid2), dim3(NT), 0, m->ctx->stream, (int64_t)tab->proj_nlines2, (const int *)tab->proj_off2,
+                           (const int *)tab->proj_idx2, (const double *)m->d_bm2, (const double *)tab->proj_cv2, (const double *)tab->proj_sv2,
+                           (const double *)tab->proj_iden2, pp);
     }
     NLG_HIP(hipGetLastError());
     return 0;
 }
+
+int project_alpha(nlg_linop *op, int slot = 0) { return project_alpha(op, op, slot); }
 
 int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     NLG_CHECK(op && vin && vout, "exptA matvec: NULL argument");
@@ -2248,7 +2251,6 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
     NLG_CHECK(op->inited, "exptA block matvec: nlg_linop_init has not been called");
     NLG_CHECK(!op->is_lane, "exptA block matvec: called on a lane");
     nlg_mesh *m = op->mesh;
-    NLG_CHECK(op->proj_nlines == 0, "exptA block matvec: the wavenumber projection runs through the single-vector path");
     const int want_scal = op->cfg.ifheat ? 1 : 0;
     for (int v = 0; v < s; ++v) {
         NLG_CHECK(vin[v] && vout[v] && vin[v]->mesh == m && vout[v]->mesh == m, "exptA block matvec: vector %d NULL or on a different mesh", v);
@@ -2273,15 +2275,20 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
         ln->adjoint = adjoint;
         ln->nproj = 0;
         NLG_TRY(load_state(ln, vin[v], 0));
+        NLG_TRY(project_alpha(op, ln, 0));   // exptA_proj_linop: the projections of do_matvec, lane by lane against the owner's tables
     }
     const Lanes L{ops, s};
     for (int istep = 1; istep <= op->nsteps; ++istep) {
         NLG_TRY(advance(L));
         if (istep <= nrst)
             for (int v = 0; v < s; ++v)
-                if (vin[v]->nrst > 0) NLG_TRY(load_state(ops[v], vin[v], istep));   // get_rst, exponential_propagator.f90:129-142
+                if (vin[v]->nrst > 0) {
+                    NLG_TRY(load_state(ops[v], vin[v], istep));   // get_rst, exponential_propagator.f90:129-142
+                    NLG_TRY(project_alpha(op, ops[v], 0));
+                }
     }
     for (int v = 0; v < s; ++v) {
+        for (int slot = 0; slot < 3; ++slot) NLG_TRY(project_alpha(op, ops[v], slot));   // final state and the lagged levels (see do_matvec)
         NLG_TRY(nlg_vec_zero(vout[v]));
         NLG_TRY(store_state(ops[v], vout[v], 0));
     }
@@ -2304,7 +2311,7 @@ int do_matvec_block(nlg_linop *op, int s, const nlg_vec *const *vin, nlg_vec *co
 }  // namespace
 
 namespace nlg {
-bool linop_can_block(const nlg_linop *op) { return op && op->proj_nlines == 0 && !op->is_lane; }
+bool linop_can_block(const nlg_linop *op) { return op && !op->is_lane; }
 }
 
 extern "C" {

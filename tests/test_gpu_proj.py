@@ -97,3 +97,36 @@ def test_poiseuille_alpha2_orr_sommerfeld(gpu_ctx, tmp_path):
     assert abs(abs(m) - abs(mu_os)) < 5e-4 and abs(m - mu_os) < 1e-3, (m, mu_os)      # measured 2.4e-4 / 2.5e-4
     assert abs(m) < 0.96                                              # the alpha = 1 mode (|mu| = 1.0022) is projected out
     assert all(abs(x) < 0.96 for x in mu)                             # and no spurious mode of the extended (state, history) map
+
+
+@pytest.mark.parametrize("dim,nel,s", [(2, (4, 3), 2), (3, (3, 2, 2), 3)])
+def test_projected_matvec_block_equals_single_matvecs(gpu_ctx, dim, nel, s):
+    """The lane-batched propagator with the wavenumber projection (round 4; exptA_proj_linop, exponential_propagator_proj.f90:30-75): every
+    projection of the single-vector path -- initial condition, replayed history states, final state and its lagged levels -- is applied lane by
+    lane against the operator's tables; s vectors advanced together give what s single matvecs give, histories included."""
+    hm, sem, gm = channel(gpu_ctx, dim, nel, 6)
+    gb = host.nek_dvector(gm)
+    gb.set_field(0, 1.0 - sem.X[1] ** 2)
+    A = host.exptA_proj_linop(0.1, gb, 2.0, idir=1, re=200.0, torder=3, vtol=1e-13, ptol=1e-13, maxit_v=400, maxit_p=4000)
+    A.init()
+    vin = []
+    for v in range(s):
+        x = host.nek_dvector(gm)
+        x.rand(True, seed=20 + v)
+        x.scal(10.0 ** (-v))
+        if v % 2 == 1:                    # odd lanes carry a restart history
+            y = host.nek_dvector(gm)
+            A.matvec(x, y)
+            x = y
+        vin.append(x)
+    single = [host.nek_dvector(gm) for _ in range(s)]
+    for v in range(s):
+        A.matvec(vin[v], single[v])
+    blk = [host.nek_dvector(gm) for _ in range(s)]
+    A.matvec_block(vin, blk)
+    for v in range(s):
+        sc = max(np.abs(single[v].get_field(i)).max() for i in range(dim))
+        for r in range(3):
+            for i in range(dim):
+                assert np.max(np.abs(blk[v].get_field(i, r) - single[v].get_field(i, r))) < 1e-11 * sc, (v, r, i)
+            assert np.max(np.abs(blk[v].get_field(host.PR, r) - single[v].get_field(host.PR, r))) < 1e-9 * max(sc, np.abs(single[v].get_field(host.PR, r)).max())
