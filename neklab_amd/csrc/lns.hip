@@ -221,6 +221,45 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
     }
 }
 
+// single-reduction PCG: p <- u + beta p ; s <- w + beta s ; x += alpha p ; r -= alpha s ; u = pc r  (u lives in `z`); partial (r, u)_ipw, (r, r)_nw.
+// The first update of a solve (ITERS == 1 after the logic) takes p = u, s = w whatever the buffers held.
+template <int NF>
+__global__ __launch_bounds__(NT) void k_cg_update_sr(const double *s, int64_t n, F3 x, F3 r, F3 z, F3 p, F3 sd, CF3 w, CF3 pc,
+                                                     const double *ipw, const double *nw, double *partial, int64_t ld) {
+    __shared__ double sm[12];
+    const int64_t lo = lane_lo(ld);
+    s += lo, x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), p = lane_f3(p, lo), sd = lane_f3(sd, lo), w = lane_f3(w, lo), partial += lo;
+    if (s[S_DONE] != 0.0) return;
+    const double alpha = s[S_ALPHA], beta = s[S_BETA];
+    const bool first = s[S_ITERS] == 1.0;
+    double a = 0.0, b = 0.0, c3 = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double uv = z.p[c][i], wv = w.p[c][i];
+            const double pv = first ? uv : uv + beta * p.p[c][i];
+            const double sv = first ? wv : wv + beta * sd.p[c][i];
+            p.p[c][i] = pv;
+            sd.p[c][i] = sv;
+            x.p[c][i] += alpha * pv;
+            double rv = r.p[c][i] - alpha * sv;
+            const double pcv = pc.p[c][i];
+            if (pcv == 0.0) rv = 0.0;   // Dirichlet dof (the preconditioner carries the mask): w is not masked
+            r.p[c][i] = rv;
+            const double zv = pcv * rv;
+            z.p[c][i] = zv;
+            a += rv * zv * wi;
+            b += rv * rv * wn;
+        }
+    }
+    block_sum3(a, b, c3, sm);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = a;
+        partial[NB + blockIdx.x] = b;
+    }
+}
+
 // partial sums of (r,z)_ipw and sum(z) when z was produced by a preconditioning operator
 // `xc`/`npe` (xc may be null): the coarse-grid part of z, one value per element of npe points, kept separate so
 // that the coarse branch can run concurrently with the element-wise solves: z_total = z + xc[i / npe]
@@ -287,6 +326,23 @@ __device__ __forceinline__ void cg_post_logic(double *s, int mode, double tol2, 
         s[S_PW] = s[S_T0];
         s[S_WMEAN] = s[S_T1] * inv_n;
         s[S_ALPHA] = s[S_RZ] / s[S_T0];
+    } else if (mode == 4) {
+        // single-reduction PCG (Chronopoulos & Gear 1989): T0 = (w, u) with w = A u, u = M^-1 r;  T1 = (r, u);  T2 = |r|^2 -- all of the
+        // CURRENT residual, in one reduction.  The convergence test standard PCG makes before applying the operator comes one operator
+        // application late here (the price of the merged reduction): one wasted application per solve.
+        if (s[S_ITERS] > 0.0 && ((use_tol && s[S_T2] < tol2) || s[S_ITERS] >= (double)maxit || s[S_T2] <= kFloor2 * s[S_RN20])) {
+            s[S_RN2] = s[S_T2];
+            s[S_DONE] = 1.0;
+            return;
+        }
+        const bool first = s[S_ITERS] == 0.0;
+        const double beta = first ? 0.0 : s[S_T1] / s[S_RZ];
+        s[S_ALPHA] = first ? s[S_T1] / s[S_T0] : s[S_T1] / (s[S_T0] - beta * s[S_T1] / s[S_ALPHA]);
+        s[S_BETA] = beta;
+        s[S_RZ] = s[S_T1];
+        s[S_RN2] = s[S_T2];
+        s[S_PW] = s[S_T0];
+        s[S_ITERS] += 1.0;
     } else {
         s[S_BETA] = s[S_T0] / s[S_RZ];
         s[S_RZ] = s[S_T0];
@@ -738,6 +794,9 @@ struct nlg_linop {
     double *p = nullptr;
     // work
     double *rhs[3] = {}, *x[3] = {}, *z[3] = {}, *pv[3] = {}, *w[3] = {}, *gp[3] = {};
+    // single-reduction PCG (Chronopoulos-Gear; several ranks, NLG_PCG_SINGLE_RED): the search direction and its image as recurrences
+    bool use_sr = false;
+    double *cgs[3] = {}, *tcgs = nullptr;
     bool rhs_in_xp = false;   // adv_a -> helm_problem: the right-hand side already is masked and in the slab-permuted layout
     double *pr_r = nullptr, *pr_x = nullptr, *pr_z = nullptr, *pr_p = nullptr, *pr_w = nullptr;
     double *pr_b = nullptr;    // the right-hand side the pressure PCG started from (after the projection): A x = b - r afterwards
@@ -826,6 +885,10 @@ void lane_buffers(nlg_linop *op, F f) {
     }
     if (op->cfg.ifheat)
         for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) f(v, m->lvs);
+    if (op->use_sr) {
+        for (int c = 0; c < dim; ++c) f(&op->cgs[c], m->lvs);
+        if (op->cfg.ifheat) f(&op->tcgs, m->lvs);
+    }
     for (double **q : {&op->p, &op->pr_r, &op->pr_x, &op->pr_z, &op->pr_p, &op->pr_w, &op->pr_b}) f(q, m->lps);
     if (op->cfg.pproj) {
         f(&op->prX, (int64_t)PROJ_L * m->lps);
@@ -850,6 +913,7 @@ void lane_bind(nlg_linop *owner, nlg_linop *ln, int v) {
     double *base = owner->slab + (int64_t)v * owner->slab_ld;
     const bool heat = ln->cfg.ifheat;
     ln->cfg.ifheat = owner->cfg.ifheat;   // (same buffer list as the owner's)
+    ln->use_sr = owner->use_sr;
     lane_buffers(ln, [&](double **p, int64_t len) {
         *p = base + off;
         off += round_up(len, kAlign);
@@ -927,6 +991,10 @@ struct CGProblem {
     int rz_n = 0;
     const double *rr_part = nullptr;   // [rr_n]: sum r^2 nw, written by `precond`, which then also performs the update
     int rr_n = 0;                      // x += alpha p, r -= alpha (w - wmean) of the iteration (no k_cg_update launch)
+    // single-reduction variant (pointwise preconditioner only): `sd` holds s = A p by recurrence, `apply_plain` computes w = A z (the
+    // preconditioned residual itself, no direction update inside) and its first-stage sums (z, w) into pw_part
+    double *const *sd = nullptr;
+    std::function<int()> apply_plain;
 };
 
 // Device-scalar PCG for P.nl lanes.  `apply` computes w = A p for ALL lanes (stream-ordered, gated by each lane's s[S_DONE]).
@@ -959,6 +1027,46 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         return 0;
     };
     launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, lgrid(g, nl), st, P.n, x, r, z, pc, P.ipw, P.nw, partial, ld);
+    if (P.sd && P.apply_plain && !P.precond && P.pw_part) {
+        // ---- single-reduction PCG (Chronopoulos-Gear): ONE reduction per iteration carries (w, u), (r, u) and |r|^2; several ranks: one
+        // all-reduce instead of two.  u = M^-1 r lives in z, p and s = A p are recurrences.  Same iterates as the loop below in exact
+        // arithmetic; the convergence test lags one operator application (cg_post_logic mode 4).
+        NLG_TRY(reduce_post(rd_std, 3, 0, 0));
+        NLG_LAUNCH(k_cg_post, lgrid(1, nl), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n, ld, (const double *)nullptr, 0);
+        const Red rd_sr = {{P.pw_part, partial, partial + NB}, {P.pw_n, g, g}};
+        F3 sdv = f3(P.sd, nf);
+        auto body_sr = [&]() -> int {
+            NLG_TRY(P.apply_plain());
+            NLG_TRY(reduce_post(rd_sr, 3, 1, 4));
+            ProfScope pu(ctx, P_CGUPDATE);
+            launch_nf(nf, k_cg_update_sr<1>, k_cg_update_sr<2>, k_cg_update_sr<3>, lgrid(g, nl), st, (const double *)s, P.n, x, r, z, p, sdv, cw,
+                      pc, P.ipw, P.nw, partial, ld);
+            return 0;
+        };
+        int launched = 0;
+        while (true) {
+            int todo = launched == 0 ? P.chunk + 1 : P.chunk_next;   // (+ 1: the iteration that notices the convergence)
+            if (launched + todo > P.maxit + 1) todo = P.maxit + 1 - launched;
+            for (int it = 0; it < todo; ++it) NLG_TRY(body_sr());
+            launched += todo;
+            NLG_HIP(hipGetLastError());
+            for (int v = 0; v < nl; ++v)
+                NLG_HIP(hipMemcpyAsync(op->h_s + (size_t)v * S_N, s + (int64_t)v * ld, sizeof(double) * S_N, hipMemcpyDeviceToHost, st));
+            NLG_HIP(hipStreamSynchronize(st));
+            bool all_done = true;
+            for (int v = 0; v < nl; ++v) all_done = all_done && op->h_s[(size_t)v * S_N + S_DONE] != 0.0;
+            if (all_done || launched >= P.maxit + 1) break;
+        }
+        for (int v = 0; v < nl; ++v) {
+            const double *h = op->h_s + (size_t)v * S_N;
+            if (!std::isfinite(h[S_RN2])) {
+                set_error("PCG (single reduction) diverged (residual is not finite) after %d iterations (lane %d of %d)", (int)h[S_ITERS], v, nl);
+                return 1;
+            }
+            iters_out[v] = (int)h[S_ITERS];
+        }
+        return 0;
+    }
     const double *xc = nullptr;
     Red rd_rz = rd_std;
     if (P.precond) {
@@ -1130,6 +1238,15 @@ int helm_finish(const Lanes &L, const HelmSolve &H, const int *iters) {
 int helm_solve(const Lanes &L, int order, double h2) {
     HelmSolve H;
     NLG_TRY(helm_problem(L, order, h2, H));
+    if (L.op()->use_sr) {
+        nlg_linop *op = L.op();
+        nlg_mesh *m = op->mesh;
+        H.P.sd = op->cgs;
+        H.P.apply_plain = [&, op, m]() -> int {   // w = QQ^T (nu A + h2 B) z and the first-stage sums of (z, w): no direction update inside
+            NLG_TRY(sem_axhelm(m, op->z, op->w, m->dim, H.nu, H.h2, H.pw_part, nullptr, nullptr, op->d_s + S_DONE, H.xp, L.nl, L.ld()));
+            return sem_gs(m, op->w, m->dim, op->d_s + S_DONE, H.xp ? LAYOUT_XP : LAYOUT_NAT, L.nl, L.ld(), L.ld());
+        };
+    }
     auto apply = [&](double *) -> int { return helm_apply(L, H); };
     int iters[kMaxLanes] = {};
     NLG_TRY(run_pcg(L.op(), H.P, apply, iters));
@@ -1221,6 +1338,14 @@ int heat_step(const Lanes &L, int k, double b0) {
         NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE, LAYOUT_NAT, nl, ld, ld));
         return 0;
     };
+    double *sdt[1] = {op->tcgs};
+    if (op->use_sr) {
+        P.sd = sdt;
+        P.apply_plain = [&]() -> int {
+            NLG_TRY(sem_axhelm(m, z, tw, 1, h1, h2, op->d_part, nullptr, nullptr, op->d_s + S_DONE, false, nl, ld));
+            return sem_gs(m, tw, 1, op->d_s + S_DONE, LAYOUT_NAT, nl, ld, ld);
+        };
+    }
     int iters[kMaxLanes] = {};
     NLG_TRY(run_pcg(op, P, apply, iters));
     for (int v = 0; v < nl; ++v) {
@@ -1947,6 +2072,11 @@ int nlg_linop_init(nlg_linop *op) {
         NLG_TRY(lalloc(op, &op->nwp, m->lps));
         NLG_HIP(hipHostMalloc(&op->h_s, sizeof(double) * kMaxLanes * S_N, hipHostMallocDefault));
         NLG_TRY(reduce_ws_reserve(ctx, 4));
+        // single-reduction PCG for the pointwise-preconditioned solves, opt-in (NLG_PCG_SINGLE_RED=1; decided before the slab is laid
+        // out: it needs one more vector per solve).  One all-reduce per iteration instead of two, for two more vector streams per
+        // iteration: measured +9 % per time step on one rank at 10,240 elements, +3 % at 1,300, and 23 of 454 collectives per time step
+        // fewer on 2 ranks -- it pays only where an all-reduce costs more than ~15 us, which this pool cannot measure
+        op->use_sr = getenv("NLG_PCG_SINGLE_RED") && atoi(getenv("NLG_PCG_SINGLE_RED")) != 0;
         NLG_TRY(slab_ensure(op, 1));   // the work buffers of one lane; a block matvec grows the slab on first use
     }
     double *U[3] = {op->baseflow->vel(0), op->baseflow->vel(1), dim == 3 ? op->baseflow->vel(2) : nullptr};

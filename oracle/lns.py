@@ -130,6 +130,44 @@ class ExptA:
         self.stats["v_iters"] += it
         return x
 
+    def pcg_helm_single_reduction(self, b, h2):
+        """The twin of run_pcg's single-reduction branch (csrc/lns.hip, cg_post_logic mode 4): Chronopoulos & Gear's PCG, in which (w, u),
+        (r, u) and |r|^2 -- u = M^-1 r, w = A u -- come from ONE reduction per iteration and p, s = A p are recurrences.  Same iterates as
+        pcg_helm in exact arithmetic; the convergence test comes one operator application late.  Returns (x, iterations)."""
+        s, cfg = self.sem, self.cfg
+        dim = s.dim
+        minv = self.hdiag_inv(h2)
+        wnorm = s.binvm1 * s.vmult / s.volvm1
+        x = [np.zeros(s.shape1) for _ in range(dim)]
+        r = [bi.copy() for bi in b]
+        u = [s.mask[i] * minv * r[i] for i in range(dim)]
+        p = [None] * dim
+        sv = [None] * dim
+        maxit = cfg.fixed_iters_v if cfg.fixed_iters_v > 0 else cfg.maxit_v
+        rn2_0 = sum(np.sum(r[i] * r[i] * wnorm) for i in range(dim))
+        if (cfg.fixed_iters_v <= 0 and rn2_0 < cfg.vtol ** 2) or maxit <= 0 or rn2_0 <= 0.0:
+            return x, 0
+        it, gamma_old, alpha = 0, None, None
+        while True:
+            w = self.helm_apply(u, h2)
+            delta = sum(np.sum(u[i] * w[i] * s.vmult) for i in range(dim))          # the three sums of ONE reduction
+            gamma = sum(np.sum(r[i] * u[i] * s.vmult) for i in range(dim))
+            rn2 = sum(np.sum(r[i] * r[i] * wnorm) for i in range(dim))
+            if it > 0 and ((cfg.fixed_iters_v <= 0 and rn2 < cfg.vtol ** 2) or it >= maxit or rn2 <= FLOOR2 * rn2_0):
+                break
+            beta = 0.0 if it == 0 else gamma / gamma_old
+            alpha = gamma / delta if it == 0 else gamma / (delta - beta * gamma / alpha)
+            gamma_old = gamma
+            it += 1
+            for i in range(dim):
+                p[i] = u[i].copy() if it == 1 else u[i] + beta * p[i]
+                sv[i] = w[i].copy() if it == 1 else w[i] + beta * sv[i]
+                x[i] += alpha * p[i]
+                r[i] -= alpha * sv[i]
+                r[i] = np.where(s.mask[i] == 0.0, 0.0, r[i])
+                u[i] = s.mask[i] * minv * r[i]
+        return x, it
+
     def pcg_heat(self, b, h1, h2):
         """Jacobi-PCG for the scalar Helmholtz problem tmask QQ^T (h1 A + h2 B) x = b (same stopping rule as the velocity)."""
         s, cfg = self.sem, self.cfg

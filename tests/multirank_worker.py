@@ -156,6 +156,7 @@ def run(rank, world, segment, outdir, case):
         return run_cylinder(rank, world, segment, outdir, case)
     base, _, mult = case.partition("@")          # "box3d@2" with world 1: the global mesh of the 2-rank run
     base = base.replace("+ovl", "")              # "+ovl": the same case with NLG_HALO_OVERLAP=1 in the environment (set by the test)
+    base = base.replace("+sr", "")               # "+sr": NLG_PCG_SINGLE_RED=1, the one-reduction PCG of the velocity / scalar solves
     nel, n, periodic, pprecond = CASES[base]
     nel = tuple(nel[:-1]) + (nel[-1] * int(mult or 1),)
     dim = len(nel)

@@ -340,3 +340,23 @@ def test_block_cgs2_deflation_is_scale_free_and_sees_the_span_of_the_basis():
     coef = block_cgs2(V, 4, 2)
     assert np.max(np.abs(coef[:4] - C)) < 1e-12 and np.all(np.diag(coef[4:]) == 0.0)
     assert V[4].norm() == 0.0 and V[5].norm() == 0.0
+
+
+def test_single_reduction_pcg_twin_matches_the_standard_pcg():
+    """oracle/lns.py pcg_helm_single_reduction (the twin of run_pcg's Chronopoulos-Gear branch, csrc/lns.hip cg_post_logic mode 4) against
+    pcg_helm on the Helmholtz problem of a time step: same solution to rounding, same iteration count (the merged reduction changes when the
+    convergence is NOTICED, not the iterates)."""
+    from oracle.lns import ExptA, LNSConfig
+    sem = SEM(box_mesh((3, 2, 2), 5, periodic=(True, False, False), deform=0.04))
+    U = [sem.mask[i] * (1.0 if i == 0 else 0.0) * np.cos(sem.X[1]) for i in range(3)]
+    A = ExptA(sem, U, LNSConfig(tau=0.02, re=40.0, torder=3, dt=0.01, vtol=1e-12, ptol=1e-12, maxit_v=200, maxit_p=2000))
+    rng = np.random.default_rng(2)
+    b = [sem.mask[i] * sem.gs(sem.bm1 * rng.standard_normal(sem.shape1)) for i in range(3)]
+    h2 = 11.0 / 6.0 / 0.01
+    it0 = A.stats["v_iters"]
+    x = A.pcg_helm(b, h2)
+    its = A.stats["v_iters"] - it0
+    y, its_sr = A.pcg_helm_single_reduction(b, h2)
+    assert its_sr == its and its > 3
+    sc = max(np.abs(a).max() for a in x)
+    assert max(np.abs(a - c).max() for a, c in zip(x, y)) < 1e-12 * sc

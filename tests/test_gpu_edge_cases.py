@@ -262,3 +262,48 @@ print("RESULT", st["p_iters"], st["v_iters"], " ".join("%%.15e" %% float(np.sum(
     assert va == vb and abs(pa - pb) <= max(2, pb // 50), out
     for a, b in zip(ca, cb):
         assert abs(a - b) < 1e-7 * max(abs(b), 1e-30), out      # (solver tolerances 1e-10 / 1e-9: the two builds round differently)
+
+
+def test_single_reduction_pcg_matches_the_two_reduction_pcg():
+    """NLG_PCG_SINGLE_RED=1 (the default with several ranks): the velocity and scalar solves run Chronopoulos & Gear's PCG -- one reduction per
+    iteration carrying (w, u), (r, u) and |r|^2, p and s = A p as recurrences (csrc/lns.hip cg_post_logic mode 4; oracle twin
+    oracle/lns.py pcg_helm_single_reduction).  The same propagator application in two processes, switch on and off: the same fields to the
+    solver tolerance, the same Helmholtz iteration counts (the convergence is noticed one operator application later, the iterates
+    are the same), direct and with the temperature coupling."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+heat = len(sys.argv) > 1 and sys.argv[1] == "heat"
+hm = box_mesh((4, 3, 3), 8, deform=0.05)
+ctx = host.Context(0); gm = host.Mesh(ctx, hm)
+X = [hm.x, hm.y, hm.z]
+gb = host.nek_dvector(gm, 1 if heat else 0)
+gb.set_field(0, hm.mask[0] * np.sin(X[1]) * np.cos(X[2])); gb.set_field(1, hm.mask[1] * 0.5 * np.sin(X[2]) * np.cos(X[0]))
+kw = dict(ifheat=1, conductivity=0.3, rhocp=1.5, buoy=(0.0, 5.0, 0.0)) if heat else {}
+if heat: gb.set_field(host.THETA, 1.0 - X[1] / hm.lengths[1])
+A = host.exptA_linop(0.05, gb, re=100.0, dt=0.01, torder=3, vtol=1e-11, ptol=1e-10, maxit_v=200, maxit_p=2000, **kw); A.init()
+v = host.nek_dvector(gm, 1 if heat else 0); v.rand(True, seed=5); w = host.nek_dvector(gm, 1 if heat else 0)
+A.matvec(v, w)
+st = A.stats()
+fields = list(range(3)) + ([host.THETA] if heat else [])
+print("RESULT", st["v_iters"], st["p_iters"], " ".join("%%.15e" %% float(np.sqrt(np.sum(w.get_field(i) ** 2))) for i in fields),
+      " ".join("%%.15e" %% float(np.sum(np.abs(w.get_field(i)) * (1.0 + 0.001 * (np.arange(w.get_field(i).size) %% 977)))) for i in fields))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("plain", "heat"):
+        out = {}
+        for tag, val in (("two", "0"), ("one", "1")):
+            env = dict(os.environ)
+            env["NLG_PCG_SINGLE_RED"] = val
+            r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            ln = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1].split()
+            out[tag] = (int(ln[1]), int(ln[2]), [float(x) for x in ln[3:]])
+        (va, pa, ca), (vb, pb, cb) = out["two"], out["one"]
+        assert abs(va - vb) <= max(1, va // 50) and abs(pa - pb) <= max(2, pa // 50), (mode, out)
+        for a, b in zip(ca, cb):
+            assert abs(a - b) < 1e-8 * max(abs(a), 1e-30), (mode, out)

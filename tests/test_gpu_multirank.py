@@ -27,6 +27,9 @@ def case_env(case):
         # the halo send / receive on the side stream beside the interior groups of the gather-scatter: under the validation
         # transport the staging copies are ordered by the same two events as the RCCL group (csrc/halo.hip halo_begin / halo_finish)
         env["NLG_HALO_OVERLAP"] = "1"
+    # the one-reduction PCG (csrc/lns.hip cg_post_logic mode 4) on the ranks only: the single-rank run it is compared with keeps
+    # the two-reduction PCG, so the case checks the partition AND the solver variant
+    env["NLG_PCG_SINGLE_RED"] = "1" if ("+sr" in case and "@" not in case) else "0"
     return env
 
 
@@ -66,13 +69,14 @@ def record(case, world, fields, hess, ritz):
 
 @pytest.mark.parametrize("case,world", [("box3d", 2), ("per3d", 2), ("box3d", 3), ("jac3d", 2), ("box2d", 2),
                                         ("agg3d", 2), ("cyl", 2), ("cyl", 3), ("heat", 2), ("proj", 2), ("proj", 3),
-                                        ("blk3d", 2), ("blk3d", 3), ("box3d+ovl", 2), ("per3d+ovl", 2), ("cyl+ovl", 3), ("blk3d+ovl", 2)])
+                                        ("blk3d", 2), ("blk3d", 3), ("box3d+ovl", 2), ("per3d+ovl", 2), ("cyl+ovl", 3), ("blk3d+ovl", 2),
+                                        ("box3d+sr", 2), ("heat+sr", 2), ("cyl+sr", 3)])
 def test_partition_independent(tmp_path, case, world):
     parts = launch(world, tmp_path, case)
     # the single-rank run of the same global mesh (`world` times the elements in the last direction)
-    gcase = "%s@%d" % (case.replace("+ovl", ""), world)       # (the cylinder case ignores the multiplier: the mesh is the global one)
+    gcase = "%s@%d" % (case.replace("+ovl", "").replace("+sr", ""), world)       # (the cylinder case ignores the multiplier: the mesh is the global one)
     r = subprocess.run([sys.executable, WORKER, "0", "1", "", str(tmp_path), gcase], cwd=ROOT, capture_output=True,
-                       text=True, timeout=420, env=case_env(case))
+                       text=True, timeout=420, env=case_env(gcase))
     assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     ref = np.load(os.path.join(tmp_path, "%s_w1_r0.npz" % gcase))
     # reductions: identical on every rank, equal to the single-rank values
@@ -98,7 +102,7 @@ def test_partition_independent(tmp_path, case, world):
         assert np.max(np.abs(got - want)) <= tol * scale, (key, np.max(np.abs(got - want)) / scale)
         worst = max(worst, np.max(np.abs(got - want)) / scale)
     # the Arnoldi factorisation: Hessenberg matrix and hence the Ritz values
-    if case in ("heat", "proj"):
+    if case.split("+")[0] in ("heat", "proj"):
         record(case, world, worst, None, None)
         return
     # (north_star: Ritz values to 1e-10 across partitions; measured 1e-15 .. 5e-15, Hessenberg entries 4e-15 .. 3e-14)
