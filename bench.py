@@ -82,8 +82,10 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
         return 8.0 * E * np1 * ((4 if dim == 3 else 2) * dim + ng + 1)
     if cls == "gs":           # value in + out per shared local dof and field, 4-byte index once
         return nshared * (16.0 * dim + 4.0)
-    if cls == "cg_update":    # k_cg_update<dim>: x, r in/out, p, w, pc in, z out per field (8 arrays) + the two weight arrays
-        return 8.0 * lvs * (8 * dim + 2)
+    if cls == "cg_update":    # k_cg_update<dim>: r in/out, w, pc in, z out per field (5 arrays) + the two weight arrays; x in/out and
+        # p in as well (8 arrays) when the deferred solution update is switched off (NLG_PCG_DEFER_X=0) or the one-reduction PCG runs
+        deferred = os.environ.get("NLG_PCG_DEFER_X", "16") != "0" and os.environ.get("NLG_PCG_SINGLE_RED", "0") == "0"
+        return 8.0 * lvs * ((5 if deferred else 8) * dim + 2)
     if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
         return 8.0 * (k * ncomp + ncomp + 1) * lvs
     fused = k >= 24           # CGS2: first subtraction + second projection in one sweep over the last min(k, 64) vectors

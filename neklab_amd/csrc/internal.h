@@ -405,7 +405,7 @@ int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int
 int sem_gs_pairs_fg(nlg_mesh *m, double *w, const double *gate = nullptr, int nl = 1, int64_t ld = 0, int64_t ldg = 0);
 int sem_gs_pairs(nlg_mesh *m, double *w, const double *gate = nullptr, int nl = 1, int64_t ld = 0, int64_t ldg = 0);   // the same in the natural layout (2-D Schwarz exchange)   // rank-local QQ^T over the two-copy groups (face interiors) of one field in the face-grouped layout
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part = nullptr,
-               double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr, bool xp = false, int nl = 1, int64_t ld = 0);   // zf: fused u <- zf + beta u; xp: u, zf, w in the x-planes-first layout (3-D, lx1 <= 8)
+               double *const *zf = nullptr, const double *beta_p = nullptr, const double *done_p = nullptr, bool xp = false, int nl = 1, int64_t ld = 0, int64_t uoff = 0);   // uoff: the updated direction is stored uoff doubles behind u (direction history of the PCG); zf: fused u <- zf + beta u; xp: u, zf, w in the x-planes-first layout (3-D, lx1 <= 8)
 int sem_axhelm_lanes(nlg_mesh *m, int nl, double *const *const *u, double *const *const *w, double h1, double h2, double *const *pw,
                      double *const *const *zf, const double *const *beta, const double *const *done, bool xp);
 int sem_opdiv_blocks(const nlg_mesh *m);

@@ -51,7 +51,8 @@ __device__ __forceinline__ CF3 lane_f3(CF3 a, int64_t lo) {
 
 // solver scalar slots (doubles) inside a per-solver device block
 enum { S_RZ = 0, S_PW = 1, S_RZN = 2, S_RN2 = 3, S_DONE = 4, S_ITERS = 5, S_ALPHA = 6, S_BETA = 7, S_T0 = 8, S_T1 = 9, S_T2 = 10,
-       S_WMEAN = 11, S_ZMEAN = 12, S_RN20 = 13, S_N = 16 };
+       S_WMEAN = 11, S_ZMEAN = 12, S_RN20 = 13, S_AH = 16, S_N = 48 };
+constexpr int kAlphaRing = 32;   // S_AH .. S_AH + 31: the step lengths of the last 32 iterations (iteration i at i mod 32), for the deferred solution update
 constexpr double kFloor2 = 1e-28;   // stop when |r|^2 has dropped by 1e-28: further iterations only divide 0 by 0
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -153,17 +154,18 @@ __global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p,
     }
 }
 
-// x += alpha p ; r -= alpha (w - wmean) ; z = pc r ; partial (r,z)_ipw, (r,r)_nw, sum(z)
+// x += alpha p (unless deferred) ; r -= alpha (w - wmean) ; z = pc r ; partial (r,z)_ipw, (r,r)_nw, sum(z)
 // Two points per lane (16-byte accesses; every field length is a multiple of 32): eight streams per component are
 // what this kernel is, so the width of an access is its efficiency.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3 x, F3 r, F3 z, CF3 p, CF3 w, CF3 pc,
-                                                  const double *ipw, const double *nw, double *partial, int64_t ld) {
+                                                  const double *ipw, const double *nw, double *partial, int64_t ld, int defer_x) {
     __shared__ double sm[12];
     const int64_t lo = lane_lo(ld);
     s += lo, x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), p = lane_f3(p, lo), w = lane_f3(w, lo), partial += lo;
     if (s[S_DONE] != 0.0) return;
     const double alpha = s[S_ALPHA], wmean = s[S_WMEAN];
+    const bool dox = defer_x == 0;   // deferred: x is assembled from the direction history afterwards (k_x_flush / k_add_hist), p is not read here
     double a = 0.0, b = 0.0, c3 = 0.0;
     const int64_t n2 = n >> 1;
     const double2 *ipw2 = reinterpret_cast<const double2 *>(ipw), *nw2 = reinterpret_cast<const double2 *>(nw);
@@ -172,11 +174,15 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             double2 *x2 = reinterpret_cast<double2 *>(x.p[c]), *r2 = reinterpret_cast<double2 *>(r.p[c]);
-            const double2 pv = reinterpret_cast<const double2 *>(p.p[c])[i], wv = reinterpret_cast<const double2 *>(w.p[c])[i];
-            double2 xv = x2[i], rv = r2[i];
-            xv.x += alpha * pv.x;
-            xv.y += alpha * pv.y;
-            x2[i] = xv;
+            const double2 wv = reinterpret_cast<const double2 *>(w.p[c])[i];
+            double2 rv = r2[i];
+            if (dox) {
+                const double2 pv = reinterpret_cast<const double2 *>(p.p[c])[i];
+                double2 xv = x2[i];
+                xv.x += alpha * pv.x;
+                xv.y += alpha * pv.y;
+                x2[i] = xv;
+            }
             rv.x -= alpha * (wv.x - wmean);
             rv.y -= alpha * (wv.y - wmean);
             double2 pcv = make_double2(1.0, 1.0);
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
         const int64_t i = n - 1;
         const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
         for (int c = 0; c < NF; ++c) {
-            x.p[c][i] += alpha * p.p[c][i];
+            if (dox) x.p[c][i] += alpha * p.p[c][i];
             double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
             const double pcv = pc.p[c] ? pc.p[c][i] : 1.0;
             if (pcv == 0.0) rv = 0.0;
@@ -263,6 +269,61 @@ __global__ __launch_bounds__(NT) void k_cg_update_sr(const double *s, int64_t n,
 // partial sums of (r,z)_ipw and sum(z) when z was produced by a preconditioning operator
 // `xc`/`npe` (xc may be null): the coarse-grid part of z, one value per element of npe points, kept separate so
 // that the coarse branch can run concurrently with the element-wise solves: z_total = z + xc[i / npe]
+// Deferred solution update of the velocity PCG.  x = sum_i alpha_i p_i never changes the iteration, so k_cg_update does not touch it:
+// the fused direction update of the operator kernel stores direction i into slot i mod PH of a ring of PH direction buffers (the
+// write it makes anyway, at another address), the scalar logic keeps alpha_i, and x is assembled afterwards in the order of the
+// iteration -- the same additions on the same operands, hence the same bits -- by k_add_hist (the velocity update that consumes x)
+// and, for the rare solve with more than PH iterations, by k_x_flush every PH iterations.  Saves the two x streams and the p
+// stream of every iteration of k_cg_update (26 -> 17 streams at three components) for one sweep over the directions per solve.
+struct PHist {
+    const double *p0[3];   // slot 0, one pointer per component; slot q is q * stride doubles behind
+    int64_t stride;
+    int ph;
+};
+// x += sum over the PH iterations `last` - PH + 1 .. `last`; launched right after the k_cg_update of iteration `last` (before the scalar
+// logic that counts it), so "not converged yet" = the solve did run them all
+template <int NF>
+__global__ __launch_bounds__(NT) void k_x_flush(const double *__restrict__ s, int64_t n, F3 x, PHist H, int last, int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    s += lo, x = lane_f3(x, lo);
+    if (s[S_DONE] != 0.0) return;   // converged inside this window: k_add_hist takes what there is of it
+    const int w0 = last - H.ph + 1;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double *__restrict__ pc = H.p0[c] + lo + i;
+            double t = x.p[c][i];
+#pragma unroll 4
+            for (int q = 0; q < H.ph; ++q) t += s[S_AH + ((w0 + q) & (kAlphaRing - 1))] * pc[q * H.stride];   // (alpha: wave-uniform scalar loads)
+            x.p[c][i] = t;
+        }
+    }
+}
+// y = a + (x + sum of alpha_i p_i over the iterations since the last full window); x, p in the layout of the solve (slot: slab-permuted -> natural)
+template <int NF>
+__global__ __launch_bounds__(NT) void k_add_hist(const double *__restrict__ s, int64_t n, int np, const int *__restrict__ slot, F3 y, CF3 a, CF3 x, PHist H,
+                                                 int64_t ld) {
+    const int64_t lo = lane_lo(ld);
+    s += lo, y = lane_f3(y, lo), a = lane_f3(a, lo), x = lane_f3(x, lo);
+    const int iters = (int)s[S_ITERS];
+    const int w0 = (iters / H.ph) * H.ph, cnt = iters - w0;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        int64_t q = i;
+        if (slot) {
+            const int64_t e = i / np;
+            q = e * np + slot[(int)(i - e * np)];
+        }
+#pragma unroll
+        for (int c = 0; c < NF; ++c) {
+            const double *__restrict__ pc = H.p0[c] + lo + q;
+            double t = x.p[c][q];
+#pragma unroll 4
+            for (int k = 0; k < cnt; ++k) t += s[S_AH + ((w0 + k) & (kAlphaRing - 1))] * pc[k * H.stride];
+            y.p[c][i] = a.p[c][i] + t;
+        }
+    }
+}
+
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_rz(const double *s, int gate, int64_t n, CF3 r, CF3 z, const double *ipw,
                                               const double *xc, int npe, double *partial, int64_t ld) {
@@ -326,6 +387,7 @@ __device__ __forceinline__ void cg_post_logic(double *s, int mode, double tol2, 
         s[S_PW] = s[S_T0];
         s[S_WMEAN] = s[S_T1] * inv_n;
         s[S_ALPHA] = s[S_RZ] / s[S_T0];
+        s[S_AH + ((int)s[S_ITERS] & (kAlphaRing - 1))] = s[S_ALPHA];
     } else if (mode == 4) {
         // single-reduction PCG (Chronopoulos & Gear 1989): T0 = (w, u) with w = A u, u = M^-1 r;  T1 = (r, u);  T2 = |r|^2 -- all of the
         // CURRENT residual, in one reduction.  The convergence test standard PCG makes before applying the operator comes one operator
@@ -796,6 +858,8 @@ struct nlg_linop {
     double *rhs[3] = {}, *x[3] = {}, *z[3] = {}, *pv[3] = {}, *w[3] = {}, *gp[3] = {};
     // single-reduction PCG (Chronopoulos-Gear; several ranks, NLG_PCG_SINGLE_RED): the search direction and its image as recurrences
     bool use_sr = false;
+    int ph = 0;                // depth of the direction ring of the velocity PCG (deferred solution update, k_add_hist); 0 = x updated every iteration
+    double *phist = nullptr;   // [ph][dim][lvs]
     double *cgs[3] = {}, *tcgs = nullptr;
     bool rhs_in_xp = false;   // adv_a -> helm_problem: the right-hand side already is masked and in the slab-permuted layout
     double *pr_r = nullptr, *pr_x = nullptr, *pr_z = nullptr, *pr_p = nullptr, *pr_w = nullptr;
@@ -885,6 +949,7 @@ void lane_buffers(nlg_linop *op, F f) {
     }
     if (op->cfg.ifheat)
         for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) f(v, m->lvs);
+    if (op->ph > 0) f(&op->phist, (int64_t)op->ph * dim * m->lvs);
     if (op->use_sr) {
         for (int c = 0; c < dim; ++c) f(&op->cgs[c], m->lvs);
         if (op->cfg.ifheat) f(&op->tcgs, m->lvs);
@@ -914,6 +979,7 @@ void lane_bind(nlg_linop *owner, nlg_linop *ln, int v) {
     const bool heat = ln->cfg.ifheat;
     ln->cfg.ifheat = owner->cfg.ifheat;   // (same buffer list as the owner's)
     ln->use_sr = owner->use_sr;
+    ln->ph = owner->ph;
     lane_buffers(ln, [&](double **p, int64_t len) {
         *p = base + off;
         off += round_up(len, kAlign);
@@ -995,6 +1061,9 @@ struct CGProblem {
     // preconditioned residual itself, no direction update inside) and its first-stage sums (z, w) into pw_part
     double *const *sd = nullptr;
     std::function<int()> apply_plain;
+    // deferred solution update (k_x_flush / k_add_hist): `apply` stores direction i into slot i mod ph of the direction ring `hist`;
+    // x is then NOT complete when run_pcg returns -- its consumer assembles it (adv_b)
+    PHist hist = {{nullptr, nullptr, nullptr}, 0, 0};
 };
 
 // Device-scalar PCG for P.nl lanes.  `apply` computes w = A p for ALL lanes (stream-ordered, gated by each lane's s[S_DONE]).
@@ -1096,6 +1165,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
     if (!P.fused_pupdate)
         launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, lgrid(g, nl), st, (const double *)s, P.n, p, cz, xc, P.npe, ld);   // p = z - zmean
     NLG_LAUNCH(k_cg_post, lgrid(1, nl), dim3(1), 0, st, s, 3, P.tol2, P.use_tol, P.maxit, P.inv_n, ld, (const double *)nullptr, 0);
+    int nbody = 0;   // iterations launched so far = the iteration index the device is at while it has not converged
     auto body = [&]() -> int {
         NLG_TRY(apply(s));
         const bool prof_cg = prof_want(ctx, P_CGVEC);
@@ -1106,8 +1176,11 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         if (!P.rr_part) {
             ProfScope pu(ctx, P_CGUPDATE);   // the largest single kernel of a step by time: its own class inside cg_vec (bench.py quotes its roofline)
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, lgrid(g, nl), st, (const double *)s, P.n, x, r, z, cp, cw,
-                      pc, P.ipw, P.nw, partial, ld);
+                      pc, P.ipw, P.nw, partial, ld, (int)(P.hist.ph > 0));
+            if (P.hist.ph > 0 && (nbody + 1) % P.hist.ph == 0)   // the direction ring is full: its PH terms go into x before slot 0 is overwritten
+                launch_nf(nf, k_x_flush<1>, k_x_flush<2>, k_x_flush<3>, lgrid(grid_for(P.n), nl), st, (const double *)s, P.n, x, P.hist, nbody, ld);
         }
+        ++nbody;
         if (prof_cg) prof_end(ctx, P_CGVEC);
         if (P.precond) {
             NLG_TRY(P.precond(s + S_DONE, P.r[0], P.z[0], &xc));
@@ -1159,6 +1232,7 @@ struct HelmSolve {
     bool xp = false;
     double nu = 0.0, h2 = 0.0;
     double *pw_part = nullptr;
+    mutable int it = 0;   // operator applications so far (= the slot of the direction ring the next one writes, modulo its depth)
 };
 
 int helm_problem(const Lanes &L, int order, double h2, HelmSolve &H) {
@@ -1210,6 +1284,11 @@ int helm_problem(const Lanes &L, int order, double h2, HelmSolve &H) {
     P.pw_n = sem_axhelm_blocks(m, dim);
     P.pw_sum = false;
     P.fused_pupdate = true;
+    if (op->ph > 0) {
+        for (int q = 0; q < dim; ++q) P.hist.p0[q] = op->phist + (int64_t)q * m->lvs;
+        P.hist.stride = (int64_t)dim * m->lvs;
+        P.hist.ph = op->ph;
+    }
     return 0;
 }
 
@@ -1217,7 +1296,18 @@ int helm_apply(const Lanes &L, const HelmSolve &H) {
     nlg_linop *op = L.op();
     nlg_mesh *m = op->mesh;
     const int dim = m->dim;
-    NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, H.xp, L.nl, L.ld()));
+    if (H.P.hist.ph > 0) {
+        // direction ring: read direction it - 1, store direction it one slot further (the first application multiplies slot ph - 1 by
+        // beta = 0: the ring is zeroed with the slab and holds finite values ever after)
+        const int ph = H.P.hist.ph, so = H.it % ph, si = (H.it + ph - 1) % ph;
+        ++H.it;
+        double *pin[3] = {nullptr, nullptr, nullptr};
+        for (int q = 0; q < dim; ++q) pin[q] = op->phist + si * H.P.hist.stride + (int64_t)q * m->lvs;
+        NLG_TRY(sem_axhelm(m, pin, op->w, dim, H.nu, H.h2, H.pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, H.xp, L.nl, L.ld(),
+                           (so - si) * H.P.hist.stride));
+    } else {
+        NLG_TRY(sem_axhelm(m, op->pv, op->w, dim, H.nu, H.h2, H.pw_part, op->z, op->d_s + S_BETA, op->d_s + S_DONE, H.xp, L.nl, L.ld()));
+    }
     NLG_TRY(sem_gs(m, op->w, dim, op->d_s + S_DONE, H.xp ? LAYOUT_XP : LAYOUT_NAT, L.nl, L.ld(), L.ld()));
     return 0;
 }
@@ -1672,7 +1762,13 @@ int adv_b(const Lanes &L) {
     const double dt = op->dt, b0 = op->adv_b0;
     // uh = u + du -> into the oldest velocity buffer (slot 2), which becomes the new current after rotation
     double **unew = op->ubuf[2];
-    if (op->use_xp > 0) {
+    if (op->ph > 0) {
+        // deferred solution update of the velocity PCG: the increment is assembled from the direction ring here (k_add_hist)
+        PHist Hh = {{nullptr, nullptr, nullptr}, (int64_t)dim * m->lvs, op->ph};
+        for (int q = 0; q < dim; ++q) Hh.p0[q] = op->phist + (int64_t)q * m->lvs;
+        launch_nf(dim, k_add_hist<1>, k_add_hist<2>, k_add_hist<3>, lgrid(grid_for(m->lvn), nl), st, (const double *)op->d_s, m->lvn, m->np1,
+                  op->use_xp > 0 ? (const int *)m->d_slot_xp : (const int *)nullptr, f3(unew, dim), cf3(op->ubuf[0], dim), cf3(op->x, dim), Hh, ld);
+    } else if (op->use_xp > 0) {
         launch_nf(dim, k_add_xp<1>, k_add_xp<2>, k_add_xp<3>, lgrid(grid_for(m->lvn), nl), st, m->lvn, m->np1, (const int *)m->d_slot_xp, f3(unew, dim),
                   cf3(op->ubuf[0], dim), cf3(op->x, dim), ld);
     } else {
@@ -2077,6 +2173,8 @@ int nlg_linop_init(nlg_linop *op) {
         // iteration: measured +9 % per time step on one rank at 10,240 elements, +3 % at 1,300, and 23 of 454 collectives per time step
         // fewer on 2 ranks -- it pays only where an all-reduce costs more than ~15 us, which this pool cannot measure
         op->use_sr = getenv("NLG_PCG_SINGLE_RED") && atoi(getenv("NLG_PCG_SINGLE_RED")) != 0;
+        // deferred solution update of the velocity PCG (k_add_hist): depth of the direction ring, NLG_PCG_DEFER_X=0 switches it off
+        op->ph = op->use_sr ? 0 : std::max(0, std::min(kAlphaRing, getenv("NLG_PCG_DEFER_X") ? atoi(getenv("NLG_PCG_DEFER_X")) : 16));
         NLG_TRY(slab_ensure(op, 1));   // the work buffers of one lane; a block matvec grows the slab on first use
     }
     double *U[3] = {op->baseflow->vel(0), op->baseflow->vel(1), dim == 3 ? op->baseflow->vel(2) : nullptr};

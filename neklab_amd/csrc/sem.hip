@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
                                                 const double *__restrict__ G4, const double *__restrict__ G5,
                                                 const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                 double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                const double *__restrict__ done_p) {
+                                                const double *__restrict__ done_p, int64_t uoff) {
     constexpr int NP = N * N * N, NS = N * N;
     extern __shared__ double smem[];
     __shared__ double sred[8];
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512) void k_axhelm3(int64_t E, int nf, int epb, con
         double v = act ? uc[base + ij + k * NS] : 0.0;
         if (upd && act) {
             v = zc[base + ij + k * NS] + beta * v;
-            const_cast<double *>(uc)[base + ij + k * NS] = v;
+            const_cast<double *>(uc)[uoff + base + ij + k * NS] = v;   // uoff: the updated direction goes to the next slot of the direction history (0 = in place)
         }
         sU[ij + k * NS] = v;
     }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
                                                        const double *__restrict__ G4, const double *__restrict__ G5,
                                                        const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                        double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                       const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld) {
+                                                       const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld, int64_t uoff) {
     static_assert(N * N <= 64, "one lane per (i, j)");
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1;
     __shared__ double sD[N * N];
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 uk[k] = zk[k] + beta * uk[k];
-                const_cast<double *>(uc)[vb + k * vs] = uk[k];
+                const_cast<double *>(uc)[uoff + vb + k * vs] = uk[k];
             }
         }
     }
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
                                                                         const double *__restrict__ G4, const double *__restrict__ G5,
                                                                         const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                                         double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld) {
+                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld, int64_t uoff) {
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((PPB * NS + 63) / 64) * 64, NWB = NTB / 64;
     __shared__ double sD[NS];
     __shared__ double mUa[PPB][N * NQ], mRa[PPB][N * NQ], mSa[PPB][N * NQ];
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 uk[k] = zk[k] + beta * uk[k];
-                const_cast<double *>(uc)[pij + k * NS] = uk[k];
+                const_cast<double *>(uc)[uoff + pij + k * NS] = uk[k];
             }
         }
     }
@@ -1061,7 +1061,7 @@ template <int N, int NF>
 __global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) void k_axhelm2(
     int64_t E, const double *__restrict__ Dg, const double *__restrict__ G0, const double *__restrict__ G1,
     const double *__restrict__ G2, const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
-    double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p, const double *__restrict__ done_p) {
+    double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p, const double *__restrict__ done_p, int64_t uoff) {
     constexpr int EPB = (NT / (N * N)) > 0 ? (NT / (N * N)) : 1;
     constexpr int NP = N * N;
     __shared__ double sD[N * N];
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(((NT / (N * N)) > 0 ? (NT / (N * N)) : 1) * N * N) 
         uu[c] = act ? u.p[c][q] : 0.0;
         if (upd && act) {
             uu[c] = zf.p[c][q] + beta * uu[c];
-            const_cast<double *>(u.p[c])[q] = uu[c];
+            const_cast<double *>(u.p[c])[uoff + q] = uu[c];
         }
         sU[le][c][ij] = uu[c];
     }
@@ -3718,8 +3718,9 @@ int sem_axhelm_blocks(nlg_mesh *m, int nf) {
 }
 
 int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h1, double h2, double *pw_part,
-               double *const *zf, const double *beta_p, const double *done_p, bool xp, int nl, int64_t ld) {
+               double *const *zf, const double *beta_p, const double *done_p, bool xp, int nl, int64_t ld, int64_t uoff) {
     NLG_CHECK(nf >= 1 && nf <= 3, "sem_axhelm: nf=%d unsupported", nf);
+    NLG_CHECK(uoff == 0 || beta_p, "sem_axhelm: an output offset for the direction without the fused direction update");
     static const bool use_cube0 = getenv("NLG_AXHELM_CUBE") && atoi(getenv("NLG_AXHELM_CUBE")) != 0;
     if (nl > 1 && (m->dim == 2 || (m->n > 8 && use_cube0))) {
         // kernels without the lane dimension (2-D, the LDS-cube variant): one launch per lane at the lane's offsets
@@ -3727,7 +3728,7 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
             double *uu[3], *ww[3], *zz[3];
             for (int c = 0; c < nf; ++c) uu[c] = u[c] + v * ld, ww[c] = w[c] + v * ld, zz[c] = zf ? zf[c] + v * ld : nullptr;
             NLG_TRY(sem_axhelm(m, uu, ww, nf, h1, h2, pw_part ? pw_part + v * ld : nullptr, zf ? zz : nullptr, beta_p ? beta_p + v * ld : nullptr,
-                               done_p ? done_p + v * ld : nullptr, xp, 1, 0));
+                               done_p ? done_p + v * ld : nullptr, xp, 1, 0, uoff));
         }
         return 0;
     }
@@ -3749,13 +3750,13 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         if constexpr (N_ <= 8) {                                                                                      \
             if (xp)                                                                                                   \
             NLG_LAUNCH((k_axhelm3r<N_, 4, true>), dim3(grid, nl), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
-                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
             else                                                                                                      \
             NLG_LAUNCH((k_axhelm3r<N_, 4, false>), dim3(grid, nl), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
-                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
         } else if (use_cube)                                                                                          \
         NLG_LAUNCH((k_axhelm3<N_>), dim3(grid), dim3(nslot * N_ * N_), lds, s, m->E, nf, nslot, m->d_D,      \
-                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p); \
+                           m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, uoff); \
         else                                                                                                          \
         {                                                                                                             \
             constexpr int PPB_ = 3;                                                                    \
@@ -3763,14 +3764,14 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
             const unsigned gb = (unsigned)((tot + (one ? 1 : PPB_) - 1) / (one ? 1 : PPB_));                          \
             if (one) {                                                                                                \
                 if (xp)                                                                                               \
-                    NLG_LAUNCH((k_axhelm3c<N_, true, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
+                    NLG_LAUNCH((k_axhelm3c<N_, true, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
                 else                                                                                                  \
-                    NLG_LAUNCH((k_axhelm3c<N_, false, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); \
+                    NLG_LAUNCH((k_axhelm3c<N_, false, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
             } else {                                                                                                  \
                 if (xp)                                                                                               \
-                    NLG_LAUNCH((k_axhelm3c<N_, true, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld); \
+                    NLG_LAUNCH((k_axhelm3c<N_, true, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
                 else                                                                                                  \
-                    NLG_LAUNCH((k_axhelm3c<N_, false, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld); \
+                    NLG_LAUNCH((k_axhelm3c<N_, false, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
             }                                                                                                         \
         }                                                                                                             \
     }
@@ -3783,13 +3784,13 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         const int grid = (int)((m->E + EPB - 1) / EPB);                                                               \
         if (nf == 1)                                                                                                  \
             NLG_LAUNCH((k_axhelm2<N_, 1>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, uoff);                                 \
         else if (nf == 2)                                                                                             \
             NLG_LAUNCH((k_axhelm2<N_, 2>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, uoff);                                 \
         else                                                                                                          \
             NLG_LAUNCH((k_axhelm2<N_, 3>), dim3(grid), dim3(EPB * N_ * N_), 0, s, m->E, m->d_D, m->d_G[0],     \
-                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p);                                       \
+                               m->d_G[1], m->d_G[2], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, uoff);                                 \
     }
         NLG_FOR_N(AX2)
 #undef AX2

@@ -307,3 +307,55 @@ print("RESULT", st["v_iters"], st["p_iters"], " ".join("%%.15e" %% float(np.sqrt
         assert abs(va - vb) <= max(1, va // 50) and abs(pa - pb) <= max(2, pa // 50), (mode, out)
         for a, b in zip(ca, cb):
             assert abs(a - b) < 1e-8 * max(abs(a), 1e-30), (mode, out)
+
+
+def test_deferred_solution_update_of_the_velocity_pcg_is_bit_identical():
+    """The velocity PCG does not update x every iteration: the operator kernel stores direction i into slot i mod PH of a ring, the scalar
+    logic keeps alpha_i, and the consumer of x assembles x = sum alpha_i p_i in iteration order (csrc/lns.hip k_add_hist; k_x_flush when a
+    solve outlasts the ring).  Same additions on the same operands: the matvec must give the same BITS with the ring switched off
+    (NLG_PCG_DEFER_X=0, x += alpha p inside k_cg_update), at its default depth, at depth 3 (several flushes and wrap-arounds per solve) and
+    at depth 1 (in place, a flush every iteration) -- 3-D single vector, 2-D, and a block of three lanes that converge at different counts."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+mode = sys.argv[1]
+dim = 2 if mode == "2d" else 3
+hm = box_mesh((5, 4) if dim == 2 else (4, 3, 2), 7 if dim == 2 else 8, periodic=(True,) + (False,) * (dim - 1), deform=0.04)
+ctx = host.Context(0); gm = host.Mesh(ctx, hm)
+X = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
+gb = host.nek_dvector(gm)
+gb.set_field(0, hm.mask[0] * (1.0 + 0.5 * np.sin(X[0]) * np.cos(X[1]))); gb.set_field(1, hm.mask[1] * 0.3 * np.sin(2 * X[0]))
+A = host.exptA_linop(0.05, gb, re=40.0, dt=0.01, torder=3, vtol=1e-12, ptol=1e-11, maxit_v=400, maxit_p=4000); A.init()
+s = 3 if mode == "block" else 1
+vin = []
+for v in range(s):
+    x = host.nek_dvector(gm); x.rand(True, seed=40 + v); x.scal(10.0 ** (-3 * v)); vin.append(x)
+out = [host.nek_dvector(gm) for _ in range(s)]
+if s == 1: A.matvec(vin[0], out[0])
+else: A.matvec_block(vin, out)
+st = A.stats()
+words = []
+for w in out:
+    for i in range(dim):
+        f = w.get_field(i).ravel()
+        words.append(float(np.sqrt(np.sum(f * f))).hex()); words.append(float(np.sum(f * (1.0 + 0.001 * (np.arange(f.size) %% 977)))).hex())
+print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("3d", "2d", "block"):
+        out = {}
+        for depth in ("0", "", "3", "1"):
+            env = dict(os.environ)
+            env.pop("NLG_PCG_DEFER_X", None)
+            if depth:
+                env["NLG_PCG_DEFER_X"] = depth
+            r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            out[depth] = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1]
+        assert int(out["0"].split()[1]) >= 8, out["0"]          # the solves do outlast a ring of depth 3
+        for depth in ("", "3", "1"):
+            assert out[depth] == out["0"], (mode, depth, out)
