@@ -215,3 +215,172 @@ double nl_cgvec(long n, double *x, double *r, double *z, double *p, const double
     for (long i = 0; i < n; ++i) p[i] = z[i] + 0.5 * p[i];
     return rz + pw;
 }
+
+/* ---- one real time step: the two PCG solvers of oracle/lns.py (pcg_helm, pcg_E) on the operators above, every vector pass an
+ * OpenMP loop, so that bench.py's cpu_baseline can TIME a whole time step instead of composing unit times (oracle/cpu_step.py drives
+ * them; tests/test_cpu_oracle.py checks the step against ExptA.advance).  The loop bodies follow the numpy twin line by line. ---- */
+
+/* y = (acc ? y : 0) + scale o sum_j c[j] x[j]   (scale may be null) */
+void nl_lincomb(long n, int k, const double *const *x, const double *c, const double *scale, double *y, int acc) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += c[j] * x[j][i];
+        if (scale) s *= scale[i];
+        y[i] = acc ? y[i] + s : s;
+    }
+}
+/* y = m o (a + b - c)  (the residual of the tentative velocity: mask (rhs + grad^T p - H u)); any of b, c may be null */
+void nl_residual(long n, const double *m, const double *a, const double *b, const double *c, double *y) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) y[i] = m[i] * (a[i] + (b ? b[i] : 0.0) - (c ? c[i] : 0.0));
+}
+/* y = a + s * (m o b)  (m may be null) */
+void nl_add_scaled(long n, const double *a, double s, const double *m, const double *b, double *y) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) y[i] = a[i] + s * (m ? m[i] * b[i] : b[i]);
+}
+double nl_sum(long n, const double *a) {
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (long i = 0; i < n; ++i) s += a[i];
+    return s;
+}
+void nl_shift(long n, double *a, double s) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) a[i] -= s;
+}
+
+#define NL_FLOOR2 1e-28
+/* Jacobi-PCG for the three velocity components at once (oracle/lns.py pcg_helm): r holds b on entry; returns the iteration count */
+int nl_pcg_helm(long E, int n, const double *D, const double *const *G, const double *bm1, long ngroups, const long *off, const long *idx,
+                const double *const *mask, const double *minv, const double *vmult, const double *wnorm, double nu, double h2,
+                double *const *r, double *const *x, double *const *z, double *const *p, double *const *w, double tol2, int maxit, int fixed) {
+    const long N = E * n * n * n;
+    double rz = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        double *xc = x[c], *rc = r[c], *zc = z[c], *pc = p[c];
+        const double *mc = mask[c];
+        double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+        for (long i = 0; i < N; ++i) {
+            xc[i] = 0.0;
+            zc[i] = mc[i] * minv[i] * rc[i];
+            pc[i] = zc[i];
+            s += rc[i] * zc[i] * vmult[i];
+        }
+        rz += s;
+    }
+    int it = 0;
+    const int lim = fixed > 0 ? fixed : maxit;
+    double rn20 = -1.0;
+    while (it < lim) {
+        double rn2 = 0.0;
+        for (int c = 0; c < 3; ++c) rn2 += nl_glsc3(N, r[c], r[c], wnorm);
+        if (rn20 < 0.0) rn20 = rn2;
+        if (rn2 <= NL_FLOOR2 * rn20) break;
+        if (fixed <= 0 && rn2 < tol2) break;
+        double pw = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            nl_axhelm(E, n, D, G, bm1, p[c], w[c], nu, h2);
+            nl_gs(ngroups, off, idx, w[c]);
+            double *wc = w[c];
+            const double *mc = mask[c], *pc = p[c];
+            double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+            for (long i = 0; i < N; ++i) {
+                wc[i] *= mc[i];
+                s += pc[i] * wc[i] * vmult[i];
+            }
+            pw += s;
+        }
+        const double alpha = rz / pw;
+        double rzn = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            double *xc = x[c], *rc = r[c], *zc = z[c];
+            const double *pc = p[c], *wc = w[c], *mc = mask[c];
+            double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+            for (long i = 0; i < N; ++i) {
+                xc[i] += alpha * pc[i];
+                rc[i] -= alpha * wc[i];
+                zc[i] = mc[i] * minv[i] * rc[i];
+                s += rc[i] * zc[i] * vmult[i];
+            }
+            rzn += s;
+        }
+        const double beta = rzn / rz;
+        rz = rzn;
+        for (int c = 0; c < 3; ++c) {
+            double *pc = p[c];
+            const double *zc = z[c];
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < N; ++i) pc[i] = zc[i] + beta * pc[i];
+        }
+        ++it;
+    }
+    return it;
+}
+
+/* Jacobi-PCG for the consistent Poisson operator on the mean-free subspace (oracle/lns.py pcg_E): r holds b on entry; u[3] is
+ * velocity-mesh scratch for E p = D (mask binvm1 QQ^T D^T p).  tol2 = (ptol / scale)^2; proj: remove the means (no outflow). */
+int nl_pcg_E(long E, int n, int n2, const double *I12, const double *D12, const double *const *rst2w, long ngroups, const long *off, const long *idx,
+             const double *const *mbinv, const double *minv, const double *bm2, double volvm2, int proj, double *r, double *x, double *z, double *p,
+             double *w, double *const *u, double tol2, int maxit, int fixed) {
+    const long N2 = E * n2 * n2 * n2, N1 = E * n * n * n;
+    if (proj) nl_shift(N2, r, nl_sum(N2, r) / (double)N2);
+    double rz = 0.0;
+    {
+        double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+        for (long i = 0; i < N2; ++i) {
+            x[i] = 0.0;
+            z[i] = minv[i] * r[i];
+            p[i] = z[i];
+            s += r[i] * z[i];
+        }
+        rz = s;
+    }
+    if (proj) nl_shift(N2, p, nl_sum(N2, p) / (double)N2);
+    int it = 0;
+    const int lim = fixed > 0 ? fixed : maxit;
+    double rn20 = -1.0;
+    while (it < lim) {
+        double rn2 = 0.0;
+#pragma omp parallel for reduction(+ : rn2) schedule(static)
+        for (long i = 0; i < N2; ++i) rn2 += r[i] * r[i] / bm2[i];
+        rn2 /= volvm2;
+        if (rn20 < 0.0) rn20 = rn2;
+        if (rn2 <= NL_FLOOR2 * rn20) break;
+        if (fixed <= 0 && rn2 < tol2) break;
+        nl_opgradt(E, n, n2, I12, D12, rst2w, p, u);
+        for (int c = 0; c < 3; ++c) {
+            nl_gs(ngroups, off, idx, u[c]);
+            double *uc = u[c];
+            const double *mb = mbinv[c];
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < N1; ++i) uc[i] *= mb[i];
+        }
+        nl_opdiv(E, n, n2, I12, D12, rst2w, (const double *const *)u, w);
+        double pw = 0.0;
+#pragma omp parallel for reduction(+ : pw) schedule(static)
+        for (long i = 0; i < N2; ++i) pw += p[i] * w[i];
+        const double alpha = rz / pw;
+        const double wm = proj ? nl_sum(N2, w) / (double)N2 : 0.0;
+        double rzn = 0.0;
+#pragma omp parallel for reduction(+ : rzn) schedule(static)
+        for (long i = 0; i < N2; ++i) {
+            x[i] += alpha * p[i];
+            r[i] -= alpha * (w[i] - wm);
+            z[i] = minv[i] * r[i];
+            rzn += r[i] * z[i];
+        }
+        const double beta = rzn / rz;
+        rz = rzn;
+        const double zm = proj ? nl_sum(N2, z) / (double)N2 : 0.0;
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < N2; ++i) p[i] = (z[i] - zm) + beta * p[i];
+        ++it;
+    }
+    return it;
+}

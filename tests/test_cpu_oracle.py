@@ -288,6 +288,44 @@ def test_c_port_matches_numpy_restatement():
     assert err(y, 0.5 * u[2] + 0.3 * u[0]) < 1e-15
 
 
+def test_c_port_time_step_matches_the_numpy_time_step():
+    """oracle/cpu_step.py CStep.advance -- the whole time step on the C + OpenMP port, both PCG solvers included, the thing bench.py's
+    cpu_baseline times end to end -- against oracle/lns.py ExptA.advance: four steps (bdf1, bdf2, bdf3, bdf3) from the same state give the
+    same velocity and pressure and the same iteration counts, with tolerance-terminated and with fixed-count solves."""
+    import subprocess
+    from oracle.cport import load
+    from oracle.cpu_step import CStep
+    from oracle.lns import ExptA, LNSConfig
+    from oracle.vectors import NekDVector
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle", "c")], check=True, capture_output=True)   # (rebuilds when the source is newer)
+    assert load() is not None
+    hm = box_mesh((3, 2, 2), 6, periodic=(True, False, False), deform=0.05)
+    sem = SEM(hm)
+    U = [sem.mask[0] * (1.0 + 0.3 * np.cos(sem.X[1])), sem.mask[1] * 0.2 * np.sin(sem.X[0]), sem.mask[2] * 0.1 * np.sin(sem.X[1])]
+    rng = np.random.default_rng(3)
+    u0 = [sem.mask[i] * sem.dsavg(rng.standard_normal(sem.shape1)) for i in range(3)]
+    p0 = rng.standard_normal(sem.shape2)
+    for fixed in (0, 7):
+        cfg = LNSConfig(tau=0.04, re=40.0, torder=3, dt=0.01, vtol=1e-11, ptol=1e-10, maxit_v=200, maxit_p=3000, fixed_iters_v=fixed, fixed_iters_p=3 * fixed)
+        A = ExptA(sem, U, cfg)
+        x = NekDVector(sem)
+        for i in range(3):
+            x.v[i][...] = u0[i]
+        x.pr[...] = p0
+        A._reset_state(x, False)
+        B = CStep(sem, U, cfg)
+        B.reset(u0, p0)
+        for step in range(4):
+            A.advance()
+            B.advance()
+            sc = max(np.abs(a).max() for a in A.u)
+            assert max(np.abs(a - b).max() for a, b in zip(A.u, B.u)) < 1e-9 * sc, (fixed, step)
+            assert np.abs(A.p - B.p).max() < 1e-8 * np.abs(A.p).max(), (fixed, step)
+        assert A.stats["v_iters"] == B.stats["v_iters"], (A.stats, B.stats)
+        assert abs(A.stats["p_iters"] - B.stats["p_iters"]) <= (0 if fixed else 2), (A.stats, B.stats)
+
+
 def test_matvec_matches_golden_3d_n8():
     """The lx1 = 8, 3-D fixture the GPU box checks the benchmark's kernel instantiations against (first matvec only here:
     the whole fixture takes half a minute of oracle time, tests/golden/make_golden.py 3d_n8)."""
