@@ -2174,7 +2174,11 @@ int nlg_linop_init(nlg_linop *op) {
         // fewer on 2 ranks -- it pays only where an all-reduce costs more than ~15 us, which this pool cannot measure
         op->use_sr = getenv("NLG_PCG_SINGLE_RED") && atoi(getenv("NLG_PCG_SINGLE_RED")) != 0;
         // deferred solution update of the velocity PCG (k_add_hist): depth of the direction ring, NLG_PCG_DEFER_X=0 switches it off
-        op->ph = op->use_sr ? 0 : std::max(0, std::min(kAlphaRing, getenv("NLG_PCG_DEFER_X") ? atoi(getenv("NLG_PCG_DEFER_X")) : 16));
+        // (default 16 slots, fewer where 16 would take more than 8 GB per lane: a solve that outlasts the ring pays one k_x_flush per
+        // ring length, which still moves fewer bytes than updating x in every iteration as long as the ring holds >= 3 directions)
+        const int64_t slot_bytes = (int64_t)sizeof(double) * dim * m->lvs;
+        const int ph_auto = (int)std::max<int64_t>(3, std::min<int64_t>(16, ((int64_t)8 << 30) / std::max<int64_t>(slot_bytes, 1)));
+        op->ph = op->use_sr ? 0 : std::max(0, std::min(kAlphaRing, getenv("NLG_PCG_DEFER_X") ? atoi(getenv("NLG_PCG_DEFER_X")) : ph_auto));
         NLG_TRY(slab_ensure(op, 1));   // the work buffers of one lane; a block matvec grows the slab on first use
     }
     double *U[3] = {op->baseflow->vel(0), op->baseflow->vel(1), dim == 3 ? op->baseflow->vel(2) : nullptr};
