@@ -277,6 +277,8 @@ struct nlg_mesh {
     double *d_tmask = nullptr;
     double *d_mbinv[3] = {nullptr, nullptr, nullptr};   // mask_i * binvm1 (fused opbinv weight)
     double *d_mbinv_fg[3] = {nullptr, nullptr, nullptr};   // the same in the face-grouped layout
+    double *d_binv_fg = nullptr;                           // binvm1 alone, face-grouped, and ...
+    unsigned char *d_maskb_fg = nullptr;                   // ... one byte per point, bit i = mask_i: the three weights of k_opdiv3n in 8.5 bytes per point
     // pressure mesh
     double *d_rst2w[9] = {};   // each lpn
     double *d_bm2 = nullptr, *d_bm2inv = nullptr;

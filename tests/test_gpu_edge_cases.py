@@ -359,3 +359,44 @@ print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
         assert int(out["0"].split()[1]) >= 8, out["0"]          # the solves do outlast a ring of depth 3
         for depth in ("", "3", "1"):
             assert out[depth] == out["0"], (mode, depth, out)
+
+
+def test_compact_divergence_weights_are_bit_identical():
+    """k_opdiv3n reads the weights mask_i * binvm1 of the consistent Poisson operator as ONE array (binvm1) and one byte per point (bit i =
+    mask_i) instead of three arrays (csrc/sem.hip sem_opdiv_lanes; NLG_OPDIV_MASKB=0 = the three arrays).  Same products: a matvec gives the
+    same BITS either way, also where the three masks differ (a free-slip plane: tangential components free, normal component fixed)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from neklab_amd import host
+from neklab_amd.mesh import box_mesh
+hm = box_mesh((4, 3, 2), 8, periodic=(True, False, False), deform=0.0)
+ymin = np.abs(hm.y - hm.y.min()) < 1e-9
+zwall = (np.abs(hm.z - hm.z.min()) < 1e-9) | (np.abs(hm.z - hm.z.max()) < 1e-9)
+for c in (0, 2):
+    hm.mask[c][ymin & ~zwall] = 1.0          # free-slip on y = ymin: u and w free, v fixed
+assert not np.array_equal(hm.mask[0], hm.mask[1])
+ctx = host.Context(0); gm = host.Mesh(ctx, hm)
+gb = host.nek_dvector(gm)
+gb.set_field(0, hm.mask[0] * (1.0 + 0.5 * np.sin(hm.x) * np.cos(hm.y))); gb.set_field(1, hm.mask[1] * 0.3 * np.sin(2 * hm.x))
+A = host.exptA_linop(0.03, gb, re=40.0, dt=0.01, torder=3, vtol=1e-12, ptol=1e-11, maxit_v=400, maxit_p=4000); A.init()
+x = host.nek_dvector(gm); x.rand(True, seed=7); w = host.nek_dvector(gm)
+A.matvec(x, w)
+st = A.stats()
+words = []
+for i in range(4):
+    f = w.get_field(i).ravel()
+    words.append(float(np.sqrt(np.sum(f * f))).hex()); words.append(float(np.sum(f * (1.0 + 0.001 * (np.arange(f.size) %% 977)))).hex())
+print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for val in ("0", "1"):
+        env = dict(os.environ)
+        env["NLG_OPDIV_MASKB"] = val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[val] = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1]
+    assert out["0"] == out["1"], out
