@@ -85,7 +85,10 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
     if cls == "cg_update":    # k_cg_update<dim>: r in/out, w, pc in, z out per field (5 arrays) + the two weight arrays; x in/out and
         # p in as well (8 arrays) when the deferred solution update is switched off (NLG_PCG_DEFER_X=0) or the one-reduction PCG runs
         deferred = os.environ.get("NLG_PCG_DEFER_X", "16") != "0" and os.environ.get("NLG_PCG_SINGLE_RED", "0") == "0"
-        return 8.0 * lvs * ((5 if deferred else 8) * dim + 2)
+        # 3-D: the preconditioner is one array 1 / diag plus a mask byte per point instead of dim masked arrays (NLG_PC_MASKB=0: as before)
+        compact = dim == 3 and os.environ.get("NLG_PC_MASKB", "1") != "0" and os.environ.get("NLG_PCG_SINGLE_RED", "0") == "0"
+        per_field = (5 if deferred else 8) - (1 if compact else 0)
+        return 8.0 * lvs * (per_field * dim + 2 + (1.125 if compact else 0.0))
     if cls == "block_dot":    # k basis vectors + w + bm1 over the inner-product dofs
         return 8.0 * (k * ncomp + ncomp + 1) * lvs
     fused = k >= 24           # CGS2: first subtraction + second projection in one sweep over the last min(k, 64) vectors

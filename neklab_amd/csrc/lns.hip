@@ -103,20 +103,23 @@ __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, doub
 // x = 0, r = b (in place), z = pc*r ; partial sums of (r,z)_ipw, (r,r)_nw and sum(z)
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3 pc, const double *ipw,
-                                                const double *nw, double *partial, int64_t ld) {
+                                                const double *nw, double *partial, int64_t ld, const unsigned char *__restrict__ mb) {
     __shared__ double sm[12];
     const int64_t lo = lane_lo(ld);
     x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), partial += lo;
     double a = 0.0, b = 0.0, c3 = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double wi = ipw ? ipw[i] : 1.0, wn = nw[i];
+        // mb: the preconditioner of component c is pc.p[0] (1 / diag) where bit c of the point's mask byte is set and 0 elsewhere
+        const double inv = mb ? pc.p[0][i] : 0.0;
+        const unsigned mk = mb ? mb[i] : 0u;
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             const double rv = r.p[c][i];
             x.p[c][i] = 0.0;
             b += rv * rv * wn;
-            if (pc.p[c]) {      // pointwise (Jacobi) preconditioner; otherwise z comes from an operator
-                const double zv = pc.p[c][i] * rv;
+            if (mb || pc.p[c]) {      // pointwise (Jacobi) preconditioner; otherwise z comes from an operator
+                const double zv = (mb ? (((mk >> c) & 1u) ? inv : 0.0) : pc.p[c][i]) * rv;
                 z.p[c][i] = zv;
                 a += rv * zv * wi;
                 c3 += zv;
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(NT) void k_cg_pw(const double *s, int64_t n, CF3 p,
 // what this kernel is, so the width of an access is its efficiency.
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3 x, F3 r, F3 z, CF3 p, CF3 w, CF3 pc,
-                                                  const double *ipw, const double *nw, double *partial, int64_t ld, int defer_x) {
+                                                  const double *ipw, const double *nw, double *partial, int64_t ld, int defer_x,
+                                                  const unsigned char *__restrict__ mb) {
     __shared__ double sm[12];
     const int64_t lo = lane_lo(ld);
     s += lo, x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), p = lane_f3(p, lo), w = lane_f3(w, lo), partial += lo;
@@ -171,6 +175,9 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
     const double2 *ipw2 = reinterpret_cast<const double2 *>(ipw), *nw2 = reinterpret_cast<const double2 *>(nw);
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * NT) {
         const double2 wi = ipw ? ipw2[i] : make_double2(1.0, 1.0), wn = nw2[i];
+        // mb: pc.p[0] = 1 / diag for all components, the masks are the bits of one byte per point (3 arrays -> 1 + 1/8)
+        const double2 inv = mb ? reinterpret_cast<const double2 *>(pc.p[0])[i] : make_double2(0.0, 0.0);
+        const unsigned mk = mb ? reinterpret_cast<const unsigned short *>(mb)[i] : 0u;
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             double2 *x2 = reinterpret_cast<double2 *>(x.p[c]), *r2 = reinterpret_cast<double2 *>(r.p[c]);
@@ -186,12 +193,15 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
             rv.x -= alpha * (wv.x - wmean);
             rv.y -= alpha * (wv.y - wmean);
             double2 pcv = make_double2(1.0, 1.0);
-            if (pc.p[c]) pcv = reinterpret_cast<const double2 *>(pc.p[c])[i];
+            if (mb)
+                pcv = make_double2(((mk >> c) & 1u) ? inv.x : 0.0, ((mk >> (8 + c)) & 1u) ? inv.y : 0.0);
+            else if (pc.p[c])
+                pcv = reinterpret_cast<const double2 *>(pc.p[c])[i];
             if (pcv.x == 0.0) rv.x = 0.0;   // Dirichlet dof (the Helmholtz preconditioner carries the mask): w is not masked
             if (pcv.y == 0.0) rv.y = 0.0;
             r2[i] = rv;
             b += rv.x * rv.x * wn.x + rv.y * rv.y * wn.y;
-            if (pc.p[c]) {
+            if (mb || pc.p[c]) {
                 double2 zv;
                 zv.x = pcv.x * rv.x;
                 zv.y = pcv.y * rv.y;
@@ -207,11 +217,11 @@ __global__ __launch_bounds__(NT) void k_cg_update(const double *s, int64_t n, F3
         for (int c = 0; c < NF; ++c) {
             if (dox) x.p[c][i] += alpha * p.p[c][i];
             double rv = r.p[c][i] - alpha * (w.p[c][i] - wmean);
-            const double pcv = pc.p[c] ? pc.p[c][i] : 1.0;
+            const double pcv = mb ? (((mb[i] >> c) & 1u) ? pc.p[0][i] : 0.0) : (pc.p[c] ? pc.p[c][i] : 1.0);
             if (pcv == 0.0) rv = 0.0;
             r.p[c][i] = rv;
             b += rv * rv * wn;
-            if (pc.p[c]) {
+            if (mb || pc.p[c]) {
                 const double zv = pcv * rv;
                 z.p[c][i] = zv;
                 a += rv * zv * wi;
@@ -812,6 +822,13 @@ __global__ __launch_bounds__(NT) void k_axpy1(int64_t n, double *y, const double
 __global__ __launch_bounds__(NT) void k_recipmask(int64_t n, double *y, const double *d, const double *mask) {
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = mask[i] / d[i];
 }
+__global__ __launch_bounds__(NT) void k_maskbits(int64_t n, double *y, const double *m0, const double *m1, const double *m2) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        y[i] = (m0[i] != 0.0 ? 1.0 : 0.0) + (m1 && m1[i] != 0.0 ? 2.0 : 0.0) + (m2 && m2[i] != 0.0 ? 4.0 : 0.0);
+}
+__global__ __launch_bounds__(NT) void k_to_bytes(int64_t n, unsigned char *y, const double *x) {
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = (unsigned char)x[i];
+}
 __global__ __launch_bounds__(NT) void k_recip1(int64_t n, double *y, const double *d) {
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = 1.0 / d[i];
 }
@@ -869,6 +886,10 @@ struct nlg_linop {
     // weight permuted once; 0 = natural layout (2-D, lx1 > 8, NLG_XP=0)
     int use_xp = -1;
     double *pcv_xp[4][3] = {}, *nwv_xp = nullptr;
+    // the same preconditioners as ONE array 1 / diag(H) per BDF order plus one mask byte per point (bit c = mask of component c), in the
+    // layout of the velocity solve: what k_cg_init / k_cg_update read (3 streams -> 1 + 1/8); pci_l[k] = {pci[k], pci[k], pci[k]}
+    double *pci[4] = {}, *pci_l[4][3] = {};
+    unsigned char *maskb_v = nullptr;
     double *pce = nullptr;     // 1 / diag(E)
     double *prX = nullptr, *prB = nullptr, *d_pc = nullptr;   // pressure residual projection: PROJ_L solution / image pairs, coefficients
     int nproj = 0;
@@ -1036,6 +1057,7 @@ struct CGProblem {
     int64_t n;           // entries per field
     double *const *x, *const *r, *const *z, *const *p, *const *w;
     double *const *pc;
+    const unsigned char *pc_mb = nullptr;   // non-null: pc[0] = 1 / diag for every component, bit c of byte i = mask of component c at point i
     const double *ipw, *nw;
     double tol2;         // squared tolerance on sum r^2 nw
     int use_tol, maxit;
@@ -1095,7 +1117,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         }
         return 0;
     };
-    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, lgrid(g, nl), st, P.n, x, r, z, pc, P.ipw, P.nw, partial, ld);
+    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, lgrid(g, nl), st, P.n, x, r, z, pc, P.ipw, P.nw, partial, ld, P.pc_mb);
     if (P.sd && P.apply_plain && !P.precond && P.pw_part) {
         // ---- single-reduction PCG (Chronopoulos-Gear): ONE reduction per iteration carries (w, u), (r, u) and |r|^2; several ranks: one
         // all-reduce instead of two.  u = M^-1 r lives in z, p and s = A p are recurrences.  Same iterates as the loop below in exact
@@ -1176,7 +1198,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         if (!P.rr_part) {
             ProfScope pu(ctx, P_CGUPDATE);   // the largest single kernel of a step by time: its own class inside cg_vec (bench.py quotes its roofline)
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, lgrid(g, nl), st, (const double *)s, P.n, x, r, z, cp, cw,
-                      pc, P.ipw, P.nw, partial, ld, (int)(P.hist.ph > 0));
+                      pc, P.ipw, P.nw, partial, ld, (int)(P.hist.ph > 0), P.pc_mb);
             if (P.hist.ph > 0 && (nbody + 1) % P.hist.ph == 0)   // the direction ring is full: its PH terms go into x before slot 0 is overwritten
                 launch_nf(nf, k_x_flush<1>, k_x_flush<2>, k_x_flush<3>, lgrid(grid_for(P.n), nl), st, (const double *)s, P.n, x, P.hist, nbody, ld);
         }
@@ -1257,6 +1279,10 @@ int helm_problem(const Lanes &L, int order, double h2, HelmSolve &H) {
     P.p = op->pv;
     P.w = op->w;
     P.pc = xp ? op->pcv_xp[order] : op->pcv[order];
+    if (op->maskb_v) {   // 1 / diag and the mask bytes instead of the three masked arrays (same values)
+        P.pc = op->pci_l[order];
+        P.pc_mb = op->maskb_v;
+    }
     P.ipw = xp ? m->d_vmult_xp : m->d_vmult;
     P.nw = xp ? op->nwv_xp : op->nwv;
     P.tol2 = c.vtol * c.vtol;
@@ -2124,6 +2150,8 @@ int nlg_linop_destroy(nlg_linop *op) {
         for (int k = 0; k < 4; ++k) fr(op->pcv[k][c]);
         for (int k = 0; k < 4; ++k) fr(op->pcv_xp[k][c]);
     }
+    for (int k = 0; k < 4; ++k) fr(op->pci[k]);
+    if (op->maskb_v) hipFree(op->maskb_v);
     for (int q = 0; q < 9; ++q) fr(op->GU[q]);
     fr(op->pce);
     for (int q = 0; q < 3; ++q) fr(op->GT[q]);
@@ -2220,6 +2248,36 @@ int nlg_linop_init(nlg_linop *op) {
                 if (!op->pcv_xp[k][c]) NLG_TRY(lalloc(op, &op->pcv_xp[k][c], m->lvs));
             NLG_TRY(sem_to_xp(m, op->pcv[k], op->pcv_xp[k], dim));
         }
+    }
+    // compact form for the streaming kernels of the PCG: needs masks of zeros and ones (sem.hip checked that when it built the byte masks
+    // of the pressure operator: m->d_maskb_fg exists) -- NLG_PC_MASKB=0 keeps the three arrays
+    if (dim == 3 && m->d_maskb_fg && !op->use_sr && !(getenv("NLG_PC_MASKB") && atoi(getenv("NLG_PC_MASKB")) == 0)) {
+        double *t0 = sem_scratch1(m, 3), *t1 = sem_scratch1(m, 4);
+        NLG_CHECK(t0 && t1, "nlg_linop_init: scratch allocation failed");
+        const bool xp = op->use_xp > 0;
+        for (int k = 1; k <= op->cfg.torder; ++k) {
+            NLG_TRY(sem_helm_diag(m, t0, nu, BDF_B0[k] / op->dt));
+            double *f[1] = {t0};
+            NLG_TRY(sem_gs(m, f, 1));
+            if (!op->pci[k]) NLG_TRY(lalloc(op, &op->pci[k], m->lvs));
+            NLG_LAUNCH(k_recip1, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, xp ? t1 : op->pci[k], (const double *)t0);
+            if (xp) {
+                double *a[1] = {t1}, *b[1] = {op->pci[k]};
+                NLG_TRY(sem_to_xp(m, a, b, 1));
+            }
+            for (int c = 0; c < 3; ++c) op->pci_l[k][c] = op->pci[k];
+        }
+        NLG_LAUNCH(k_maskbits, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, t0, (const double *)m->d_mask[0], (const double *)m->d_mask[1],
+                           (const double *)m->d_mask[2]);
+        if (xp) {
+            double *a[1] = {t0}, *b[1] = {t1};
+            NLG_TRY(sem_to_xp(m, a, b, 1));
+        }
+        if (!op->maskb_v) {
+            NLG_HIP(hipMalloc(&op->maskb_v, (size_t)m->lvs));
+            NLG_HIP(hipMemsetAsync(op->maskb_v, 0, (size_t)m->lvs, st));
+        }
+        NLG_LAUNCH(k_to_bytes, dim3(grid_for(m->lvn)), dim3(NT), 0, st, m->lvn, op->maskb_v, (const double *)(xp ? t1 : t0));
     }
     if (op->cfg.ifheat) {
         if (!op->pct[1]) {

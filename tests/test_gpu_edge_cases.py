@@ -364,7 +364,8 @@ print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
 def test_compact_divergence_weights_are_bit_identical():
     """k_opdiv3n reads the weights mask_i * binvm1 of the consistent Poisson operator as ONE array (binvm1) and one byte per point (bit i =
     mask_i) instead of three arrays (csrc/sem.hip sem_opdiv_lanes; NLG_OPDIV_MASKB=0 = the three arrays).  Same products: a matvec gives the
-    same BITS either way, also where the three masks differ (a free-slip plane: tangential components free, normal component fixed)."""
+    same BITS either way, also where the three masks differ (a free-slip plane: tangential components free, normal component fixed).  The
+    Jacobi preconditioner mask_i / diag(H) of the velocity PCG is read the same way (1 / diag and the mask bytes, NLG_PC_MASKB=0 = three arrays)."""
     import os
     import subprocess
     import sys
@@ -393,10 +394,11 @@ for i in range(4):
 print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for val in ("0", "1"):
+    for val in ("00", "10", "01", "11"):     # (divergence weights, Jacobi preconditioner of the velocity PCG: k_cg_init / k_cg_update, NLG_PC_MASKB)
         env = dict(os.environ)
-        env["NLG_OPDIV_MASKB"] = val
+        env["NLG_OPDIV_MASKB"] = val[0]
+        env["NLG_PC_MASKB"] = val[1]
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         out[val] = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1]
-    assert out["0"] == out["1"], out
+    assert out["00"] == out["10"] == out["01"] == out["11"], out
