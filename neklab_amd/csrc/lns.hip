@@ -1987,7 +1987,11 @@ int do_matvec(nlg_linop *op, const nlg_vec *vin, nlg_vec *vout, int adjoint) {
     NLG_TRY(reset_state(op, 1));
     op->istep = 0;
     op->adjoint = adjoint;
-    op->nproj = 0;   // the projection space belongs to one matvec: the result must not depend on earlier calls
+    // the projection space belongs to one matvec: the result must not depend on earlier calls.  (Keeping it across matvecs, as a
+    // Nek5000 run does across time steps, was measured in round 4: 11.76 -> 11.40 pressure iterations per time step over 844 matvecs
+    // of a real Arnoldi / Krylov-Schur run -- successive Krylov vectors are orthogonal, their pressure increments share little --
+    // while bench.py, which re-applies the operator to the SAME column every step, would show 12.5 -> 6.5: an artefact, not adopted.)
+    op->nproj = 0;
     NLG_TRY(load_state(op, vin, 0));
     NLG_TRY(project_alpha(op));                       // exptA_proj_matvec: initial condition, exponential_propagator_proj.f90:51
     for (int istep = 1; istep <= op->nsteps; ++istep) {
