@@ -103,7 +103,7 @@ __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, doub
 // x = 0, r = b (in place), z = pc*r ; partial sums of (r,z)_ipw, (r,r)_nw and sum(z)
 template <int NF>
 __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3 pc, const double *ipw,
-                                                const double *nw, double *partial, int64_t ld, const unsigned char *__restrict__ mb) {
+                                                const double *nw, double *partial, int64_t ld, const unsigned char *__restrict__ mb, int defer_x) {
     __shared__ double sm[12];
     const int64_t lo = lane_lo(ld);
     x = lane_f3(x, lo), r = lane_f3(r, lo), z = lane_f3(z, lo), partial += lo;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NT) void k_cg_init(int64_t n, F3 x, F3 r, F3 z, CF3
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             const double rv = r.p[c][i];
-            x.p[c][i] = 0.0;
+            if (!defer_x) x.p[c][i] = 0.0;   // (deferred solution update: x is first WRITTEN by k_x_flush / never read before that)
             b += rv * rv * wn;
             if (mb || pc.p[c]) {      // pointwise (Jacobi) preconditioner; otherwise z comes from an operator
                 const double zv = (mb ? (((mk >> c) & 1u) ? inv : 0.0) : pc.p[c][i]) * rv;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT) void k_x_flush(const double *__restrict__ s, in
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             const double *__restrict__ pc = H.p0[c] + lo + i;
-            double t = x.p[c][i];
+            double t = w0 > 0 ? x.p[c][i] : 0.0;   // the first window starts the sum (k_cg_init leaves x alone)
 #pragma unroll 4
             for (int q = 0; q < H.ph; ++q) t += s[S_AH + ((w0 + q) & (kAlphaRing - 1))] * pc[q * H.stride];   // (alpha: wave-uniform scalar loads)
             x.p[c][i] = t;
@@ -326,10 +326,10 @@ __global__ __launch_bounds__(NT) void k_add_hist(const double *__restrict__ s, i
 #pragma unroll
         for (int c = 0; c < NF; ++c) {
             const double *__restrict__ pc = H.p0[c] + lo + q;
-            double t = x.p[c][q];
+            double t = w0 > 0 ? x.p[c][q] : 0.0;   // x holds the full windows, if there were any
 #pragma unroll 4
             for (int k = 0; k < cnt; ++k) t += s[S_AH + ((w0 + k) & (kAlphaRing - 1))] * pc[k * H.stride];
-            y.p[c][i] = a.p[c][i] + t;
+            y.p[c][i] = a.p[c] ? a.p[c][i] + t : t;   // (a == null: the solution itself, the pressure solve)
         }
     }
 }
@@ -875,6 +875,8 @@ struct nlg_linop {
     double *rhs[3] = {}, *x[3] = {}, *z[3] = {}, *pv[3] = {}, *w[3] = {}, *gp[3] = {};
     // single-reduction PCG (Chronopoulos-Gear; several ranks, NLG_PCG_SINGLE_RED): the search direction and its image as recurrences
     bool use_sr = false;
+    int php = 0;               // the same for the pressure PCG (ring prh[php][lps]; the update rides in the preconditioner, the direction update in the gradient kernel)
+    double *prh = nullptr;
     int ph = 0;                // depth of the direction ring of the velocity PCG (deferred solution update, k_add_hist); 0 = x updated every iteration
     double *phist = nullptr;   // [ph][dim][lvs]
     double *cgs[3] = {}, *tcgs = nullptr;
@@ -971,6 +973,7 @@ void lane_buffers(nlg_linop *op, F f) {
     if (op->cfg.ifheat)
         for (double **v : {&op->trhs, &op->tx, &op->tz, &op->tpv, &op->tw}) f(v, m->lvs);
     if (op->ph > 0) f(&op->phist, (int64_t)op->ph * dim * m->lvs);
+    if (op->php > 0) f(&op->prh, (int64_t)op->php * m->lps);
     if (op->use_sr) {
         for (int c = 0; c < dim; ++c) f(&op->cgs[c], m->lvs);
         if (op->cfg.ifheat) f(&op->tcgs, m->lvs);
@@ -1001,6 +1004,7 @@ void lane_bind(nlg_linop *owner, nlg_linop *ln, int v) {
     ln->cfg.ifheat = owner->cfg.ifheat;   // (same buffer list as the owner's)
     ln->use_sr = owner->use_sr;
     ln->ph = owner->ph;
+    ln->php = owner->php;
     lane_buffers(ln, [&](double **p, int64_t len) {
         *p = base + off;
         off += round_up(len, kAlign);
@@ -1117,7 +1121,7 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
         }
         return 0;
     };
-    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, lgrid(g, nl), st, P.n, x, r, z, pc, P.ipw, P.nw, partial, ld, P.pc_mb);
+    launch_nf(nf, k_cg_init<1>, k_cg_init<2>, k_cg_init<3>, lgrid(g, nl), st, P.n, x, r, z, pc, P.ipw, P.nw, partial, ld, P.pc_mb, (int)(P.hist.ph > 0));
     if (P.sd && P.apply_plain && !P.precond && P.pw_part) {
         // ---- single-reduction PCG (Chronopoulos-Gear): ONE reduction per iteration carries (w, u), (r, u) and |r|^2; several ranks: one
         // all-reduce instead of two.  u = M^-1 r lives in z, p and s = A p are recurrences.  Same iterates as the loop below in exact
@@ -1199,8 +1203,6 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
             ProfScope pu(ctx, P_CGUPDATE);   // the largest single kernel of a step by time: its own class inside cg_vec (bench.py quotes its roofline)
             launch_nf(nf, k_cg_update<1>, k_cg_update<2>, k_cg_update<3>, lgrid(g, nl), st, (const double *)s, P.n, x, r, z, cp, cw,
                       pc, P.ipw, P.nw, partial, ld, (int)(P.hist.ph > 0), P.pc_mb);
-            if (P.hist.ph > 0 && (nbody + 1) % P.hist.ph == 0)   // the direction ring is full: its PH terms go into x before slot 0 is overwritten
-                launch_nf(nf, k_x_flush<1>, k_x_flush<2>, k_x_flush<3>, lgrid(grid_for(P.n), nl), st, (const double *)s, P.n, x, P.hist, nbody, ld);
         }
         ++nbody;
         if (prof_cg) prof_end(ctx, P_CGVEC);
@@ -1209,6 +1211,8 @@ int run_pcg(nlg_linop *op, const CGProblem &P, Apply apply, int *iters_out) {
             if (!P.rz_part)
                 launch_nf(nf, k_cg_rz<1>, k_cg_rz<2>, k_cg_rz<3>, lgrid(g, nl), st, (const double *)s, 1, P.n, cr, cz, P.ipw, xc, P.npe, partial, ld);
         }
+        if (P.hist.ph > 0 && nbody % P.hist.ph == 0)   // the direction ring is full: its PH terms go into x before slot 0 is overwritten
+            launch_nf(nf, k_x_flush<1>, k_x_flush<2>, k_x_flush<3>, lgrid(grid_for(P.n), nl), st, (const double *)s, P.n, x, P.hist, nbody - 1, ld);
         NLG_TRY(reduce_post(rd_rz_loop, 3, 1, 2));
         if (!P.fused_pupdate)
             launch_nf(nf, k_cg_pupdate<1>, k_cg_pupdate<2>, k_cg_pupdate<3>, lgrid(g, nl), st, (const double *)s, P.n, p, cz, xc, P.npe, ld);
@@ -1493,6 +1497,7 @@ struct PresSolve {
     double *pw_part = nullptr;
     bool proj = false;
     int nold = 0;
+    mutable int it = 0;   // operator applications so far (slot of the direction ring, modulo its depth)
 };
 
 int pres_problem(const Lanes &L, double scale, PresSolve &Q) {
@@ -1532,6 +1537,18 @@ int pres_problem(const Lanes &L, double scale, PresSolve &Q) {
         upd.wmean = op->d_s + S_N + S_WMEAN;
         upd.x = op->pr_x;
         upd.p = op->pr_p;
+        {
+            // deferred solution update (as in the velocity solve, k_cg_update): the gradient kernel's fused direction update stores direction
+            // i into slot i mod php of a ring, the update kernel of the preconditioner streams neither x nor p, pres_solve assembles x
+            static const bool fuse = !(getenv("NLG_FUSE_PPUPDATE") && atoi(getenv("NLG_FUSE_PPUPDATE")) == 0);
+            if (op->php > 0 && fuse && sem_opgradt_fuses_pupdate(m)) {
+                upd.x = nullptr;
+                upd.p = nullptr;
+                P.hist.p0[0] = op->prh;
+                P.hist.stride = m->lps;
+                P.hist.ph = op->php;
+            }
+        }
         upd.w = op->pr_w;
         upd.nw = op->nwp;
         upd.rr_part = op->d_part + 2 * m->E + 2 * ((m->E + 3) / 4);
@@ -1592,11 +1609,19 @@ int pres_problem(const Lanes &L, double scale, PresSolve &Q) {
 // gated: launches past convergence (the host only looks at the flags once per chunk) return at once
 int pres_apply(const Lanes &L, const PresSolve &Q) {
     nlg_linop *op = L.op();
+    // direction ring (deferred solution update): read direction it - 1, the fused update stores direction it one slot further
+    double *p_in = op->pr_p, *p_out = op->pr_p;
+    if (Q.P.hist.ph > 0) {
+        const int ph = Q.P.hist.ph, so = Q.it % ph, si = (Q.it + ph - 1) % ph;
+        ++Q.it;
+        p_in = op->prh + (int64_t)si * Q.P.hist.stride;
+        p_out = op->prh + (int64_t)so * Q.P.hist.stride;
+    }
     if (L.nl == 1) {
         if (Q.P.fused_pupdate) {   // p <- (z - zmean) + beta p while the gradient kernel loads p
             nlg_pupd u;
-            u.z = op->pr_z, u.beta = op->d_s + S_N + S_BETA, u.zmean = op->d_s + S_N + S_ZMEAN, u.p = op->pr_p;
-            return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE, &u);
+            u.z = op->pr_z, u.beta = op->d_s + S_N + S_BETA, u.zmean = op->d_s + S_N + S_ZMEAN, u.p = p_out;
+            return sem_cdabdtp(op->mesh, p_in, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE, &u);
         }
         return sem_cdabdtp(op->mesh, op->pr_p, op->pr_w, Q.pw_part, op->d_s + S_N + S_DONE);
     }
@@ -1606,9 +1631,9 @@ int pres_apply(const Lanes &L, const PresSolve &Q) {
     nlg_pupd pu[kMaxLanes];
     const int64_t ld = L.ld();
     for (int v = 0; v < L.nl; ++v) {
-        pp[v] = op->pr_p + v * ld, ww[v] = op->pr_w + v * ld, pw[v] = Q.pw_part + v * ld, gg[v] = op->d_s + S_N + S_DONE + v * ld;
+        pp[v] = p_in + v * ld, ww[v] = op->pr_w + v * ld, pw[v] = Q.pw_part + v * ld, gg[v] = op->d_s + S_N + S_DONE + v * ld;
         if (Q.P.fused_pupdate)
-            pu[v].z = op->pr_z + v * ld, pu[v].beta = op->d_s + S_N + S_BETA + v * ld, pu[v].zmean = op->d_s + S_N + S_ZMEAN + v * ld, pu[v].p = op->pr_p + v * ld;
+            pu[v].z = op->pr_z + v * ld, pu[v].beta = op->d_s + S_N + S_BETA + v * ld, pu[v].zmean = op->d_s + S_N + S_ZMEAN + v * ld, pu[v].p = p_out + v * ld;
     }
     return sem_cdabdtp_lanes(op->mesh, L.nl, pp, ww, pw, gg, Q.P.fused_pupdate ? pu : nullptr);
 }
@@ -1673,6 +1698,14 @@ int pres_solve(const Lanes &L, double scale) {
     auto apply = [&](double *) -> int { return pres_apply(L, Q); };
     int iters[kMaxLanes] = {};
     NLG_TRY(run_pcg(L.op(), Q.P, apply, iters));
+    if (Q.P.hist.ph > 0) {   // x = sum alpha_i p_i, in iteration order (k_add_hist without an addend)
+        nlg_linop *op = L.op();
+        nlg_mesh *m = op->mesh;
+        F3 y = {{op->pr_x, nullptr, nullptr}};
+        CF3 none = {{nullptr, nullptr, nullptr}}, x = {{op->pr_x, nullptr, nullptr}};
+        NLG_LAUNCH(k_add_hist<1>, lgrid(grid_for(m->lpn), L.nl), dim3(NT), 0, m->ctx->stream, (const double *)Q.P.s, m->lpn, 1, (const int *)nullptr, y, none, x,
+                   Q.P.hist, L.ld());
+    }
     return pres_finish(L, Q, iters);
 }
 
@@ -2211,6 +2244,10 @@ int nlg_linop_init(nlg_linop *op) {
         const int64_t slot_bytes = (int64_t)sizeof(double) * dim * m->lvs;
         const int ph_auto = (int)std::max<int64_t>(3, std::min<int64_t>(16, ((int64_t)8 << 30) / std::max<int64_t>(slot_bytes, 1)));
         op->ph = op->use_sr ? 0 : std::max(0, std::min(kAlphaRing, getenv("NLG_PCG_DEFER_X") ? atoi(getenv("NLG_PCG_DEFER_X")) : ph_auto));
+        // ... and of the pressure PCG, where the gradient kernel performs the direction update (3-D, lx1 = 8 .. 10).  Opt-in
+        // (NLG_PCG_DEFER_XP=16): measured neutral at 10^4 elements -- the update kernel of the preconditioner drops 3 of its 9 streams
+        // (preconditioner class 7.06 -> 6.83 ms per step), the assembly of x and the colder directions give it back (44.5 ms either way)
+        op->php = (dim == 3 && sem_opgradt_fuses_pupdate(m) && getenv("NLG_PCG_DEFER_XP")) ? std::max(0, std::min(kAlphaRing, atoi(getenv("NLG_PCG_DEFER_XP")))) : 0;
         NLG_TRY(slab_ensure(op, 1));   // the work buffers of one lane; a block matvec grows the slab on first use
     }
     double *U[3] = {op->baseflow->vel(0), op->baseflow->vel(1), dim == 3 ? op->baseflow->vel(2) : nullptr};

@@ -783,7 +783,8 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restri
         r += lo;
         t += (int64_t)blockIdx.y * lt;
         if (W) W += (int64_t)blockIdx.y * lW;
-        if (u.alpha) u.alpha += lo, u.wmean += lo, u.x += lo, u.p += lo, u.w += lo, u.rr_part += lo;
+        if (u.alpha) u.alpha += lo, u.wmean += lo, u.w += lo, u.rr_part += lo;
+        if (u.x) u.x += lo, u.p += lo;   // (x == null: deferred solution update, the directions stay in the ring of the solver)
     }
     if (flag && flag[0] != 0.0) return;
     constexpr int NC = 1 << DIM;
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local(const double *__restri
         double v = r[e * np2 + q];
         if (upd) {   // the PCG update of this point: the new residual is what gets restricted
             const int64_t i = e * np2 + q;
-            u.x[i] += alpha * u.p[i];
+            if (u.x) u.x[i] += alpha * u.p[i];
             v -= alpha * (u.w[i] - wmean);
             r[i] = v;
             rr += v * v * u.nw[i];
@@ -869,7 +870,8 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
         r += lo;
         t += (int64_t)blockIdx.y * lt;
         if (W) W += (int64_t)blockIdx.y * lW;
-        if (u.alpha) u.alpha += lo, u.wmean += lo, u.x += lo, u.p += lo, u.w += lo, u.rr_part += lo;
+        if (u.alpha) u.alpha += lo, u.wmean += lo, u.w += lo, u.rr_part += lo;
+        if (u.x) u.x += lo, u.p += lo;   // (x == null: deferred solution update, the directions stay in the ring of the solver)
     }
     if (flag && flag[0] != 0.0) return;
     constexpr int NP2 = N2 * N2 * N2, N = N2 + 2, NIT = 4;   // four points per lane in flight (lx1 = 8: the whole element)
@@ -892,10 +894,9 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
             const int64_t i = (act ? e : 0) * NP2 + qc;
             v[it] = r[i];
             if (upd) {
-                pv[it] = u.p[i];
                 wv[it] = u.w[i];
-                xv[it] = u.x[i];
                 nv[it] = u.nw[i];
+                if (u.x) pv[it] = u.p[i], xv[it] = u.x[i];
             }
             if (W) {
                 qv[it] = wq[i];
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(NT) void k_q1_restrict_local3s(const double *__rest
             const int64_t i = e * NP2 + q;
             double vv = v[it];
             if (upd) {
-                u.x[i] = xv[it] + alpha * pv[it];
+                if (u.x) u.x[i] = xv[it] + alpha * pv[it];
                 vv -= alpha * (wv[it] - wmean);
                 r[i] = vv;
                 rr += vv * vv * nv[it];

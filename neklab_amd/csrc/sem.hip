@@ -4157,7 +4157,10 @@ int sem_cdabdtp_lanes(nlg_mesh *m, int nl, const double *const *p, double *const
     } else {
         for (int v = 0; v < nl; ++v) NLG_TRY(sem_gs(m, w[v], m->dim, gate ? gate[v] : nullptr, fg ? LAYOUT_FG : LAYOUT_NAT));
     }
-    return sem_opdiv_lanes(m, nl, wl, out, 1.0, fg ? m->d_mbinv_fg : m->d_mbinv, fg, p, pw_part, gate);
+    // (p, E p): p AFTER the fused direction update, which may have gone to another buffer than the one it was read from (direction ring)
+    const double *pd[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int v = 0; v < nl; ++v) pd[v] = (upd && upd[v].z && upd[v].p) ? upd[v].p : p[v];
+    return sem_opdiv_lanes(m, nl, wl, out, 1.0, fg ? m->d_mbinv_fg : m->d_mbinv, fg, pd, pw_part, gate);
 }
 
 int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, const double *gate, const nlg_pupd *upd) {
@@ -4168,7 +4171,7 @@ int sem_cdabdtp(nlg_mesh *m, const double *p, double *out, double *pw_part, cons
         // shared face are contiguous runs -> coalesced gather-scatter; the rank halo uses index lists in that layout
         NLG_TRY(sem_opgradt(m, p, w, true, gate, upd));
         NLG_TRY(sem_gs(m, w, 3, gate, LAYOUT_FG));
-        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, p, pw_part, gate));
+        NLG_TRY(sem_opdiv(m, w, out, 1.0, m->d_mbinv_fg, true, (upd && upd->z && upd->p) ? upd->p : p, pw_part, gate));   // (p, E p) with the UPDATED p
         return 0;
     }
     NLG_TRY(sem_opgradt(m, p, w, false, gate, upd));

@@ -314,7 +314,9 @@ def test_deferred_solution_update_of_the_velocity_pcg_is_bit_identical():
     logic keeps alpha_i, and the consumer of x assembles x = sum alpha_i p_i in iteration order (csrc/lns.hip k_add_hist; k_x_flush when a
     solve outlasts the ring).  Same additions on the same operands: the matvec must give the same BITS with the ring switched off
     (NLG_PCG_DEFER_X=0, x += alpha p inside k_cg_update), at its default depth, at depth 3 (several flushes and wrap-arounds per solve) and
-    at depth 1 (in place, a flush every iteration) -- 3-D single vector, 2-D, and a block of three lanes that converge at different counts."""
+    at depth 1 (in place, a flush every iteration) -- 3-D single vector, 2-D, and a block of three lanes that converge at different counts.
+    The pressure PCG does the same where the gradient kernel performs the direction update (NLG_PCG_DEFER_XP; the update kernel of the
+    preconditioner then streams neither x nor p, pres_solve assembles x)."""
     import os
     import subprocess
     import sys
@@ -348,16 +350,18 @@ print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("3d", "2d", "block"):
         out = {}
-        for depth in ("0", "", "3", "1"):
+        for depth in ("0", "", "3", "1", "16"):      # ("": the defaults -- velocity ring 16, pressure ring off)
             env = dict(os.environ)
             env.pop("NLG_PCG_DEFER_X", None)
+            env.pop("NLG_PCG_DEFER_XP", None)
             if depth:
                 env["NLG_PCG_DEFER_X"] = depth
+                env["NLG_PCG_DEFER_XP"] = depth      # the pressure PCG keeps its directions in a ring of its own (3-D, lx1 = 8 .. 10)
             r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600, env=env)
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
             out[depth] = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1]
         assert int(out["0"].split()[1]) >= 8, out["0"]          # the solves do outlast a ring of depth 3
-        for depth in ("", "3", "1"):
+        for depth in ("", "3", "1", "16"):
             assert out[depth] == out["0"], (mode, depth, out)
 
 
