@@ -1453,8 +1453,24 @@ int heat_step(const Lanes &L, int k, double b0) {
     P.pw_n = sem_axhelm_blocks(m, 1);
     P.pw_sum = false;
     P.fused_pupdate = true;
+    // deferred solution update as in the velocity solve (helm_apply): the scalar's directions use the velocity solve's ring, one field wide
+    // (the two solves never overlap: each ring is consumed right after its solve)
+    const bool defer = op->ph > 0 && !op->use_sr;
+    if (defer) {
+        P.hist.p0[0] = op->phist;
+        P.hist.stride = m->lvs;
+        P.hist.ph = op->ph;
+    }
+    int napp = 0;
     auto apply = [&](double *) -> int {
-        NLG_TRY(sem_axhelm(m, p, tw, 1, h1, h2, op->d_part, z, op->d_s + S_BETA, op->d_s + S_DONE, false, nl, ld));
+        if (defer) {
+            const int ph = op->ph, so = napp % ph, si = (napp + ph - 1) % ph;
+            ++napp;
+            double *pin[1] = {op->phist + (int64_t)si * m->lvs};
+            NLG_TRY(sem_axhelm(m, pin, tw, 1, h1, h2, op->d_part, z, op->d_s + S_BETA, op->d_s + S_DONE, false, nl, ld, (so - si) * (int64_t)m->lvs));
+        } else {
+            NLG_TRY(sem_axhelm(m, p, tw, 1, h1, h2, op->d_part, z, op->d_s + S_BETA, op->d_s + S_DONE, false, nl, ld));
+        }
         NLG_TRY(sem_gs(m, tw, 1, op->d_s + S_DONE, LAYOUT_NAT, nl, ld, ld));
         return 0;
     };
@@ -1476,7 +1492,10 @@ int heat_step(const Lanes &L, int k, double b0) {
     {
         F3 y = {{op->tbuf[2], nullptr, nullptr}};
         CF3 a = {{op->tbuf[0], nullptr, nullptr}}, b = {{op->tx, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr}};
-        NLG_LAUNCH(k_lin3<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0, ld);
+        if (defer)
+            NLG_LAUNCH(k_add_hist<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, (const double *)op->d_s, m->lvn, 1, (const int *)nullptr, y, a, b, P.hist, ld);
+        else
+            NLG_LAUNCH(k_lin3<1>, lgrid(grid_for(m->lvn), nl), dim3(NT), 0, st, m->lvn, y, a, b, 1.0, none, 0.0, ld);
         for (int v = 0; v < nl; ++v) {
             nlg_linop *ln = L.ops[v];
             double *t = ln->tbuf[2];

@@ -330,25 +330,28 @@ dim = 2 if mode == "2d" else 3
 hm = box_mesh((5, 4) if dim == 2 else (4, 3, 2), 7 if dim == 2 else 8, periodic=(True,) + (False,) * (dim - 1), deform=0.04)
 ctx = host.Context(0); gm = host.Mesh(ctx, hm)
 X = [hm.x, hm.y] + ([hm.z] if dim == 3 else [])
-gb = host.nek_dvector(gm)
+heat = mode == "heat"
+gb = host.nek_dvector(gm, 1 if heat else 0)
 gb.set_field(0, hm.mask[0] * (1.0 + 0.5 * np.sin(X[0]) * np.cos(X[1]))); gb.set_field(1, hm.mask[1] * 0.3 * np.sin(2 * X[0]))
-A = host.exptA_linop(0.05, gb, re=40.0, dt=0.01, torder=3, vtol=1e-12, ptol=1e-11, maxit_v=400, maxit_p=4000); A.init()
+kw = dict(ifheat=1, conductivity=0.3, rhocp=1.5, buoy=(0.0, 5.0, 0.0)) if heat else {}
+if heat: gb.set_field(host.THETA, 1.0 - X[1] / hm.lengths[1])
+A = host.exptA_linop(0.05, gb, re=40.0, dt=0.01, torder=3, vtol=1e-12, ptol=1e-11, maxit_v=400, maxit_p=4000, **kw); A.init()
 s = 3 if mode == "block" else 1
 vin = []
 for v in range(s):
-    x = host.nek_dvector(gm); x.rand(True, seed=40 + v); x.scal(10.0 ** (-3 * v)); vin.append(x)
-out = [host.nek_dvector(gm) for _ in range(s)]
+    x = host.nek_dvector(gm, 1 if heat else 0); x.rand(True, seed=40 + v); x.scal(10.0 ** (-3 * v)); vin.append(x)
+out = [host.nek_dvector(gm, 1 if heat else 0) for _ in range(s)]
 if s == 1: A.matvec(vin[0], out[0])
 else: A.matvec_block(vin, out)
 st = A.stats()
 words = []
 for w in out:
-    for i in range(dim):
+    for i in list(range(dim)) + ([host.THETA] if heat else []):
         f = w.get_field(i).ravel()
         words.append(float(np.sqrt(np.sum(f * f))).hex()); words.append(float(np.sum(f * (1.0 + 0.001 * (np.arange(f.size) %% 977)))).hex())
 print("RESULT", st["v_iters"], st["p_iters"], " ".join(words))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("3d", "2d", "block"):
+    for mode in ("3d", "2d", "block", "heat"):
         out = {}
         for depth in ("0", "", "3", "1", "16"):      # ("": the defaults -- velocity ring 16, pressure ring off)
             env = dict(os.environ)
