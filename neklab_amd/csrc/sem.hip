@@ -3683,8 +3683,16 @@ int sem_to_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int n
 int sem_from_xp(nlg_mesh *m, double *const *src, double *const *dst, int nf, int nl, int64_t ld) { return xp_perm(m, src, dst, nf, false, nl, ld); }
 
 // (element, field) slots per block of k_axhelm3: bounded by 512 threads and by 64 KB of dynamic LDS
+// waves = (element, field) slots per block of k_axhelm3r.  Three: the three components of ONE element share a block, hence an XCD and its
+// L2 -- the seven metric arrays are 37 % of the kernel's bytes, and with four slots per block two thirds of the elements had their
+// components in two blocks, i.e. on two XCDs (measured traffic 1.18 x algorithmic).  Same box: 5.62 (four) -> 5.46 (three) ms per step,
+// 6.46 with six.  NLG_AXHELM_WPB = 4 / 6 for A/B runs.
+static int axhelm3_wpb() {
+    static const int w = getenv("NLG_AXHELM_WPB") ? atoi(getenv("NLG_AXHELM_WPB")) : 3;
+    return (w == 4 || w == 6) ? w : 3;
+}
 static int axhelm3_nslot(int N) {
-    if (N <= 8) return 4;   // k_axhelm3r: four waves = four (element, field) slots per block
+    if (N <= 8) return axhelm3_wpb();   // k_axhelm3r: one wave per (element, field) slot
     int nslot = 512 / (N * N);
     const int lds_cap = (int)((64 * 1024 / 8 - N * N) / (4 * N * N * N));
     if (nslot > lds_cap) nslot = lds_cap;
@@ -3763,9 +3771,21 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         const int grid = (int)((tot + nslot - 1) / nslot);                                                            \
         const size_t lds = sizeof(double) * (size_t)(N_ * N_ + nslot * 4 * N_ * N_ * N_);                             \
         if constexpr (N_ <= 8) {                                                                                      \
-            if (xp)                                                                                                   \
+            if (xp && nslot == 3)                                                                                     \
+            NLG_LAUNCH((k_axhelm3r<N_, 3, true>), dim3(grid, nl), dim3(192), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
+            else if (xp && nslot == 6)                                                                                \
+            NLG_LAUNCH((k_axhelm3r<N_, 6, true>), dim3(grid, nl), dim3(384), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
+            else if (xp)                                                                                              \
             NLG_LAUNCH((k_axhelm3r<N_, 4, true>), dim3(grid, nl), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
                                m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
+            else if (nslot == 3)                                                                                      \
+            NLG_LAUNCH((k_axhelm3r<N_, 3, false>), dim3(grid, nl), dim3(192), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
+            else if (nslot == 6)                                                                                      \
+            NLG_LAUNCH((k_axhelm3r<N_, 6, false>), dim3(grid, nl), dim3(384), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
+                               m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
             else                                                                                                      \
             NLG_LAUNCH((k_axhelm3r<N_, 4, false>), dim3(grid, nl), dim3(256), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], \
                                m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
