@@ -75,7 +75,10 @@ def algorithmic_bytes(cls, E, n, dim, k, ncomp, lvs, lps, nshared, main_len, lor
     np1, np2 = n ** dim, n2 ** dim
     if cls == "opgradt":      # p + dim^2 metric terms in, dim velocity-mesh fields out
         return 8.0 * E * (np2 * (1 + dim * dim) + dim * np1)
-    if cls == "opdiv":        # dim fields + dim fused weights in, dim^2 metric terms, p out
+    if cls == "opdiv":        # dim fields + dim fused weights in, dim^2 metric terms, p out; 3-D: the weights are one array and a mask
+        # byte per point (k_opdiv3n, NLG_OPDIV_MASKB=0: dim arrays as before)
+        if dim == 3 and os.environ.get("NLG_OPDIV_MASKB", "1") != "0":
+            return 8.0 * E * (dim * np1 + 1.125 * np1 + np2 * (dim * dim + 1))
         return 8.0 * E * (2 * dim * np1 + np2 * (dim * dim + 1))
     if cls == "axhelm":       # NF = dim fields in/out, 6 (3) metric factors + mass; 3-D: the fused PCG direction
         ng = 6 if dim == 3 else 3   # update p <- z + beta p adds z in and p out

@@ -12,7 +12,7 @@ for n, s, e in rows:
     n = re.sub(r'\(anonymous namespace\)::', '', n).split('(')[0].replace('void ', '')
     key = n
     if n.startswith('k_gs<'):   # the layout of a gather-scatter dispatch follows from the kernel before it (scripts/pmc_traffic.py)
-        key = n + (' slab-permuted' if re.match(r'k_axhelm3rb?<.*true>|k_axhelm3c<\d+, true|k_rhs<\d+, true', prev) else ' face-grouped' if re.match(r'k_opgradt3<\d+, \d+, true|k_opgradt3n<\d+, true|k_fdm|k_sch|k_q1', prev) else ' natural')
+        key = n + (' slab-permuted' if re.match(r'k_axhelm3rb?<.*true>|k_axhelm3c<\d+, true|k_rhs<\d+, true', prev) else ' face-grouped' if re.match(r'k_opgradt3<\d+, \d+, true|k_opgradt3[nw]<\d+, true|k_fdm|k_sch|k_q1', prev) else ' natural')
     if not n.startswith('__amd') and not n.startswith('k_cg_final') and not n.startswith('k_cg_post'): prev = n
     if s < t0: continue
     a = agg.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += (e - s)
