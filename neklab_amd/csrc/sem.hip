@@ -3092,6 +3092,12 @@ __global__ __launch_bounds__(256, (ND > 16) ? 1 : 2) void k_conv3m(int64_t E, co
                 if (4 * rt + q < RF) out[4 * rt + q] = d[q];
         }
     };
+    // KEEPU: keep the transporting base flow Ur_j of this wave's column tiles in registers across the three velocity components m instead of
+    // re-reading it for every m (the PMC traffic of this kernel is 1.40 x its algorithmic bytes, and those re-reads are the difference).
+    // Measured at lx1 = 8 (194 registers, no spills): 420 - 432 -> 443 us -- the re-reads come from the Infinity Cache at no cost worth 54
+    // registers; at lxd = 15 it spills (78 registers).  Off.
+    constexpr bool KEEPU = false;
+    double buk[KEEPU ? NTZ : 1][3][RF];
     double acc[NTZ][3][RF];   // [column tile of this wave][output component][D register = fine level (lane >> 4) + 4 r]
 #pragma unroll
     for (int ti = 0; ti < NTZ; ++ti)
@@ -3156,17 +3162,18 @@ __global__ __launch_bounds__(256, (ND > 16) ? 1 : 2) void k_conv3m(int64_t E, co
                 const bool okc = ZF || col < CZ;
                 // base-flow values of the tile's points, requested before the matrix work: Ur_j and the three G of this component
                 const int64_t qb = e * NPD + col;
-                double bu[3][RF], bg[3][RF];
+                double bg[3][RF];
 #pragma unroll
                 for (int r = 0; r < RF; ++r) {
                     const bool ok = okc && (RFF || lg + 4 * r < ND);
                     const int64_t q = qb + (int64_t)CZ * (lg + 4 * r);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        bu[j][r] = ok ? Ur.p[j][q] : 0.0;
+                        if (KEEPU ? m == 0 : true) buk[KEEPU ? ti : 0][j][r] = ok ? Ur.p[j][q] : 0.0;   // KEEPU: the same for every component m, loaded once and kept
                         bg[j][r] = ok ? (adjoint ? GU.p[m * 3 + j][q] : GU.p[j * 3 + m][q]) : 0.0;   // multiplies uf_m in output component j
                     }
                 }
+                const double (&bu)[3][RF] = buk[KEEPU ? ti : 0];
                 double v0[KF], v1[KF], v2[KF];
 #pragma unroll
                 for (int ks = 0; ks < KF; ++ks) {
