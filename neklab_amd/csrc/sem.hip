@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(PBlockN<N>::NTB) void k_opdiv3n(int64_t E, const do
     __shared__ double sR[N2 * N * RS];
     __shared__ double red[2 * (NTB / 64)];
     const int tid = threadIdx.x;
-    const int64_t e = blockIdx.x;
+    const int64_t e = blockIdx.x;   // (elements in REVERSE order, to meet what the gradient kernel left in the Infinity Cache: this kernel 3.80 -> 3.47 ms per step, the step unchanged -- the next kernel pays; not adopted)
     for (int lv = 0; lv < (ML ? nl : 1); ++lv) {   // ML = false: the single-vector kernel (a runtime lane loop costs it 25 - 30 %)
         if (gatel.p[lv] && gatel.p[lv][0] != 0.0) continue;
         double acc[N2];
