@@ -1018,11 +1018,35 @@ int slab_ensure(nlg_linop *op, int cap) {
     if (op->slab && op->slab_cap >= cap) return 0;
     nlg_ctx *ctx = op->mesh->ctx;
     NLG_HIP(hipStreamSynchronize(ctx->stream));
-    const int64_t ld = lane_stride(op);
+    if (op->slab) NLG_HIP(hipFree(op->slab));   // (first: the old and the new slab need not exist together)
+    op->slab = nullptr;
+    op->slab_cap = 0;
+    // the direction rings (deferred solution update) are bandwidth bought with memory: where the slab does not fit with them -- a block of
+    // lanes next to a Krylov basis that fills the card -- they shrink and finally go (k_cg_update then updates x every iteration again)
+    int64_t ld = 0;
     double *nslab = nullptr;
-    NLG_HIP(hipMalloc(&nslab, sizeof(double) * (size_t)(ld * cap)));
+    for (;;) {
+        ld = lane_stride(op);
+        const bool rings = op->ph > 0 || op->php > 0;
+        if (hipMalloc(&nslab, sizeof(double) * (size_t)(ld * cap)) == hipSuccess) {
+            size_t free_b = 0, total_b = 0;
+            // with rings, a tenth of the card must stay free for what is allocated later (lane scratch of the pressure operator and of the
+            // preconditioner, solver work space): the rings are the one thing here that is optional
+            if (!rings || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= total_b / 10) break;
+            (void)hipFree(nslab);
+        } else {
+            (void)hipGetLastError();
+            NLG_CHECK(rings, "exptA: out of device memory for the work buffers of %d lane(s) (%.1f GB)", cap, 8e-9 * (double)(ld * cap));
+        }
+        nslab = nullptr;
+        if (op->php > 0)
+            op->php = 0;
+        else if (op->ph > 3)
+            op->ph = std::max(3, op->ph / 2);
+        else
+            op->ph = 0;
+    }
     NLG_HIP(hipMemsetAsync(nslab, 0, sizeof(double) * (size_t)(ld * cap), ctx->stream));
-    if (op->slab) NLG_HIP(hipFree(op->slab));
     op->slab = nslab;
     op->slab_ld = ld;
     op->slab_cap = cap;
