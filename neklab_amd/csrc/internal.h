@@ -177,6 +177,25 @@ inline int xp_slot(int N, int a, int j, int k) {
         sp_slab_table(N, tab.data());
         cachedN = N;
     }
+    // NLG_XP_LAYOUT=1 (lx1 = 8, experiment): a 128-byte line must not hold rows of two different FACES -- the two faces are summed by
+    // different blocks of the gather-scatter, on different XCDs, and each fetches the whole line (measured traffic 2.03 x algorithmic).
+    // Interior slabs 1..6 are interleaved in pairs, row by row: line r of a pair block = [row r of slab k | row r of slab k + 1], so the
+    // a = 0 rows of two consecutive slabs (same face) share a line; slabs 0 and 7 (z faces) hold their 36 face points, then the four
+    // edges, then the corners.  The operator kernels address through the element's slot table, so any permutation will do for them.
+    static const int mode = getenv("NLG_XP_LAYOUT") ? atoi(getenv("NLG_XP_LAYOUT")) : 0;
+    if (mode == 1 && N == 8) {
+        const int NS = N * N;
+        if (k >= 1 && k <= N - 2) {
+            const int t = tab[a + N * j], pair = (k - 1) / 2, half = (k - 1) % 2;
+            return NS + pair * 2 * NS + (t / 8) * 16 + half * 8 + (t % 8);
+        }
+        const int base = k == 0 ? 0 : NS + (N - 2) * NS;
+        const bool ia = a > 0 && a < N - 1, ij = j > 0 && j < N - 1;
+        if (ia && ij) return base + (a - 1) + (N - 2) * (j - 1);
+        if (!ia && !ij) return base + 60 + (a == 0 ? 0 : 1) + 2 * (j == 0 ? 0 : 1);
+        const int edge = !ia ? (a == 0 ? 0 : 1) : (j == 0 ? 2 : 3);
+        return base + 36 + edge * 6 + (!ia ? j - 1 : a - 1);
+    }
     return N * N * k + tab[a + N * j];
 }
 

@@ -676,9 +676,12 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     const int i = ij % N, j = ij / N;
     const int64_t eoff = (e < E ? e : 0) * NP;
     const int base = ij;   // offset inside the element, natural layout (metric factors)
-    // field offsets inside the element: vb + k * vs
-    const int vb = XP ? xptab[ij] : ij;   // slab-permuted layout: position inside the slab from the table (internal.h sp_slab_table)
-    constexpr int vs = NS;
+    // field offsets inside the element: vk[k]
+    int vk[N];   // field offsets inside the element; slab-permuted layout: from the element's slot table (internal.h xp_slot), any permutation
+    const int gen = XP ? xptab[N * N * N] : 0;   // entry N^3 of the table: 1 = general permutation, 0 = every slab permuted alike (one entry per lane)
+    const int v0 = XP ? xptab[ij] : ij;
+#pragma unroll
+    for (int k = 0; k < N; ++k) vk[k] = gen ? xptab[ij + NS * k] : v0 + NS * k;
     const double *uc = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2])) + eoff;
     double *wc = (c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2])) + eoff;
     const double *zc = (c == 0 ? zf.p[0] : (c == 1 ? zf.p[1] : zf.p[2])) + eoff;
@@ -692,15 +695,15 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
         double zk[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            uk[k] = act ? uc[vb + k * vs] : 0.0;
-            zk[k] = (upd && act) ? zc[vb + k * vs] : 0.0;
+            uk[k] = act ? uc[vk[k]] : 0.0;
+            zk[k] = (upd && act) ? zc[vk[k]] : 0.0;
             wk[k] = 0.0;
         }
         if (upd && act) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 uk[k] = zk[k] + beta * uk[k];
-                const_cast<double *>(uc)[uoff + vb + k * vs] = uk[k];
+                const_cast<double *>(uc)[uoff + vk[k]] = uk[k];
             }
         }
     }
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(64 * WPB) void k_axhelm3r(int64_t E, int nf, const 
     if (act) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            wc[vb + k * vs] = wk[k];
+            wc[vk[k]] = wk[k];
             pw += wk[k] * uk[k];
         }
     }
@@ -814,9 +817,12 @@ __global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const doub
     const int i = ij % N, j = ij / N;
     const int64_t eoff = (e < E ? e : 0) * NP;
     const int base = ij;   // offset inside the element, natural layout (metric factors)
-    // field offsets inside the element: vb + k * vs
-    const int vb = XP ? xptab[ij] : ij;   // slab-permuted layout: position inside the slab from the table (internal.h sp_slab_table)
-    constexpr int vs = NS;
+    // field offsets inside the element: vk[k]
+    int vk[N];   // field offsets inside the element; slab-permuted layout: from the element's slot table (internal.h xp_slot), any permutation
+    const int gen = XP ? xptab[N * N * N] : 0;   // entry N^3 of the table: 1 = general permutation, 0 = every slab permuted alike (one entry per lane)
+    const int v0 = XP ? xptab[ij] : ij;
+#pragma unroll
+    for (int k = 0; k < N; ++k) vk[k] = gen ? xptab[ij + NS * k] : v0 + NS * k;
     const double *uc = L.u[lv][c] + eoff;
     double *wc = L.w[lv][c] + eoff;
     const double *zc = L.z[lv][c] + eoff;
@@ -832,15 +838,15 @@ __global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const doub
         double zk[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            uk[k] = act ? uc[vb + k * vs] : 0.0;
-            zk[k] = (upd && act) ? zc[vb + k * vs] : 0.0;
+            uk[k] = act ? uc[vk[k]] : 0.0;
+            zk[k] = (upd && act) ? zc[vk[k]] : 0.0;
             wk[k] = 0.0;
         }
         if (upd && act) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 uk[k] = zk[k] + beta * uk[k];
-                const_cast<double *>(uc)[vb + k * vs] = uk[k];
+                const_cast<double *>(uc)[vk[k]] = uk[k];
             }
         }
     }
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(64 * 3 * NL) void k_axhelm3rb(int64_t E, const doub
     if (act) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            wc[vb + k * vs] = wk[k];
+            wc[vk[k]] = wk[k];
             pw += wk[k] * uk[k];
         }
     }
@@ -967,7 +973,11 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
     const int ij = act ? tid - pb * NS : 0;
     double *const mU = mUa[pb < PPB ? pb : 0], *const mR = mRa[pb < PPB ? pb : 0], *const mS = mSa[pb < PPB ? pb : 0];
     const int i = ij % N, j = ij / N;
-    const int pij = XP ? xptab[ij] : ij;   // slab-permuted layout: the vectors of the PCG; the metric arrays stay natural
+    int pk[N];   // slab-permuted layout (any permutation of the element, internal.h xp_slot): the vectors of the PCG; the metric arrays stay natural
+    const int gen = XP ? xptab[N * N * N] : 0;   // entry N^3 of the table: 1 = general permutation, 0 = every slab permuted alike
+    const int p0 = XP ? xptab[ij] : ij;
+#pragma unroll
+    for (int k = 0; k < N; ++k) pk[k] = gen ? xptab[ij + NS * k] : p0 + NS * k;
     const int64_t eoff = e * NP;
     const double *uc = (c == 0 ? u.p[0] : (c == 1 ? u.p[1] : u.p[2])) + eoff;
     double *wc = (c == 0 ? w.p[0] : (c == 1 ? w.p[1] : w.p[2])) + eoff;
@@ -980,15 +990,15 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
         double zk[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            uk[k] = act ? uc[pij + k * NS] : 0.0;
-            zk[k] = (upd && act) ? zc[pij + k * NS] : 0.0;
+            uk[k] = act ? uc[pk[k]] : 0.0;
+            zk[k] = (upd && act) ? zc[pk[k]] : 0.0;
             wk[k] = 0.0;
         }
         if (upd && act) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 uk[k] = zk[k] + beta * uk[k];
-                const_cast<double *>(uc)[uoff + pij + k * NS] = uk[k];
+                const_cast<double *>(uc)[uoff + pk[k]] = uk[k];
             }
         }
     }
@@ -1039,7 +1049,7 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
     if (act) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            wc[pij + k * NS] = wk[k];
+            wc[pk[k]] = wk[k];
             pw += wk[k] * uk[k];
         }
     }
@@ -4753,8 +4763,14 @@ int nlg_mesh_create(nlg_ctx *ctx, const nlg_mesh_desc *d, nlg_mesh **out) {
             std::vector<int> slot((size_t)m->np1);
             for (int p = 0; p < m->np1; ++p) slot[p] = xp_slot(n, p % n, (p / n) % n, p / (n * n));
             m->h_slot_xp = slot;
-            NLG_HIP(hipMalloc(&m->d_slot_xp, sizeof(int) * slot.size()));
-            NLG_HIP(hipMemcpy(m->d_slot_xp, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
+            {   // device copy with one more entry: 1 = the slabs of an element are NOT all permuted alike (the operator kernels then look every point up)
+                std::vector<int> dev(slot);
+                int general = 0;
+                for (int p = 0; p < m->np1; ++p) general |= (slot[p] != slot[p % (n * n)] + (p / (n * n)) * n * n);
+                dev.push_back(general);
+                NLG_HIP(hipMalloc(&m->d_slot_xp, sizeof(int) * dev.size()));
+                NLG_HIP(hipMemcpy(m->d_slot_xp, dev.data(), sizeof(int) * dev.size(), hipMemcpyHostToDevice));
+            }
             if (!groups.empty()) {
                 std::vector<std::vector<int>> gl(groups.size());
                 for (size_t gi = 0; gi + 1 < off.size(); ++gi) {
