@@ -323,14 +323,19 @@ __global__ __launch_bounds__(NT) void k_add_hist(const double *__restrict__ s, i
             const int64_t e = i / np;
             q = e * np + slot[(int)(i - e * np)];
         }
+        // the components side by side, four directions per trip: 4 NF independent loads in flight per lane (the sums stay per component, in
+        // iteration order)
+        double t[NF];
 #pragma unroll
-        for (int c = 0; c < NF; ++c) {
-            const double *__restrict__ pc = H.p0[c] + lo + q;
-            double t = w0 > 0 ? x.p[c][q] : 0.0;   // x holds the full windows, if there were any
+        for (int c = 0; c < NF; ++c) t[c] = w0 > 0 ? x.p[c][q] : 0.0;   // x holds the full windows, if there were any
 #pragma unroll 4
-            for (int k = 0; k < cnt; ++k) t += s[S_AH + ((w0 + k) & (kAlphaRing - 1))] * pc[k * H.stride];
-            y.p[c][i] = a.p[c] ? a.p[c][i] + t : t;   // (a == null: the solution itself, the pressure solve)
+        for (int k = 0; k < cnt; ++k) {
+            const double al = s[S_AH + ((w0 + k) & (kAlphaRing - 1))];
+#pragma unroll
+            for (int c = 0; c < NF; ++c) t[c] += al * H.p0[c][lo + q + k * H.stride];
         }
+#pragma unroll
+        for (int c = 0; c < NF; ++c) y.p[c][i] = a.p[c] ? a.p[c][i] + t[c] : t[c];   // (a == null: the solution itself, the pressure solve)
     }
 }
 
