@@ -183,6 +183,7 @@ inline int xp_slot(int N, int a, int j, int k) {
     // a = 0 rows of two consecutive slabs (same face) share a line; slabs 0 and 7 (z faces) hold their 36 face points, then the four
     // edges, then the corners.  The operator kernels address through the element's slot table, so any permutation will do for them.
     static const int mode = getenv("NLG_XP_LAYOUT") ? atoi(getenv("NLG_XP_LAYOUT")) : 0;
+    if (mode == 2) return fg_slot(N, a, j, k);   // (experiment: the face-grouped layout of the pressure operator for the velocity PCG too)
     if (mode == 1 && N == 8) {
         const int NS = N * N;
         if (k >= 1 && k <= N - 2) {
