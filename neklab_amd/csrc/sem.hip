@@ -943,7 +943,7 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
                                                                         const double *__restrict__ G4, const double *__restrict__ G5,
                                                                         const double *__restrict__ bm1, CF3 u, F3 w, double h1, double h2,
                                                                         double *__restrict__ pw_part, CF3 zf, const double *__restrict__ beta_p,
-                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld, int64_t uoff) {
+                                                                        const double *__restrict__ done_p, const int *__restrict__ xptab, int64_t ld, int64_t uoff, int xcd_map) {
     constexpr int NP = N * N * N, NS = N * N, NQ = N + 1, NTB = ((PPB * NS + 63) / 64) * 64, NWB = NTB / 64;
     __shared__ double sD[NS];
     __shared__ double mUa[PPB][N * NQ], mRa[PPB][N * NQ], mSa[PPB][N * NQ];
@@ -968,8 +968,20 @@ __global__ __launch_bounds__(((PPB * N * N + 63) / 64) * 64) void k_axhelm3c(int
     const int64_t pair = (int64_t)blockIdx.x * PPB + (pb < PPB ? pb : 0);
     const bool act = pb < PPB && pair < E * nf;
     const int64_t pr_ = act ? pair : 0;
-    const int64_t e = pr_ / nf;
-    const int c = (int)(pr_ % nf);
+    int64_t e = pr_ / nf;
+    int c = (int)(pr_ % nf);
+    if (PPB == 1 && nf == 3 && xcd_map) {
+        // one pair per block (lx1 = 10): blocks go to the XCDs round-robin, so the three components of an element -- which read the same seven
+        // metric arrays -- are given block numbers that are equal modulo 8: they run on ONE XCD, close in time, and share its L2
+        // (groups of 8 elements x 3 components = 24 consecutive blocks; the elements behind the last full group keep the plain order)
+        const int64_t full = (E / 8) * 24;
+        if (pr_ < full) {
+            const int64_t q = pr_ / 24;
+            const int r = (int)(pr_ % 24);
+            e = 8 * q + (r & 7);
+            c = r >> 3;
+        }
+    }
     const int ij = act ? tid - pb * NS : 0;
     double *const mU = mUa[pb < PPB ? pb : 0], *const mR = mRa[pb < PPB ? pb : 0], *const mS = mSa[pb < PPB ? pb : 0];
     const int i = ij % N, j = ij / N;
@@ -3812,18 +3824,19 @@ int sem_axhelm(nlg_mesh *m, double *const *u, double *const *w, int nf, double h
         else                                                                                                          \
         {                                                                                                             \
             constexpr int PPB_ = 3;                                                                    \
+            static const int xcd3c = !(getenv("NLG_AXHELM_XCD") && atoi(getenv("NLG_AXHELM_XCD")) == 0);              \
             const bool one = axhelm3c_ppb(N_) == 1;                                                                   \
             const unsigned gb = (unsigned)((tot + (one ? 1 : PPB_) - 1) / (one ? 1 : PPB_));                          \
             if (one) {                                                                                                \
                 if (xp)                                                                                               \
-                    NLG_LAUNCH((k_axhelm3c<N_, true, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
+                    NLG_LAUNCH((k_axhelm3c<N_, true, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff, xcd3c); \
                 else                                                                                                  \
-                    NLG_LAUNCH((k_axhelm3c<N_, false, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
+                    NLG_LAUNCH((k_axhelm3c<N_, false, 1>), dim3(gb, nl), dim3(((N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff, xcd3c); \
             } else {                                                                                                  \
                 if (xp)                                                                                               \
-                    NLG_LAUNCH((k_axhelm3c<N_, true, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff); \
+                    NLG_LAUNCH((k_axhelm3c<N_, true, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)m->d_slot_xp, ld, uoff, xcd3c); \
                 else                                                                                                  \
-                    NLG_LAUNCH((k_axhelm3c<N_, false, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff); \
+                    NLG_LAUNCH((k_axhelm3c<N_, false, PPB_>), dim3(gb, nl), dim3(((PPB_ * N_ * N_ + 63) / 64) * 64), 0, s, m->E, nf, m->d_D, m->d_G[0], m->d_G[1], m->d_G[2], m->d_G[3], m->d_G[4], m->d_G[5], m->d_bm1, cu, cw, h1, h2, pw_part, cz, beta_p, done_p, (const int *)nullptr, ld, uoff, xcd3c); \
             }                                                                                                         \
         }                                                                                                             \
     }
